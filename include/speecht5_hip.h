@@ -1,0 +1,165 @@
+/*
+ * libspeecht5_hip.so -- C ABI of the MI355X (gfx950) SpeechT5 forward/backward hot path.
+ *
+ * The reference (microsoft/SpeechT5) has no FFI: its hot path is PyTorch op call sites inside
+ * SpeechT5/speecht5/models/modules/[module].py.  Each entry point below replaces
+ * the torch op(s) at the cited reference call site; INTEGRATION.md shows the ctypes stub that a
+ * reference maintainer would add.  Conventions:
+ *   - plain pointers + sizes, caller-owned device buffers, no torch types;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
+ *   - `dtype` is ST5_F32 (0) or ST5_BF16 (1): the element type of activations/weights;
+ *     statistics, softmax, accumulators, biases, LayerNorm affine params and weight gradients are fp32;
+ *   - return value 0 = ok, non-zero = ST5_ERR_* (argument / alignment / launch error).
+ */
+#ifndef SPEECHT5_HIP_H
+#define SPEECHT5_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST5_F32 0
+#define ST5_BF16 1
+
+#define ST5_ACT_NONE 0
+#define ST5_ACT_GELU 1
+#define ST5_ACT_RELU 2
+#define ST5_ACT_TANH 3
+
+/* gemm flags */
+#define ST5_GEMM_A_KSTRIDED 1  /* A(i,k) stored k-outer (i contiguous): "transposed" operand      */
+#define ST5_GEMM_B_KSTRIDED 2  /* B(j,k) stored k-outer (j contiguous)                            */
+#define ST5_GEMM_OUT_F32 4     /* C / R are fp32 regardless of dtype (weight gradients)           */
+#define ST5_GEMM_DACT 8        /* multiply result by act'(P) (P = saved pre-activation, C layout) */
+
+/* Generalised operand addressing (elements):
+ *   off(outer, inner) = (rpb ? (outer / rpb) * bstride + (outer % rpb) * ld : outer * ld)
+ *                     + (seg ? (inner / seg) * seg_stride + inner % seg : inner)
+ *                     + (z / zdiv) * zs0 + (z % zdiv) * zs1            (z = batch index)
+ * K-major operand: outer = row (i or j), inner = k.  K-strided operand: outer = k, inner = row.
+ * This one descriptor covers nn.Linear fwd/dgrad/wgrad, strided / grouped conv1d as implicit GEMM
+ * on channels-last activations (overlapping rows: ld = stride*C, inner spans k*C), and the
+ * per-(batch,head) attention matmuls. */
+typedef struct st5_operand {
+  const void* ptr;
+  int64_t ld;
+  int32_t rpb;
+  int32_t seg;
+  int64_t bstride;
+  int64_t seg_stride;
+  int64_t zs0, zs1;
+} st5_operand;
+
+typedef struct st5_gemm_params {
+  st5_operand A;    /* [M x K] */
+  st5_operand B;    /* [N x K] (nn.Linear weight layout when K-major) */
+  st5_operand C;    /* [M x N] output; outer = row, inner = col */
+  st5_operand R;    /* optional residual added to the output (ptr may be NULL), C layout */
+  st5_operand P;    /* optional pre-activation for ST5_GEMM_DACT, C layout */
+  st5_operand Cpre; /* optional second output receiving the pre-activation value, C layout */
+  const float* bias; /* optional fp32 [N] (+ z * bias_zs) */
+  int64_t bias_zs;
+  int32_t M, N, K;
+  int32_t batch, zdiv;
+  int32_t act;      /* ST5_ACT_* applied after bias */
+  int32_t flags;
+  float alpha;      /* scales A*B before bias */
+  float beta;       /* C = result + beta * C_old (0 => C_old not read) */
+  float dropout_p;  /* dropout applied last (after act, before residual); 0 => off */
+  uint64_t seed;    /* dropout RNG seed; element counter = z*M*N + row*N + col */
+} st5_gemm_params;
+
+/* Generic MFMA GEMM: C = drop(act(alpha * A.B^T + bias)) [* act'(P)] + R + beta*C.
+ * Replaces F.linear at multihead_attention.py:213-231,397; transformer_layer.py:127-131,385-389;
+ * speech_encoder_prenet.py:177; F.conv1d at speech_encoder_prenet.py:300 (layers 1..6) and :107
+ * (pos_conv); torch.bmm at multihead_attention.py:340,389; and their autograd backward passes. */
+int st5_gemm(const st5_gemm_params* p, int dtype, void* stream);
+
+/* ---- row-wise normalisation (encoder.py:226, transformer_layer.py:124,132, speech_encoder_prenet.py:174) */
+/* y = LN(x) * gamma + beta over the last dim (cols); saves mean/rstd (fp32 [rows]). */
+int st5_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                      float* rstd, int64_t rows, int32_t cols, float eps, int dtype, void* stream);
+/* dx; dgamma/dbeta are ACCUMULATED (+=) into fp32 [cols]; ws >= st5_layernorm_bwd_ws_bytes(). */
+int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                      const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws,
+                      int64_t rows, int32_t cols, int dtype, void* stream);
+int64_t st5_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols);
+
+/* ---- attention probabilities (multihead_attention.py:343-386) ----
+ * scores [BH, T, lds] (dtype) hold alpha*q.k^T; qp [BH, T, nb] (dtype) holds alpha*q.pe^T (may be NULL);
+ * P[bh,i,j] = softmax_j(scores + qp[bh,i,clip(i-j,-maxrel,maxrel-1)+maxrel] + causal + key-padding(-inf)).
+ * Writes probs (dtype, [BH,T,lds], pad cols zeroed) and, when dropout_p > 0, probs_drop (dropout applied).
+ * kpm: uint8 [B, S] (1 = padded key) or NULL.  H = heads (bh = b*H + h). */
+int st5_softmax_fwd(const void* scores, const void* qp, const uint8_t* kpm, void* probs, void* probs_drop,
+                    int32_t BH, int32_t H, int32_t T, int32_t S, int32_t lds, int32_t nb, int32_t maxrel,
+                    int32_t causal, float dropout_p, uint64_t seed, int dtype, void* stream);
+/* dS = P * (dP' - sum_j dP'_j P_j), dP' = dropout'(dP) (+ dP_extra fp32 on the un-dropped probs);
+ * dqp[bh,i,b] (dtype, fully written by the kernel) = sum_{j: bucket(i-j)=b} dS[bh,i,j]. dS overwrites dP. */
+int st5_softmax_bwd(void* dP_inout, const void* probs, const float* dP_extra, void* dqp, int32_t BH, int32_t T,
+                    int32_t S, int32_t lds, int32_t nb, int32_t maxrel, float dropout_p, uint64_t seed, int dtype,
+                    void* stream);
+
+/* ---- speech pre-net layer 0: Conv1d(1->C,k,stride,no bias) + GroupNorm(C groups) + GELU
+ *      (speech_encoder_prenet.py:300,323-324).  wav fp32 [B,S]; out channels-last [B,L,C] (dtype);
+ *      stats fp32 [B,C,2] = (mean, rstd) saved for backward.  ws >= st5_conv0_ws_bytes. */
+int st5_conv0_gn_gelu_fwd(const float* wav, const float* w, const float* gamma, const float* beta, void* out,
+                          float* stats, void* ws, int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride,
+                          float eps, int dtype, void* stream);
+/* dY channels-last (dtype).  Accumulates (+=) dw [C,k], dgamma [C], dbeta [C] (fp32), scaled by gscale. */
+int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const float* gamma, const float* beta,
+                          const float* stats, const void* dY, float* dw, float* dgamma, float* dbeta, void* ws,
+                          int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride, float gscale, int dtype,
+                          void* stream);
+int64_t st5_conv0_ws_bytes(int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride);
+
+/* ---- element-wise / reductions (glue ops fused where the reference has separate torch calls) */
+/* dst(dtype) = src(fp32), optionally transposed: src [rows, cols] -> dst [cols, rows] */
+int st5_cast_from_f32(const float* src, void* dst, int64_t rows, int64_t cols, int32_t transpose, int dtype,
+                      void* stream);
+int st5_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream);
+/* out[c] (+)= scale * sum_r x[r, c]   (bias gradients); ws >= st5_colsum_ws_bytes(rows, cols) */
+int st5_colsum_ws(const void* x, float* out, void* ws, int64_t rows, int32_t cols, int64_t ld, float scale,
+                  int32_t accumulate, int dtype, void* stream);
+int64_t st5_colsum_ws_bytes(int64_t rows, int32_t cols);
+/* out[0] (+)= scale * sum(x^2)   (features_pen, speech_encoder_prenet.py:172) */
+int st5_sumsq(const void* x, float* out, int64_t n, float scale, int32_t accumulate, int dtype, void* stream);
+/* y = a*x + b*y */
+int st5_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, void* stream);
+/* y = act(x) ; dx = dy * act'(x) */
+int st5_act_fwd(const void* x, void* y, int64_t n, int32_t act, int dtype, void* stream);
+int st5_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int32_t act, int dtype, void* stream);
+/* y = dropout(x) with the library's counter RNG (same generator as the GEMM epilogue) */
+int st5_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* x[r,:] = v (fp32 [cols]) where mask[r] != 0  (apply_hubert_mask, speech_encoder_prenet.py:249) */
+int st5_masked_fill_rows(void* x, const uint8_t* mask, const float* v, int64_t rows, int32_t cols, int dtype,
+                         void* stream);
+/* dv[c] += sum_{r: mask[r]} dx[r,c]; dx[r,:] = 0 where mask[r] */
+int st5_masked_fill_rows_bwd(void* dx, const uint8_t* mask, float* dv, int64_t rows, int32_t cols, int dtype,
+                             void* stream);
+/* y[r,:] = x[r,:] + scale * table[idx[r], :]   (table fp32 [n, cols]); idx int32 [rows] */
+int st5_add_table_rows(const void* x, const float* table, const int32_t* idx, void* y, int64_t rows, int32_t cols,
+                       float scale, int dtype, void* stream);
+/* y[r,:] = emb_scale * table[tok[r],:] + pos_scale * pos[pidx[r],:]   (embedding + positions) */
+int st5_embed_rows(const float* table, const int32_t* tok, const float* pos, const int32_t* pidx, void* y,
+                   int64_t rows, int32_t cols, float emb_scale, float pos_scale, int dtype, void* stream);
+/* dtable[tok[r],:] += scale * dy[r,:]  (fp32 atomics) */
+int st5_embed_rows_bwd(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, float scale,
+                       int dtype, void* stream);
+/* zero-padded copy: dst [B, pad_l + T + pad_r, C] <- src [B, T, C] */
+int st5_pad_time(const void* src, void* dst, int32_t B, int32_t T, int32_t C, int32_t pad_l, int32_t pad_r,
+                 int dtype, void* stream);
+
+/* ---- losses ---- */
+/* Row-wise (label-smoothed) cross entropy on logits [rows, ld] (dtype, first V cols valid).
+ * loss_sum[0] += sum_r w_r * ((1-eps)*nll_r + eps/V... ) following speech_to_text_loss.py:93-110;
+ * target < 0 or == ignore_index rows are skipped.  Also writes dlogits = scale * dloss/dlogits. */
+int st5_cross_entropy(const void* logits, const int32_t* target, float* loss_sum, float* nll_sum, void* dlogits,
+                      int64_t rows, int32_t V, int64_t ld, float label_smoothing, int32_t ignore_index,
+                      float grad_scale, int dtype, void* stream);
+
+const char* st5_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

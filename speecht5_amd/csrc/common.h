@@ -1,0 +1,136 @@
+// Shared device helpers for the SpeechT5 gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ST5_OK 0
+#define ST5_ERR_ARG 1
+#define ST5_ERR_ALIGN 2
+#define ST5_ERR_LAUNCH 3
+
+#define ST5_F32 0
+#define ST5_BF16 1
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VEC = 4;  // elements per 16 bytes
+  __device__ static float to_f(float v) { return v; }
+  __device__ static float from_f(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static float to_f(bf16_t v) { return (float)v; }
+  __device__ static bf16_t from_f(float v) { return (bf16_t)v; }
+};
+
+__device__ __forceinline__ float bf16_bits_to_f(unsigned int lo16) {
+  return __uint_as_float(lo16 << 16);
+}
+
+// Load `n` (<= 8) consecutive elements as floats; 16-byte vector path when full & aligned.
+template <typename T>
+__device__ __forceinline__ void load8f(const T* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load8f<float>(const float* p, float (&v)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+template <>
+__device__ __forceinline__ void load8f<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  u32x4 a = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(a[i] << 16);
+    v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8f(T* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store8f<float>(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <>
+__device__ __forceinline__ void store8f<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GELU as torch.nn.GELU() / fairseq "gelu" in fp32
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+#define ACT_NONE 0
+#define ACT_GELU 1
+#define ACT_RELU 2
+#define ACT_TANH 3
+
+__device__ __forceinline__ float act_f(int act, float x) {
+  switch (act) {
+    case ACT_GELU: return gelu_f(x);
+    case ACT_RELU: return x > 0.f ? x : 0.f;
+    case ACT_TANH: return tanhf(x);
+    default: return x;
+  }
+}
+// derivative given the PRE-activation value
+__device__ __forceinline__ float act_grad_f(int act, float x) {
+  switch (act) {
+    case ACT_GELU: return gelu_grad_f(x);
+    case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case ACT_TANH: { float t = tanhf(x); return 1.f - t * t; }
+    default: return 1.f;
+  }
+}
+
+// Counter-based RNG for dropout: one 32-bit hash per element index (murmur3 finalizer over a
+// 64-bit counter mixed with the seed).  keep = u >= p * 2^32.  The same (seed, index) is
+// re-evaluated in the backward pass, so no mask is stored.
+__device__ __forceinline__ unsigned int rng_hash(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (unsigned int)(z >> 16);
+}
+__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned long long idx,
+                                               unsigned int thresh, float inv_keep) {
+  return rng_hash(seed, idx) >= thresh ? inv_keep : 0.f;
+}
+
+#define HIP_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e_ = hipGetLastError();                       \
+    if (e_ != hipSuccess) return ST5_ERR_LAUNCH;             \
+  } while (0)

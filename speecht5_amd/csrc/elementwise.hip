@@ -1,0 +1,437 @@
+// Element-wise, gather/scatter and small reduction kernels of the SpeechT5 hot path (HBM-bound;
+// 16-byte vector IO, grid-stride).  Each replaces a torch call site cited in include/speecht5_hip.h.
+#include "common.h"
+#include "../../include/speecht5_hip.h"
+
+namespace {
+
+inline dim3 grid_for(long long nvec) {
+  long long b = (nvec + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+// ---- casts ----
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
+  const long long nv = n / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    load8f<float>(src + i * 8, v);
+    store8f<T>(dst + i * 8, v);
+  }
+  for (long long i = nv * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    dst[i] = Elem<T>::from_f(src[i]);
+}
+// dst[c, r] = src[r, c] via a 32x32 LDS tile
+template <typename T>
+__global__ void cast_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, long long rows,
+                                      long long cols) {
+  __shared__ float tile[32][33];
+  const long long r0 = (long long)blockIdx.y * 32, c0 = (long long)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const long long r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < rows && c < cols) ? src[r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const long long c = c0 + j, r = r0 + tx;
+    if (c < cols && r < rows) dst[c * rows + r] = Elem<T>::from_f(tile[tx][j]);
+  }
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, long long n) {
+  const long long nv = n / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    load8f<T>(src + i * 8, v);
+    store8f<float>(dst + i * 8, v);
+  }
+  for (long long i = nv * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    dst[i] = Elem<T>::to_f(src[i]);
+}
+
+// ---- generic unary / binary element-wise with a functor on 8-vectors ----
+template <typename T, typename F>
+__global__ void map1_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, F f) {
+  const long long nv = n / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    load8f<T>(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f(v[e], i * 8 + e);
+    store8f<T>(y + i * 8, v);
+  }
+  for (long long i = nv * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    y[i] = Elem<T>::from_f(f(Elem<T>::to_f(x[i]), i));
+}
+template <typename T, typename F>
+__global__ void map2_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n, F f) {
+  const long long nv = n / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    float u[8], v[8];
+    load8f<T>(a + i * 8, u);
+    load8f<T>(b + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] = f(u[e], v[e]);
+    store8f<T>(y + i * 8, u);
+  }
+  for (long long i = nv * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    y[i] = Elem<T>::from_f(f(Elem<T>::to_f(a[i]), Elem<T>::to_f(b[i])));
+}
+
+struct ActF { int act; __device__ float operator()(float x, long long) const { return act_f(act, x); } };
+struct ActB { int act; __device__ float operator()(float dy, float x) const { return dy * act_grad_f(act, x); } };
+struct Axpby { float a, b; __device__ float operator()(float x, float y) const { return a * x + b * y; } };
+struct Drop {
+  unsigned long long seed; unsigned int thresh; float inv_keep;
+  __device__ float operator()(float x, long long i) const { return x * dropout_scale(seed, (unsigned long long)i, thresh, inv_keep); }
+};
+
+// ---- sum of squares ----
+template <typename T>
+__global__ void sumsq_kernel(const T* __restrict__ x, float* __restrict__ part, long long n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long long nv = n / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    load8f<T>(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(v[e], v[e], s);
+  }
+  for (long long i = nv * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float v = Elem<T>::to_f(x[i]);
+    s = fmaf(v, v, s);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int n, float scale,
+                                 int accumulate) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)part[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float r = (float)((red[0] + red[1] + red[2] + red[3]) * (double)scale);
+    out[0] = accumulate ? out[0] + r : r;
+  }
+}
+
+// ---- row ops: one wave per row ----
+template <typename T>
+__global__ void masked_fill_rows_kernel(T* __restrict__ x, const uint8_t* __restrict__ mask,
+                                        const float* __restrict__ v, long long rows, int cols) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows || !mask[row]) return;
+  for (int c = threadIdx.x & 63; c < cols; c += 64) x[row * cols + c] = Elem<T>::from_f(v[c]);
+}
+// dv[c] += sum_{masked rows} dx[r,c]; dx[r,:] = 0 for masked rows.  Grid over column blocks.
+template <typename T>
+__global__ void masked_fill_rows_bwd_kernel(T* __restrict__ dx, const uint8_t* __restrict__ mask,
+                                            float* __restrict__ dv, long long rows, int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (long long r = 0; r < rows; ++r) {
+    if (mask[r]) {
+      s += Elem<T>::to_f(dx[r * cols + c]);
+      dx[r * cols + c] = Elem<T>::from_f(0.f);
+    }
+  }
+  if (dv) dv[c] += s;
+}
+template <typename T>
+__global__ void add_table_rows_kernel(const T* __restrict__ x, const float* __restrict__ table,
+                                      const int32_t* __restrict__ idx, T* __restrict__ y, long long rows, int cols,
+                                      float scale) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* trow = table + (long long)idx[row] * cols;
+  for (int c = (threadIdx.x & 63) * 8; c < cols; c += 512) {
+    if (c + 8 <= cols) {
+      float v[8], t[8];
+      load8f<T>(x + row * cols + c, v);
+      load8f<float>(trow + c, t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(scale, t[e], v[e]);
+      store8f<T>(y + row * cols + c, v);
+    } else {
+      for (int e = 0; c + e < cols; ++e)
+        y[row * cols + c + e] = Elem<T>::from_f(Elem<T>::to_f(x[row * cols + c + e]) + scale * trow[c + e]);
+    }
+  }
+}
+template <typename T>
+__global__ void embed_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ tok,
+                                  const float* __restrict__ pos, const int32_t* __restrict__ pidx,
+                                  T* __restrict__ y, long long rows, int cols, float emb_scale, float pos_scale) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* trow = table + (long long)tok[row] * cols;
+  const float* prow = pos ? pos + (long long)pidx[row] * cols : nullptr;
+  for (int c = threadIdx.x & 63; c < cols; c += 64) {
+    float v = emb_scale * trow[c];
+    if (prow) v = fmaf(pos_scale, prow[c], v);
+    y[row * cols + c] = Elem<T>::from_f(v);
+  }
+}
+template <typename T>
+__global__ void embed_rows_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ tok,
+                                      float* __restrict__ dtable, long long rows, int cols, float scale) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* trow = dtable + (long long)tok[row] * cols;
+  for (int c = threadIdx.x & 63; c < cols; c += 64)
+    atomicAdd(&trow[c], scale * Elem<T>::to_f(dy[row * cols + c]));
+}
+template <typename T>
+__global__ void pad_time_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int Tn, int C, int pad_l,
+                                int pad_r) {
+  const int Tp = pad_l + Tn + pad_r;
+  const long long nrow = (long long)B * Tp;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrow) return;
+  const int b = (int)(row / Tp), t = (int)(row % Tp) - pad_l;
+  const bool in = t >= 0 && t < Tn;
+  const T* s = src + ((long long)b * Tn + (in ? t : 0)) * C;
+  T* d = dst + row * C;
+  const T zero = Elem<T>::from_f(0.f);
+  for (int c = threadIdx.x & 63; c < C; c += 64) d[c] = in ? s[c] : zero;
+}
+
+// ---- cross entropy: one wave per row ----
+template <typename T>
+__global__ void cross_entropy_kernel(const T* __restrict__ logits, const int32_t* __restrict__ target,
+                                     float* __restrict__ loss_sum, float* __restrict__ nll_sum,
+                                     T* __restrict__ dlogits, long long rows, int V, long long ld, float eps,
+                                     int ignore_index, float grad_scale) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* lrow = logits + row * ld;
+  const int tgt = target[row];
+  const bool skip = tgt < 0 || tgt == ignore_index;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, Elem<T>::to_f(lrow[c]));
+  mx = wave_max(mx);
+  float se = 0.f, sl = 0.f;
+  for (int c = lane; c < V; c += 64) {
+    const float l = Elem<T>::to_f(lrow[c]);
+    if (l != -INFINITY) { se += __expf(l - mx); sl += l; }
+  }
+  se = wave_sum(se); sl = wave_sum(sl);
+  const float lse = mx + __logf(se);
+  // fairseq label_smoothed_nll_loss (speech_to_text_loss.py:93-110):
+  //   nll = -lprob[tgt]; smooth = -sum_c lprob[c]; loss = (1-eps-eps_i)*nll + eps_i*smooth, eps_i = eps/(V-1)
+  if (!skip) {
+    const float lt = Elem<T>::to_f(lrow[tgt]);
+    const float nll = lse - lt;
+    const float eps_i = V > 1 ? eps / (float)(V - 1) : 0.f;
+    const float smooth = (float)V * lse - sl;
+    if (lane == 0) {
+      atomicAdd(loss_sum, (1.f - eps - eps_i) * nll + eps_i * smooth);
+      if (nll_sum) atomicAdd(nll_sum, nll);
+    }
+  }
+  if (dlogits) {
+    T* drow = dlogits + row * ld;
+    const float eps_i = V > 1 ? eps / (float)(V - 1) : 0.f;
+    for (int c = lane; c < V; c += 64) {
+      float g = 0.f;
+      if (!skip) {
+        const float l = Elem<T>::to_f(lrow[c]);
+        const float p = l == -INFINITY ? 0.f : __expf(l - lse);
+        // d/dl_c [(1-eps-eps_i)*(lse - l_t) + eps_i*(V*lse - sum l)] = (1-eps-eps_i)(p - [c==t]) + eps_i (V p - 1)
+        g = (1.f - eps - eps_i) * (p - (c == tgt ? 1.f : 0.f)) + eps_i * ((float)V * p - 1.f);
+        if (l == -INFINITY) g = 0.f;
+      }
+      drow[c] = Elem<T>::from_f(g * grad_scale);
+    }
+    for (int c = V + lane; c < ld; c += 64) drow[c] = Elem<T>::from_f(0.f);
+  }
+}
+
+float* g_scratch = nullptr;  // 2048-float device scratch for block partials (lazily allocated)
+float* scratch() {
+  if (!g_scratch) { if (hipMalloc(&g_scratch, 2048 * sizeof(float)) != hipSuccess) return nullptr; }
+  return g_scratch;
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, CALL_BF, CALL_F)   \
+  if (dtype == ST5_BF16) { CALL_BF; }      \
+  else if (dtype == ST5_F32) { CALL_F; }   \
+  else return ST5_ERR_ARG;
+
+extern "C" int st5_cast_from_f32(const float* src, void* dst, int64_t rows, int64_t cols, int32_t transpose, int dtype,
+                                 void* stream) {
+  if (!src || !dst || rows < 0 || cols < 0) return ST5_ERR_ARG;
+  if (rows * cols == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (!transpose) {
+    const long long n = rows * cols;
+    DISPATCH(dtype, hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, grid_for(n / 8 + 1), dim3(256), 0, s, src, (bf16_t*)dst, n),
+             hipLaunchKernelGGL(cast_from_f32_kernel<float>, grid_for(n / 8 + 1), dim3(256), 0, s, src, (float*)dst, n));
+  } else {
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    DISPATCH(dtype, hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, (long long)rows, (long long)cols),
+             hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, (long long)rows, (long long)cols));
+  }
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream) {
+  if (!src || !dst || n < 0) return ST5_ERR_ARG;
+  if (n == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH(dtype, hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, grid_for(n / 8 + 1), dim3(256), 0, s, (const bf16_t*)src, dst, (long long)n),
+           hipLaunchKernelGGL(cast_to_f32_kernel<float>, grid_for(n / 8 + 1), dim3(256), 0, s, (const float*)src, dst, (long long)n));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_sumsq(const void* x, float* out, int64_t n, float scale, int32_t accumulate, int dtype, void* stream) {
+  if (!x || !out || n < 0) return ST5_ERR_ARG;
+  float* part = scratch();
+  if (!part) return ST5_ERR_LAUNCH;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid = grid_for(n / 8 + 1);
+  DISPATCH(dtype, hipLaunchKernelGGL(sumsq_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, part, (long long)n),
+           hipLaunchKernelGGL(sumsq_kernel<float>, grid, dim3(256), 0, s, (const float*)x, part, (long long)n));
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, s, part, out, (int)grid.x, scale, accumulate);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, void* stream) {
+  if (!x || !y || n < 0) return ST5_ERR_ARG;
+  if (n == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  Axpby f{a, b};
+  DISPATCH(dtype, hipLaunchKernelGGL((map2_kernel<bf16_t, Axpby>), grid_for(n / 8 + 1), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)y, (long long)n, f),
+           hipLaunchKernelGGL((map2_kernel<float, Axpby>), grid_for(n / 8 + 1), dim3(256), 0, s, (const float*)x, (const float*)y, (float*)y, (long long)n, f));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_act_fwd(const void* x, void* y, int64_t n, int32_t act, int dtype, void* stream) {
+  if (!x || !y || n < 0) return ST5_ERR_ARG;
+  if (n == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  ActF f{act};
+  DISPATCH(dtype, hipLaunchKernelGGL((map1_kernel<bf16_t, ActF>), grid_for(n / 8 + 1), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long long)n, f),
+           hipLaunchKernelGGL((map1_kernel<float, ActF>), grid_for(n / 8 + 1), dim3(256), 0, s, (const float*)x, (float*)y, (long long)n, f));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int32_t act, int dtype, void* stream) {
+  if (!dy || !x || !dx || n < 0) return ST5_ERR_ARG;
+  if (n == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  ActB f{act};
+  DISPATCH(dtype, hipLaunchKernelGGL((map2_kernel<bf16_t, ActB>), grid_for(n / 8 + 1), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, (long long)n, f),
+           hipLaunchKernelGGL((map2_kernel<float, ActB>), grid_for(n / 8 + 1), dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, (long long)n, f));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+  if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return ST5_ERR_ARG;
+  if (n == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  Drop f{(unsigned long long)seed, (unsigned int)((double)p * 4294967296.0), 1.f / (1.f - p)};
+  DISPATCH(dtype, hipLaunchKernelGGL((map1_kernel<bf16_t, Drop>), grid_for(n / 8 + 1), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long long)n, f),
+           hipLaunchKernelGGL((map1_kernel<float, Drop>), grid_for(n / 8 + 1), dim3(256), 0, s, (const float*)x, (float*)y, (long long)n, f));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_masked_fill_rows(void* x, const uint8_t* mask, const float* v, int64_t rows, int32_t cols, int dtype,
+                                    void* stream) {
+  if (!x || !mask || !v || rows < 0 || cols <= 0) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  DISPATCH(dtype, hipLaunchKernelGGL(masked_fill_rows_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)x, mask, v, (long long)rows, cols),
+           hipLaunchKernelGGL(masked_fill_rows_kernel<float>, grid, dim3(256), 0, s, (float*)x, mask, v, (long long)rows, cols));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_masked_fill_rows_bwd(void* dx, const uint8_t* mask, float* dv, int64_t rows, int32_t cols, int dtype,
+                                        void* stream) {
+  if (!dx || !mask || rows < 0 || cols <= 0) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((cols + 63) / 64));
+  DISPATCH(dtype, hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<bf16_t>, grid, dim3(64), 0, s, (bf16_t*)dx, mask, dv, (long long)rows, cols),
+           hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<float>, grid, dim3(64), 0, s, (float*)dx, mask, dv, (long long)rows, cols));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_add_table_rows(const void* x, const float* table, const int32_t* idx, void* y, int64_t rows,
+                                  int32_t cols, float scale, int dtype, void* stream) {
+  if (!x || !table || !idx || !y || rows < 0 || cols <= 0 || cols % 8) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  DISPATCH(dtype, hipLaunchKernelGGL(add_table_rows_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, table, idx, (bf16_t*)y, (long long)rows, cols, scale),
+           hipLaunchKernelGGL(add_table_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)x, table, idx, (float*)y, (long long)rows, cols, scale));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_embed_rows(const float* table, const int32_t* tok, const float* pos, const int32_t* pidx, void* y,
+                              int64_t rows, int32_t cols, float emb_scale, float pos_scale, int dtype, void* stream) {
+  if (!table || !tok || !y || rows < 0 || cols <= 0 || (pos && !pidx)) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  DISPATCH(dtype, hipLaunchKernelGGL(embed_rows_kernel<bf16_t>, grid, dim3(256), 0, s, table, tok, pos, pidx, (bf16_t*)y, (long long)rows, cols, emb_scale, pos_scale),
+           hipLaunchKernelGGL(embed_rows_kernel<float>, grid, dim3(256), 0, s, table, tok, pos, pidx, (float*)y, (long long)rows, cols, emb_scale, pos_scale));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_embed_rows_bwd(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols,
+                                  float scale, int dtype, void* stream) {
+  if (!dy || !tok || !dtable || rows < 0 || cols <= 0) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  DISPATCH(dtype, hipLaunchKernelGGL(embed_rows_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, tok, dtable, (long long)rows, cols, scale),
+           hipLaunchKernelGGL(embed_rows_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, tok, dtable, (long long)rows, cols, scale));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_pad_time(const void* src, void* dst, int32_t B, int32_t T, int32_t C, int32_t pad_l, int32_t pad_r,
+                            int dtype, void* stream) {
+  if (!src || !dst || B <= 0 || T <= 0 || C <= 0 || pad_l < 0 || pad_r < 0) return ST5_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long long nrow = (long long)B * (pad_l + T + pad_r);
+  dim3 grid((unsigned)((nrow + 3) / 4));
+  DISPATCH(dtype, hipLaunchKernelGGL(pad_time_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, B, T, C, pad_l, pad_r),
+           hipLaunchKernelGGL(pad_time_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, B, T, C, pad_l, pad_r));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_cross_entropy(const void* logits, const int32_t* target, float* loss_sum, float* nll_sum,
+                                 void* dlogits, int64_t rows, int32_t V, int64_t ld, float label_smoothing,
+                                 int32_t ignore_index, float grad_scale, int dtype, void* stream) {
+  if (!logits || !target || !loss_sum || rows < 0 || V <= 0 || ld < V) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  DISPATCH(dtype, hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)logits, target, loss_sum, nll_sum, (bf16_t*)dlogits, (long long)rows, V, (long long)ld, label_smoothing, ignore_index, grad_scale),
+           hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, dim3(256), 0, s, (const float*)logits, target, loss_sum, nll_sum, (float*)dlogits, (long long)rows, V, (long long)ld, label_smoothing, ignore_index, grad_scale));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+extern "C" const char* st5_version(void) { return "speecht5_hip 0.1 (gfx950)"; }

@@ -1,0 +1,428 @@
+// Generic MFMA GEMM for gfx950 (CDNA4): C = epilogue(alpha * A.B^T), A [M x K], B [N x K].
+//
+// One kernel family covers every matmul-shaped op of the SpeechT5 hot path through a generalised
+// operand descriptor (include/speecht5_hip.h): nn.Linear fwd/dgrad/wgrad, strided/grouped Conv1d as
+// implicit GEMM over channels-last activations, and the per-(batch,head) attention matmuls.
+//
+// Tiling (wave64): 256 threads = 4 waves (2x2), block tile 128x128, wave tile 64x64 = 2x2 MFMA
+// 32x32 tiles, k-tile = 128 bytes per row (64 bf16 / 32 f32).  Operands are staged
+// HBM -> registers -> LDS (double buffered, one barrier per k-tile).  The LDS image is
+// [row][8 x 16B chunks] with chunk' = chunk ^ ((row>>1)&7): conflict-free for the ds_read_b128
+// fragment reads of a 32-row MFMA operand (lane groups per MI355X_MICROARCH.md "LDS").
+// K-strided ("transposed") operands are transposed in registers on the way into LDS, so the MFMA
+// fragment reads are identical for all four layout combinations.
+// bf16 uses v_mfma_f32_32x32x16_bf16; f32 uses v_mfma_f32_32x32x2_f32 (exact f32, parity mode).
+// The epilogue goes through LDS so that bias/activation/residual/dropout are applied on 8
+// consecutive columns per lane and stored as 16-byte vectors.
+#include "common.h"
+#include "../../include/speecht5_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int TILE_BYTES = 128 * 128;  // one operand tile: 128 rows x 128 B
+constexpr int EP_LD = 68;              // floats per staged epilogue row (64 + 4 pad)
+
+// operand addressing, by value (no pointers into the kernarg struct => stays in SGPRs)
+struct OpAddr {
+  long long ld, bstride, seg_stride;
+  int rpb, seg;
+  __device__ __forceinline__ long long outer(int idx) const {
+    return rpb ? (long long)(idx / rpb) * bstride + (long long)(idx % rpb) * ld : (long long)idx * ld;
+  }
+  __device__ __forceinline__ long long inner(int idx) const {
+    return seg ? (long long)(idx / seg) * seg_stride + (idx % seg) : (long long)idx;
+  }
+};
+__device__ __forceinline__ OpAddr make_addr(long long ld, long long bstride, long long seg_stride, int rpb, int seg) {
+  OpAddr a; a.ld = ld; a.bstride = bstride; a.seg_stride = seg_stride; a.rpb = rpb; a.seg = seg;
+  return a;
+}
+__device__ __forceinline__ long long z_off(long long zs0, long long zs1, int z, int zdiv) {
+  return (long long)(z / zdiv) * zs0 + (long long)(z % zdiv) * zs1;
+}
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__device__ __forceinline__ unsigned int elem_bits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ unsigned int elem_bits(bf16_t v) {
+  return (unsigned int)__builtin_bit_cast(unsigned short, v);
+}
+// gather nvalid (< NE) consecutive elements into one 16-byte register, zero-filling the rest
+template <typename T, int NE>
+__device__ __forceinline__ u32x4 pack_tail(const T* p, int nvalid) {
+  u32x4 r = {0, 0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    if (e < nvalid) {
+      if constexpr (sizeof(T) == 4) r[e] = elem_bits(p[e]);
+      else r[e >> 1] |= elem_bits(p[e]) << ((e & 1) * 16);
+    }
+  }
+  return r;
+}
+
+// ---------------- K-major operand: rows contiguous along k ----------------
+template <typename T>
+struct LoaderKM {
+  static constexpr int VEC = Elem<T>::VEC;
+  const T* base;
+  OpAddr ad;
+  long long rowoff[4];
+  int chunk, rbase, K;
+  u32x4 r[4];
+  __device__ __forceinline__ void init(const OpAddr& a, const T* b, int row0, int limit, int K_, int tid) {
+    ad = a; base = b; K = K_;
+    chunk = tid & 7; rbase = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int row = row0 + rbase + 32 * p;
+      row = row < limit ? row : limit - 1;
+      rowoff[p] = ad.outer(row);
+    }
+  }
+  __device__ __forceinline__ void load(int k0) {
+    const int k = k0 + chunk * VEC;
+    if (k + VEC <= K) {
+      const long long ko = ad.inner(k);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const u32x4*>(base + rowoff[p] + ko);
+    } else if (k < K) {  // K tail (a VEC group never straddles a segment: seg % VEC == 0)
+      const long long ko = ad.inner(k);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) r[p] = pack_tail<T, VEC>(base + rowoff[p] + ko, K - k);
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) r[p] = u32x4{0, 0, 0, 0};
+    }
+  }
+  __device__ __forceinline__ void store(char* tile) const {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = rbase + 32 * p;
+      *reinterpret_cast<u32x4*>(tile + lds_off(row, chunk)) = r[p];
+    }
+  }
+};
+
+// ---------------- K-strided operand: rows contiguous along the row index ----------------
+// Thread block = VEC k-values x 4 rows; transposed in registers, written as 4 x 16 B.
+template <typename T>
+struct LoaderKS {
+  static constexpr int VEC = Elem<T>::VEC;
+  static constexpr int W = 4 * sizeof(T) / 4;  // dwords per 4-row load (2 for bf16, 4 for f32)
+  const T* base;  // already offset by the inner (row) index
+  OpAddr ad;
+  int kb, rb, K, nvalid;  // nvalid = valid rows of this thread's 4-row group (0..4)
+  unsigned int g[VEC][W];
+  __device__ __forceinline__ void init(const OpAddr& a, const T* b, int row0, int limit, int K_, int tid) {
+    ad = a; K = K_;
+    kb = tid >> 5; rb = tid & 31;
+    const int i0 = row0 + rb * 4;
+    nvalid = limit - i0; nvalid = nvalid > 4 ? 4 : (nvalid < 0 ? 0 : nvalid);
+    base = b + ad.inner(nvalid > 0 ? i0 : 0);
+  }
+  __device__ __forceinline__ void load(int k0) {
+    const int kf = k0 + kb * VEC;
+    int q = 0, rm = kf;
+    if (ad.rpb) { q = kf / ad.rpb; rm = kf % ad.rpb; }
+#pragma unroll
+    for (int kk = 0; kk < VEC; ++kk) {
+      const int k = kf + kk;
+      const long long oo = ad.rpb ? (long long)q * ad.bstride + (long long)rm * ad.ld : (long long)k * ad.ld;
+      if (k < K && nvalid == 4) {
+        if constexpr (W == 2) {
+          const u32x2 v = *reinterpret_cast<const u32x2*>(base + oo);
+          g[kk][0] = v[0]; g[kk][1] = v[1];
+        } else {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(base + oo);
+          g[kk][0] = v[0]; g[kk][1] = v[1]; g[kk][2] = v[2]; g[kk][3] = v[3];
+        }
+      } else if (k < K && nvalid > 0) {
+        const u32x4 tw = pack_tail<T, 4>(base + oo, nvalid);
+#pragma unroll
+        for (int w = 0; w < W; ++w) g[kk][w] = tw[w];
+      } else {
+#pragma unroll
+        for (int w = 0; w < W; ++w) g[kk][w] = 0u;
+      }
+      if (ad.rpb) { if (++rm == ad.rpb) { rm = 0; ++q; } }
+    }
+  }
+  __device__ __forceinline__ void store(char* tile) const {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      u32x4 o;
+      if constexpr (W == 2) {  // bf16: pick half (rr&1) of dword (rr>>1) from 8 k-rows
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const unsigned int a = g[2 * w][rr >> 1], b = g[2 * w + 1][rr >> 1];
+          o[w] = (rr & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+        }
+      } else {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o[w] = g[w][rr];
+      }
+      const int row = rb * 4 + rr;
+      *reinterpret_cast<u32x4*>(tile + lds_off(row, kb)) = o;
+    }
+  }
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x4 type; };
+
+template <typename T>
+__device__ __forceinline__ void mma(const typename Frag<T>::type& a, const typename Frag<T>::type& b, f32x16& c);
+template <>
+__device__ __forceinline__ void mma<bf16_t>(const bf16x8& a, const bf16x8& b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma<float>(const f32x4& a, const f32x4& b, f32x16& c) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], c, 0, 0, 0);
+}
+
+// predicated (static-index) tail accessors: arrays stay in registers
+template <typename U>
+__device__ __forceinline__ void load_vec(const U* p, bool full, int ne, float (&v)[8]) {
+  if (full) load8f<U>(p, v);
+  else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = e < ne ? Elem<U>::to_f(p[e]) : 0.f;
+  }
+}
+template <typename U>
+__device__ __forceinline__ void store_vec(U* p, bool full, int ne, const float (&v)[8]) {
+  if (full) store8f<U>(p, v);
+  else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < ne) p[e] = Elem<U>::from_f(v[e]);
+  }
+}
+
+struct EpiArgs {  // everything the epilogue needs, by value
+  void* C; const void* R; const void* P; void* Cpre; const float* bias;
+  long long c_ld, c_bs, r_ld, r_bs, p_ld, p_bs, q_ld, q_bs;
+  int rpb, M, N, act, out_f32, dact, c_vec_ok;
+  float alpha, beta, dropout_p;
+  unsigned long long seed, ctr_base;
+};
+
+__device__ __forceinline__ void stage_write(float* stage, const f32x16& acc0, const f32x16& acc1, const int lane) {
+  const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+    stage[row * EP_LD + frow] = acc0[r];
+    stage[row * EP_LD + 32 + frow] = acc1[r];
+  }
+}
+
+// Applies the fused epilogue to one staged 32x64 half of the wave tile.  Kept as a rolled loop
+// (the activation code is large); called from a rolled loop over the two halves.
+template <typename T>
+__device__ __forceinline__ void epilogue_rows(const EpiArgs& ea, const float* stage, const int mbase, const int nbase,
+                                              const int lane) {
+  const unsigned int thresh = ea.dropout_p > 0.f ? (unsigned int)((double)ea.dropout_p * 4294967296.0) : 0u;
+  const float inv_keep = ea.dropout_p > 0.f ? 1.f / (1.f - ea.dropout_p) : 1.f;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = pass * 8 + (lane >> 3), cc = (lane & 7) * 8;
+    const int gm = mbase + row, gn = nbase + cc;
+    if (gm < ea.M && gn < ea.N) {
+      float v[8];
+      {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + cc);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + cc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+      }
+      const int ne = (ea.N - gn) < 8 ? (ea.N - gn) : 8;
+      const bool full = (ne == 8) && ea.c_vec_ok;
+      // C-class operands share the row split `rpb` (each has its own ld / block stride)
+      int q = 0, rm = gm;
+      if (ea.rpb) { q = gm / ea.rpb; rm = gm % ea.rpb; }
+      const long long co = (long long)q * ea.c_bs + (long long)rm * ea.c_ld + gn;
+      float rv[8], pv[8], ov[8], pre[8];
+      if (ea.R) {
+        const long long ro = (long long)q * ea.r_bs + (long long)rm * ea.r_ld + gn;
+        if (ea.out_f32) load_vec<float>(reinterpret_cast<const float*>(ea.R) + ro, full, ne, rv);
+        else load_vec<T>(reinterpret_cast<const T*>(ea.R) + ro, full, ne, rv);
+      }
+      if (ea.dact) {
+        const long long po = (long long)q * ea.p_bs + (long long)rm * ea.p_ld + gn;
+        load_vec<T>(reinterpret_cast<const T*>(ea.P) + po, full, ne, pv);
+      }
+      if (ea.beta != 0.f) {
+        if (ea.out_f32) load_vec<float>(reinterpret_cast<const float*>(ea.C) + co, full, ne, ov);
+        else load_vec<T>(reinterpret_cast<const T*>(ea.C) + co, full, ne, ov);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e] * ea.alpha;
+        if (ea.bias && e < ne) x += ea.bias[gn + e];
+        pre[e] = x;
+        // DACT: result *= act'(P) (forward activation not applied); else forward activation.
+        v[e] = ea.dact ? x * act_grad_f(ea.act, pv[e]) : act_f(ea.act, x);
+      }
+      if (ea.dropout_p > 0.f) {
+        const unsigned long long ctr = ea.ctr_base + (unsigned long long)gm * (unsigned long long)ea.N + gn;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dropout_scale(ea.seed, ctr + e, thresh, inv_keep);
+      }
+      if (ea.R) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (ea.beta != 0.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += ea.beta * ov[e];
+      }
+      if (ea.Cpre) {
+        const long long qo = (long long)q * ea.q_bs + (long long)rm * ea.q_ld + gn;
+        store_vec<T>(reinterpret_cast<T*>(ea.Cpre) + qo, full, ne, pre);
+      }
+      if (ea.out_f32) store_vec<float>(reinterpret_cast<float*>(ea.C) + co, full, ne, v);
+      else store_vec<T>(reinterpret_cast<T*>(ea.C) + co, full, ne, v);
+    }
+  }
+}
+
+template <typename T, bool AKS, bool BKS>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  constexpr int BK = 128 / (int)sizeof(T);
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int z = blockIdx.z;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  // XCD-aware remap (block b runs on XCD b % 8): give each XCD a contiguous range of tiles so that
+  // neighbouring tiles (sharing an A row panel) hit the same L2.  Bijective for any grid size.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
+    bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
+  const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
+
+  typename std::conditional<AKS, LoaderKS<T>, LoaderKM<T>>::type la;
+  typename std::conditional<BKS, LoaderKS<T>, LoaderKM<T>>::type lb;
+  la.init(make_addr(p.A.ld, p.A.bstride, p.A.seg_stride, p.A.rpb, p.A.seg), Ap, m0, p.M, p.K, tid);
+  lb.init(make_addr(p.B.ld, p.B.bstride, p.B.seg_stride, p.B.rpb, p.B.seg), Bp, n0, p.N, p.K, tid);
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+  const int nk = (p.K + BK - 1) / BK;
+  la.load(0); lb.load(0);
+  la.store(smem); lb.store(smem + TILE_BYTES);
+  __syncthreads();
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int arow0 = wr * 64 + frow, brow0 = wc * 64 + frow;
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+    if (kt + 1 < nk) { la.load((kt + 1) * BK); lb.load((kt + 1) * BK); }
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const frag_t a0 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0, kg * 2 + fhalf));
+      const frag_t a1 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0 + 32, kg * 2 + fhalf));
+      const frag_t b0 = *reinterpret_cast<const frag_t*>(cur + TILE_BYTES + lds_off(brow0, kg * 2 + fhalf));
+      const frag_t b1 = *reinterpret_cast<const frag_t*>(cur + TILE_BYTES + lds_off(brow0 + 32, kg * 2 + fhalf));
+      mma<T>(a0, b0, acc00); mma<T>(a0, b1, acc01); mma<T>(a1, b0, acc10); mma<T>(a1, b1, acc11);
+    }
+    if (kt + 1 < nk) { la.store(nxt); lb.store(nxt + TILE_BYTES); }
+    __syncthreads();
+  }
+
+  // ------------------------------ epilogue ------------------------------
+  EpiArgs ea;
+  ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
+  ea.bias = p.bias ? p.bias + (long long)z * p.bias_zs : nullptr;
+  ea.c_ld = p.C.ld; ea.c_bs = p.C.bstride; ea.r_ld = p.R.ld; ea.r_bs = p.R.bstride;
+  ea.p_ld = p.P.ld; ea.p_bs = p.P.bstride; ea.q_ld = p.Cpre.ld; ea.q_bs = p.Cpre.bstride;
+  ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
+  ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
+  ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
+  ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
+  // fold the batch offsets into the base pointers
+  {
+    const long long zc = z_off(p.C.zs0, p.C.zs1, z, p.zdiv);
+    if (ea.out_f32) ea.C = reinterpret_cast<float*>(ea.C) + zc; else ea.C = reinterpret_cast<T*>(ea.C) + zc;
+    if (ea.R) {
+      const long long zr = z_off(p.R.zs0, p.R.zs1, z, p.zdiv);
+      if (ea.out_f32) ea.R = reinterpret_cast<const float*>(ea.R) + zr; else ea.R = reinterpret_cast<const T*>(ea.R) + zr;
+    }
+    if (ea.P) ea.P = reinterpret_cast<const T*>(ea.P) + z_off(p.P.zs0, p.P.zs1, z, p.zdiv);
+    if (ea.Cpre) ea.Cpre = reinterpret_cast<T*>(ea.Cpre) + z_off(p.Cpre.zs0, p.Cpre.zs1, z, p.zdiv);
+  }
+  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (h == 0) stage_write(stage, acc00, acc01, lane);
+    else stage_write(stage, acc10, acc11, lane);
+    __syncthreads();
+    epilogue_rows<T>(ea, stage, m0 + wr * 64 + h * 32, n0 + wc * 64, lane);
+    __syncthreads();
+  }
+}
+
+template <typename T>
+int launch(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  dim3 grid(tiles, 1, p.batch), block(NTHREADS);
+  const bool aks = p.flags & ST5_GEMM_A_KSTRIDED, bks = p.flags & ST5_GEMM_B_KSTRIDED;
+  if (!aks && !bks) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, p, c_vec_ok);
+  else if (!aks && bks) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, p, c_vec_ok);
+  else if (aks && !bks) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, s, p, c_vec_ok);
+  else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, s, p, c_vec_ok);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
+  if (!pp) return ST5_ERR_ARG;
+  st5_gemm_params p = *pp;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return ST5_ERR_ARG;
+  if (!p.A.ptr || !p.B.ptr || !p.C.ptr) return ST5_ERR_ARG;
+  if (p.batch <= 0) p.batch = 1;
+  if (p.zdiv <= 0) p.zdiv = 1;
+  if ((p.flags & ST5_GEMM_DACT) && !p.P.ptr) return ST5_ERR_ARG;
+  if (dtype != ST5_BF16 && dtype != ST5_F32) return ST5_ERR_ARG;
+  const int es = dtype == ST5_BF16 ? 2 : 4;
+  const int vec = 16 / es;
+  // operand alignment: 16-byte vectors along the contiguous index
+  auto op_ok = [&](const st5_operand& o, bool kstrided) {
+    const int64_t q = kstrided ? 4 : vec;
+    if (!aligned(o.ptr, (size_t)q * es)) return false;
+    if (o.ld % q || o.bstride % q || o.zs0 % q || o.zs1 % q) return false;
+    if (o.seg && (o.seg % q || o.seg_stride % q)) return false;
+    return true;
+  };
+  if (!op_ok(p.A, p.flags & ST5_GEMM_A_KSTRIDED)) return ST5_ERR_ALIGN;
+  if (!op_ok(p.B, p.flags & ST5_GEMM_B_KSTRIDED)) return ST5_ERR_ALIGN;
+  auto c_ok = [&](const st5_operand& o) {
+    if (!o.ptr) return true;
+    return aligned(o.ptr, 16) && o.ld % 8 == 0 && o.bstride % 8 == 0 && o.zs0 % 8 == 0 && o.zs1 % 8 == 0;
+  };
+  const int c_vec_ok = c_ok(p.C) && c_ok(p.R) && c_ok(p.P) && c_ok(p.Cpre);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, s);
+  return launch<float>(p, c_vec_ok, s);
+}

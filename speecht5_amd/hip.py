@@ -1,0 +1,166 @@
+"""ctypes binding of libspeecht5_hip.so (C ABI declared in include/speecht5_hip.h).
+
+PyTorch is used only for device memory (`tensor.data_ptr()`), the current HIP stream and
+`torch.distributed`; every compute call of the hot path goes through this binding.  There is NO
+fallback: if the shared library is missing or a kernel returns an error the call raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+import torch
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+A_KSTRIDED, B_KSTRIDED, OUT_F32, DACT = 1, 2, 4, 8
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libspeecht5_hip.so")
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class Operand(Structure):
+    _fields_ = [("ptr", c_void_p), ("ld", c_int64), ("rpb", c_int32), ("seg", c_int32),
+                ("bstride", c_int64), ("seg_stride", c_int64), ("zs0", c_int64), ("zs1", c_int64)]
+
+
+class GemmParams(Structure):
+    _fields_ = [("A", Operand), ("B", Operand), ("C", Operand), ("R", Operand), ("P", Operand), ("Cpre", Operand),
+                ("bias", c_void_p), ("bias_zs", c_int64),
+                ("M", c_int32), ("N", c_int32), ("K", c_int32), ("batch", c_int32), ("zdiv", c_int32),
+                ("act", c_int32), ("flags", c_int32),
+                ("alpha", c_float), ("beta", c_float), ("dropout_p", c_float), ("seed", c_uint64)]
+
+
+_SIGS = {
+    "st5_gemm": (c_int, [POINTER(GemmParams), c_int, c_void_p]),
+    "st5_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                  c_float, c_int, c_void_p]),
+    "st5_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_int64, c_int32, c_int, c_void_p]),
+    "st5_layernorm_bwd_ws_bytes": (c_int64, [c_int64, c_int32]),
+    "st5_softmax_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_int, c_void_p]),
+    "st5_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                c_int32, c_float, c_uint64, c_int, c_void_p]),
+    "st5_conv0_gn_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                      c_int32, c_int32, c_int32, c_int32, c_float, c_int, c_void_p]),
+    "st5_conv0_gn_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int,
+                                      c_void_p]),
+    "st5_conv0_ws_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "st5_cast_from_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int, c_void_p]),
+    "st5_cast_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "st5_colsum_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_float, c_int32, c_int,
+                              c_void_p]),
+    "st5_colsum_ws_bytes": (c_int64, [c_int64, c_int32]),
+    "st5_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int32, c_int, c_void_p]),
+    "st5_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
+    "st5_act_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
+    "st5_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
+    "st5_dropout": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_uint64, c_int, c_void_p]),
+    "st5_masked_fill_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
+    "st5_masked_fill_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
+    "st5_add_table_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_int,
+                                   c_void_p]),
+    "st5_embed_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
+                               c_int, c_void_p]),
+    "st5_embed_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_int, c_void_p]),
+    "st5_pad_time": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    "st5_cross_entropy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,
+                                  c_float, c_int32, c_float, c_int, c_void_p]),
+    "st5_version": (c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises HipLibraryMissing if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise HipLibraryMissing(
+                f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C speecht5_amd/csrc`). The SpeechT5 hot path has no CPU/PyTorch fallback.")
+        L = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def dt(t):
+    if isinstance(t, torch.Tensor):
+        t = t.dtype
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipKernelError(f"{what} failed with ST5 error {rc} "
+                             "(1=bad argument, 2=alignment, 3=launch)")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def operand(t, ld, off=0, rpb=0, bstride=0, seg=0, seg_stride=0, zs0=0, zs1=0):
+    """Describe a GEMM operand living in tensor `t` starting `off` elements in."""
+    o = Operand()
+    o.ptr = t.data_ptr() + off * t.element_size()
+    o.ld, o.rpb, o.seg, o.bstride, o.seg_stride, o.zs0, o.zs1 = ld, rpb, seg, bstride, seg_stride, zs0, zs1
+    return o
+
+
+_NULL_OP = Operand()
+
+
+def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_zs=0, batch=1, zdiv=1, act=ACT_NONE,
+         flags=0, alpha=1.0, beta=0.0, dropout_p=0.0, seed=0):
+    p = GemmParams()
+    p.A, p.B, p.C = A, B, C
+    p.R = R if R is not None else _NULL_OP
+    p.P = P if P is not None else _NULL_OP
+    p.Cpre = Cpre if Cpre is not None else _NULL_OP
+    p.bias = ptr(bias)
+    p.bias_zs = bias_zs
+    p.M, p.N, p.K, p.batch, p.zdiv = M, N, K, batch, zdiv
+    p.act, p.flags = act, flags
+    p.alpha, p.beta, p.dropout_p, p.seed = alpha, beta, dropout_p, seed
+    check(lib().st5_gemm(byref(p), dtype, stream()), "st5_gemm")
+
+
+# ---------------------------------------------------------------------------------------------
+# workspace: one grow-only byte buffer per device for the two-stage reductions
+_ws = {}
+
+
+def workspace(nbytes, device):
+    key = (device.type, device.index)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf

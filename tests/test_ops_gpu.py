@@ -1,0 +1,396 @@
+"""Kernel-level parity of the C-ABI library (through ctypes) against plain PyTorch fp32 CPU math.
+
+fp32 mode must agree to fp32 round-off (it backs the 1e-3 mel / bit-exact token-id parity claims);
+bf16 mode is compared with the same math evaluated on bf16-rounded inputs, tolerance 2e-2 of the
+output scale (bf16 has 8 mantissa bits; accumulation is fp32)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from speecht5_amd import hip  # noqa: E402
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+
+
+def rt(x, dtype):  # round-trip through dtype (what the kernel sees); always a fresh tensor
+    return x.detach().to(dtype).float().clone()
+
+
+def close(got, ref, dtype, scale=None, what=""):
+    rtol, atol = tol(dtype)
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    s = ref.abs().max().item() if scale is None else scale
+    err = (got - ref).abs().max().item()
+    assert err <= atol * max(s, 1e-6) + 1e-7, f"{what}: max err {err:.3e} vs scale {s:.3e} ({dtype})"
+
+
+def dev(x, dtype, cuda):
+    return x.to(dtype).to(cuda).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 200, 136), (128, 128, 64), (1, 83, 768), (257, 520, 776), (64, 48, 6144)])
+def test_gemm_nt_epilogues(cuda, dtype, M, N, K):
+    torch.manual_seed(M * 7 + N)
+    a, w = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K)
+    bias, res = torch.randn(N), torch.randn(M, N)
+    ldc = (N + 7) // 8 * 8
+    A, W = dev(a, dtype, cuda), dev(w, dtype, cuda)
+    Rr = torch.zeros(M, ldc); Rr[:, :N] = res
+    Rd = dev(Rr, dtype, cuda)
+    C = torch.full((M, ldc), float("nan"), dtype=dtype, device=cuda)
+    Cp = torch.full((M, ldc), float("nan"), dtype=dtype, device=cuda)
+    hip.gemm(hip.operand(A, K), hip.operand(W, K), hip.operand(C, ldc), M, N, K, hip.dt(dtype),
+             R=hip.operand(Rd, ldc), Cpre=hip.operand(Cp, ldc), bias=bias.to(cuda), act=hip.ACT_GELU, alpha=0.5)
+    pre = 0.5 * rt(a, dtype) @ rt(w, dtype).t() + bias
+    ref = F.gelu(pre) + rt(res, dtype)
+    close(C[:, :N], ref, dtype, what="gemm nt")
+    close(Cp[:, :N], pre, dtype, what="gemm pre-activation")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("aks,bks", [(0, 1), (1, 0), (1, 1)])
+def test_gemm_transposed_layouts(cuda, dtype, aks, bks):
+    torch.manual_seed(3)
+    M, N, K = 200, 136, 300
+    a, b = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K)
+    ref = rt(a, dtype) @ rt(b, dtype).t()
+    lda_t, ldb_t = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    ldk = (K + 7) // 8 * 8  # K-major rows are 16-byte aligned; the K tail (300 % 8 != 0) is masked in-kernel
+    if aks:
+        At = torch.zeros(K, lda_t); At[:, :M] = a.t(); A = dev(At, dtype, cuda); opA = hip.operand(A, lda_t)
+    else:
+        Ap = torch.full((M, ldk), float("nan")); Ap[:, :K] = a; A = dev(Ap, dtype, cuda); opA = hip.operand(A, ldk)
+    if bks:
+        Bt = torch.zeros(K, ldb_t); Bt[:, :N] = b.t(); B = dev(Bt, dtype, cuda); opB = hip.operand(B, ldb_t)
+    else:
+        Bp = torch.full((N, ldk), float("nan")); Bp[:, :K] = b; B = dev(Bp, dtype, cuda); opB = hip.operand(B, ldk)
+    # fp32 output with accumulate (the weight-gradient form)
+    C = torch.ones(M, N, dtype=torch.float32, device=cuda)
+    hip.gemm(opA, opB, hip.operand(C, N), M, N, K, hip.dt(dtype),
+             flags=(hip.A_KSTRIDED if aks else 0) | (hip.B_KSTRIDED if bks else 0) | hip.OUT_F32, beta=1.0)
+    close(C, ref + 1.0, dtype, what=f"gemm aks={aks} bks={bks}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_batched_heads(cuda, dtype):
+    """q.k^T per (batch, head) straight out of a fused [B*T, 3d] projection buffer."""
+    torch.manual_seed(5)
+    B, H, T, hd = 2, 3, 70, 64
+    d = H * hd
+    qkv = torch.randn(B * T, 3 * d)
+    Q = dev(qkv, dtype, cuda)
+    lds = (T + 7) // 8 * 8
+    S = torch.zeros(B * H, T, lds, dtype=dtype, device=cuda)
+    hip.gemm(hip.operand(Q, 3 * d, zs0=T * 3 * d, zs1=hd), hip.operand(Q, 3 * d, off=d, zs0=T * 3 * d, zs1=hd),
+             hip.operand(S, lds, zs0=H * T * lds, zs1=T * lds), T, T, hd, hip.dt(dtype), batch=B * H, zdiv=H, alpha=0.125)
+    x = rt(qkv, dtype).view(B, T, 3, H, hd)
+    ref = 0.125 * torch.einsum("bihd,bjhd->bhij", x[:, :, 0], x[:, :, 1]).reshape(B * H, T, T)
+    close(S[:, :, :T], ref, dtype, what="batched qk")
+    # P.V with V k-strided, output back into [B*T, d]
+    P = torch.softmax(ref, -1)
+    Pd = torch.zeros(B * H, T, lds); Pd[:, :, :T] = P
+    Pd = dev(Pd, dtype, cuda)
+    O = torch.zeros(B * T, d, dtype=dtype, device=cuda)
+    hip.gemm(hip.operand(Pd, lds, zs0=H * T * lds, zs1=T * lds),
+             hip.operand(Q, 3 * d, off=2 * d, zs0=T * 3 * d, zs1=hd),
+             hip.operand(O, d, zs0=T * d, zs1=hd), T, hd, T, hip.dt(dtype), batch=B * H, zdiv=H, flags=hip.B_KSTRIDED)
+    refo = torch.einsum("bhij,bjhd->bihd", rt(P, dtype).view(B, H, T, T), x[:, :, 2]).reshape(B * T, d)
+    close(O, refo, dtype, what="batched pv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,stride", [(3, 2), (2, 2)])
+def test_gemm_conv1d_channels_last(cuda, dtype, k, stride):
+    """Strided Conv1d as implicit GEMM on channels-last activations (overlapping rows) + GELU."""
+    torch.manual_seed(11)
+    B, L, Cin, Cout = 3, 101, 64, 72
+    Lo = (L - k) // stride + 1
+    x = torch.randn(B, L, Cin)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    X = dev(x, dtype, cuda)
+    Wk = dev(w.permute(0, 2, 1).reshape(Cout, k * Cin), dtype, cuda)  # [Cout, k, Cin]
+    Y = torch.zeros(B, Lo, Cout, dtype=dtype, device=cuda)
+    hip.gemm(hip.operand(X, stride * Cin, rpb=Lo, bstride=L * Cin), hip.operand(Wk, k * Cin), hip.operand(Y, Cout),
+             B * Lo, Cout, k * Cin, hip.dt(dtype), act=hip.ACT_GELU)
+    ref = F.gelu(F.conv1d(rt(x, dtype).transpose(1, 2), rt(w, dtype), stride=stride)).transpose(1, 2)
+    close(Y, ref, dtype, what="conv1d implicit gemm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_grouped_posconv(cuda, dtype):
+    """Grouped Conv1d(k=16, groups=4, pad=8) via K segmentation over a zero-padded channels-last copy."""
+    torch.manual_seed(13)
+    B, T, C, G, k = 2, 50, 64, 4, 16
+    cg = C // G
+    x = torch.randn(B, T, C)
+    w = torch.randn(C, cg, k) / math.sqrt(cg * k)
+    bias = torch.randn(C)
+    X = dev(x, dtype, cuda)
+    Tp = T + k
+    Xp = torch.empty(B, Tp, C, dtype=dtype, device=cuda)
+    hip.check(hip.lib().st5_pad_time(X.data_ptr(), Xp.data_ptr(), B, T, C, k // 2, k // 2, hip.dt(dtype), hip.stream()), "pad")
+    # weights -> [G][cg_out][k][cg_in]
+    Wg = dev(w.view(G, cg, cg, k).permute(0, 1, 3, 2).reshape(G, cg, k * cg), dtype, cuda)
+    Y = torch.zeros(B, T, C, dtype=dtype, device=cuda)
+    hip.gemm(hip.operand(Xp, C, rpb=T, bstride=Tp * C, seg=cg, seg_stride=C, zs0=cg),
+             hip.operand(Wg, k * cg, zs0=cg * k * cg), hip.operand(Y, C, zs0=cg), B * T, cg, k * cg, hip.dt(dtype),
+             batch=G, bias=bias.to(cuda), bias_zs=cg, act=hip.ACT_GELU)
+    ref = F.conv1d(rt(x, dtype).transpose(1, 2), rt(w, dtype), bias, padding=k // 2, groups=G)[:, :, :T]
+    ref = F.gelu(ref).transpose(1, 2)
+    close(Y, ref, dtype, what="grouped pos conv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_dact_and_dropout(cuda, dtype):
+    torch.manual_seed(17)
+    M, N, K = 150, 96, 64
+    a, w, pre = torch.randn(M, K), torch.randn(N, K) / 8, torch.randn(M, N)
+    A, W, P = dev(a, dtype, cuda), dev(w, dtype, cuda), dev(pre, dtype, cuda)
+    C = torch.zeros(M, N, dtype=dtype, device=cuda)
+    hip.gemm(hip.operand(A, K), hip.operand(W, K), hip.operand(C, N), M, N, K, hip.dt(dtype), P=hip.operand(P, N),
+             act=hip.ACT_GELU, flags=hip.DACT)
+    x = rt(pre, dtype).requires_grad_(True)
+    F.gelu(x).sum().backward()
+    close(C, (rt(a, dtype) @ rt(w, dtype).t()) * x.grad, dtype, what="dact")
+    # dropout: deterministic in (seed, index), ~p zeros, survivors scaled
+    C1 = torch.zeros(M, N, dtype=dtype, device=cuda); C2 = torch.zeros_like(C1); C3 = torch.zeros_like(C1)
+    for out, seed in ((C1, 7), (C2, 7), (C3, 8)):
+        hip.gemm(hip.operand(A, K), hip.operand(W, K), hip.operand(out, N), M, N, K, hip.dt(dtype), dropout_p=0.25, seed=seed)
+    assert torch.equal(C1, C2) and not torch.equal(C1, C3)
+    full = rt(a, dtype) @ rt(w, dtype).t()
+    keep = (C1 != 0).float().cpu()
+    assert abs(keep.mean().item() - 0.75) < 0.03
+    close(C1.float().cpu(), full * keep / 0.75, dtype, what="dropout survivors")
+    # the standalone dropout kernel uses the same generator/counter as the epilogue
+    Y = torch.zeros(M, N, dtype=dtype, device=cuda)
+    Fd = dev(full, dtype, cuda)
+    hip.check(hip.lib().st5_dropout(Fd.data_ptr(), Y.data_ptr(), M * N, 0.25, 7, hip.dt(dtype), hip.stream()), "dropout")
+    assert torch.equal((Y != 0), (C1 != 0)) or ((Y != 0) ^ (C1 != 0)).float().mean().item() < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(37, 768), (130, 512), (9, 64), (5, 1024)])
+def test_layernorm(cuda, dtype, rows, cols):
+    torch.manual_seed(rows)
+    x = torch.randn(rows, cols) * 2 + 0.5
+    g, b, dy = torch.randn(cols), torch.randn(cols), torch.randn(rows, cols)
+    X, DY = dev(x, dtype, cuda), dev(dy, dtype, cuda)
+    G, Bt = g.to(cuda), b.to(cuda)
+    Y = torch.empty_like(X)
+    mean = torch.empty(rows, device=cuda); rstd = torch.empty(rows, device=cuda)
+    L = hip.lib()
+    hip.check(L.st5_layernorm_fwd(X.data_ptr(), G.data_ptr(), Bt.data_ptr(), Y.data_ptr(), mean.data_ptr(),
+                                  rstd.data_ptr(), rows, cols, 1e-5, hip.dt(dtype), hip.stream()), "ln fwd")
+    xr = rt(x, dtype).requires_grad_(True); gr = g.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (cols,), gr, br, 1e-5)
+    close(Y, ref, dtype, what="ln fwd")
+    ref.backward(rt(dy, dtype))
+    DX = torch.empty_like(X)
+    dG = torch.ones(cols, device=cuda); dB = torch.ones(cols, device=cuda)  # accumulate semantics
+    ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows, cols), cuda)
+    hip.check(L.st5_layernorm_bwd(DY.data_ptr(), X.data_ptr(), G.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                  DX.data_ptr(), dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), rows, cols,
+                                  hip.dt(dtype), hip.stream()), "ln bwd")
+    close(DX, xr.grad, dtype, what="ln dx")
+    close(dG - 1, gr.grad, dtype, what="ln dgamma")
+    close(dB - 1, br.grad, dtype, what="ln dbeta")
+
+
+def _ref_attn_probs(scores, qp, kpm, H, causal, maxrel):
+    """multihead_attention.py:343-385 with the bias gathered from q.pe^T."""
+    BH, T, S = scores.shape
+    s = scores.clone()
+    if qp is not None:
+        i = torch.arange(T)[:, None]; j = torch.arange(S)[None, :]
+        idx = (i - j).clamp(-maxrel, maxrel - 1) + maxrel
+        s = s + torch.gather(qp, 2, idx.expand(BH, T, S))
+    if causal:
+        s = s + torch.triu(torch.full((T, S), float("-inf")), 1 + (S - T))
+    if kpm is not None:
+        s = s.view(-1, H, T, S).masked_fill(kpm[:, None, None, :].bool(), float("-inf")).view(BH, T, S)
+    return torch.softmax(s, -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,S,causal,rel,pad", [(70, 70, 0, 1, 1), (33, 33, 1, 0, 1), (20, 75, 0, 0, 1), (200, 200, 0, 1, 0)])
+def test_softmax_relpos(cuda, dtype, T, S, causal, rel, pad):
+    torch.manual_seed(T + S)
+    B, H, maxrel = 2, 3, 16
+    BH, nb = B * H, 2 * maxrel
+    lds = (S + 7) // 8 * 8
+    scores = torch.randn(BH, T, S) * 2
+    qp = torch.randn(BH, T, nb) if rel else None
+    kpm = torch.zeros(B, S, dtype=torch.uint8)
+    if pad:
+        kpm[1, S - 5:] = 1
+    sc = torch.zeros(BH, T, lds); sc[:, :, :S] = scores
+    SC = dev(sc, dtype, cuda)
+    QP = dev(qp, dtype, cuda) if rel else None
+    KP = kpm.to(cuda) if pad else None
+    P = torch.full((BH, T, lds), float("nan"), dtype=dtype, device=cuda)
+    L = hip.lib()
+    hip.check(L.st5_softmax_fwd(SC.data_ptr(), hip.ptr(QP), hip.ptr(KP), P.data_ptr(), 0, BH, H, T, S, lds, nb, maxrel,
+                                causal, 0.0, 0, hip.dt(dtype), hip.stream()), "softmax fwd")
+    sr = rt(scores, dtype).requires_grad_(True)
+    qr = rt(qp, dtype).requires_grad_(True) if rel else None
+    ref = _ref_attn_probs(sr, qr, kpm if pad else None, H, causal, maxrel)
+    close(P[:, :, :S], ref, dtype, what="softmax fwd")
+    assert float(P[:, :, S:].abs().sum()) == 0.0
+    # backward: dS and the bucket-scattered dQP
+    dP = torch.randn(BH, T, S)
+    extra = torch.randn(BH, T, S) * 0.1
+    ref.backward(rt(dP, dtype) + extra)
+    dp = torch.zeros(BH, T, lds); dp[:, :, :S] = dP
+    DP = dev(dp, dtype, cuda)
+    DQP = torch.full((BH, T, nb), float("nan"), dtype=dtype, device=cuda) if rel else None
+    Pin = dev(torch.cat([ref.detach(), torch.zeros(BH, T, lds - S)], -1), dtype, cuda)
+    EX = extra.to(cuda)
+    hip.check(L.st5_softmax_bwd(DP.data_ptr(), Pin.data_ptr(), EX.data_ptr(), hip.ptr(DQP), BH, T, S, lds,
+                                nb, maxrel, 0.0, 0, hip.dt(dtype), hip.stream()), "softmax bwd")
+    close(DP[:, :, :S], sr.grad, dtype, scale=1.0, what="softmax dS")
+    if rel:
+        close(DQP, qr.grad, dtype, scale=max(1.0, qr.grad.abs().max().item()), what="softmax dQP")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_dropout_consistency(cuda, dtype):
+    torch.manual_seed(2)
+    BH, H, T, S = 4, 2, 40, 40
+    SC = dev(torch.randn(BH, T, S), dtype, cuda)
+    P = torch.empty_like(SC); PD = torch.empty_like(SC)
+    L = hip.lib()
+    hip.check(L.st5_softmax_fwd(SC.data_ptr(), 0, 0, P.data_ptr(), PD.data_ptr(), BH, H, T, S, S, 0, 0, 0, 0.3, 99,
+                                hip.dt(dtype), hip.stream()), "softmax fwd drop")
+    keep = (PD != 0)
+    assert abs(keep.float().mean().item() - 0.7) < 0.03
+    close(PD.float().cpu(), P.float().cpu() * keep.float().cpu() / 0.7, dtype, what="dropped probs")
+    # backward regenerates the same mask: dS must equal P*(m*dP/keep - sum(...))
+    dP = torch.randn(BH, T, S)
+    DP = dev(dP, dtype, cuda)
+    hip.check(L.st5_softmax_bwd(DP.data_ptr(), P.data_ptr(), 0, 0, BH, T, S, S, 0, 0, 0.3, 99, hip.dt(dtype),
+                                hip.stream()), "softmax bwd drop")
+    p = P.float().cpu(); g = rt(dP, dtype) * keep.float().cpu() / 0.7
+    ref = p * (g - (g * p).sum(-1, keepdim=True))
+    close(DP, ref, dtype, scale=1.0, what="softmax bwd with dropout")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,C", [(2, 3000, 64), (1, 16000, 512)])
+def test_conv0_groupnorm_gelu(cuda, dtype, B, S, C):
+    torch.manual_seed(S)
+    k, stride = 10, 5
+    wav = torch.randn(B, S)
+    w = torch.randn(C, 1, k) * math.sqrt(2.0 / k)
+    g, b = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    Lo = (S - k) // stride + 1
+    Ld = hip.lib()
+    WAV, W, G, Bt = wav.to(cuda), w.view(C, k).contiguous().to(cuda), g.to(cuda), b.to(cuda)
+    out = torch.empty(B, Lo, C, dtype=dtype, device=cuda)
+    stats = torch.empty(B, C, 2, device=cuda)
+    ws = hip.workspace(Ld.st5_conv0_ws_bytes(B, S, C, k, stride), cuda)
+    hip.check(Ld.st5_conv0_gn_gelu_fwd(WAV.data_ptr(), W.data_ptr(), G.data_ptr(), Bt.data_ptr(), out.data_ptr(),
+                                       stats.data_ptr(), ws.data_ptr(), B, S, C, k, stride, 1e-5, hip.dt(dtype),
+                                       hip.stream()), "conv0 fwd")
+    wr = w.clone().requires_grad_(True); gr = g.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    y = F.gelu(F.group_norm(F.conv1d(wav[:, None], wr, stride=stride), C, gr, br, 1e-5))  # [B,C,L]
+    close(out, y.transpose(1, 2), dtype, what="conv0 fwd")
+    dy = torch.randn(B, Lo, C)
+    y.backward(rt(dy, dtype).transpose(1, 2) * 0.1)  # gscale = 0.1 (feature_grad_mult)
+    DY = dev(dy, dtype, cuda)
+    dW = torch.zeros(C, k, device=cuda); dG = torch.zeros(C, device=cuda); dB = torch.zeros(C, device=cuda)
+    hip.check(Ld.st5_conv0_gn_gelu_bwd(WAV.data_ptr(), W.data_ptr(), G.data_ptr(), Bt.data_ptr(), stats.data_ptr(),
+                                       DY.data_ptr(), dW.data_ptr(), dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), B, S,
+                                       C, k, stride, 0.1, hip.dt(dtype), hip.stream()), "conv0 bwd")
+    # bf16: the kernel recomputes x_hat in fp32 while dY is bf16-rounded -> same tolerance class
+    close(dW, wr.grad.view(C, k), dtype, what="conv0 dW")
+    close(dG, gr.grad, dtype, what="conv0 dgamma")
+    close(dB, br.grad, dtype, what="conv0 dbeta")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise_and_losses(cuda, dtype):
+    torch.manual_seed(23)
+    L = hip.lib()
+    d, s = hip.dt(dtype), hip.stream()
+    rows, cols = 77, 96
+    x = torch.randn(rows, cols)
+    X = dev(x, dtype, cuda)
+    # casts (+ transpose)
+    Wt = torch.empty(cols, rows, dtype=dtype, device=cuda)
+    XF = x.to(cuda)
+    hip.check(L.st5_cast_from_f32(XF.data_ptr(), Wt.data_ptr(), rows, cols, 1, d, s), "cast t")
+    close(Wt, rt(x, dtype).t(), dtype, what="cast transpose")
+    back = torch.empty(rows * cols, device=cuda)
+    hip.check(L.st5_cast_to_f32(X.data_ptr(), back.data_ptr(), rows * cols, d, s), "cast back")
+    assert torch.equal(back.cpu().view(rows, cols), rt(x, dtype))
+    # colsum / sumsq
+    out = torch.ones(cols, device=cuda)
+    ws = hip.workspace(L.st5_colsum_ws_bytes(rows, cols), cuda)
+    hip.check(L.st5_colsum_ws(X.data_ptr(), out.data_ptr(), ws.data_ptr(), rows, cols, cols, 2.0, 1, d, s), "colsum")
+    close(out - 1, 2 * rt(x, dtype).sum(0), dtype, what="colsum")
+    sq = torch.zeros(1, device=cuda)
+    hip.check(L.st5_sumsq(X.data_ptr(), sq.data_ptr(), rows * cols, 1.0 / (rows * cols), 0, d, s), "sumsq")
+    close(sq, rt(x, dtype).pow(2).mean().view(1), dtype, what="sumsq")
+    # activation fwd/bwd
+    for act, fn in ((hip.ACT_GELU, F.gelu), (hip.ACT_RELU, F.relu), (hip.ACT_TANH, torch.tanh)):
+        Y = torch.empty_like(X)
+        hip.check(L.st5_act_fwd(X.data_ptr(), Y.data_ptr(), rows * cols, act, d, s), "act")
+        xr = rt(x, dtype).requires_grad_(True)
+        yr = fn(xr)
+        close(Y, yr, dtype, what=f"act {act}")
+        yr.sum().backward()
+        DX = torch.empty_like(X)
+        ones = torch.ones_like(X)
+        hip.check(L.st5_act_bwd(ones.data_ptr(), X.data_ptr(), DX.data_ptr(), rows * cols, act, d, s), "act bwd")
+        close(DX, xr.grad, dtype, what=f"act bwd {act}")
+    # masked fill rows fwd/bwd
+    mask = (torch.rand(rows) < 0.4).to(torch.uint8)
+    v = torch.randn(cols)
+    X2 = X.clone()
+    MK, Vd = mask.to(cuda), v.to(cuda)  # keep device temporaries alive across the async launches
+    hip.check(L.st5_masked_fill_rows(X2.data_ptr(), MK.data_ptr(), Vd.data_ptr(), rows, cols, d, s), "mfill")
+    ref = rt(x, dtype).clone(); ref[mask.bool()] = rt(v, dtype)
+    close(X2, ref, dtype, what="masked fill")
+    DXm = X.clone(); dv = torch.zeros(cols, device=cuda)
+    hip.check(L.st5_masked_fill_rows_bwd(DXm.data_ptr(), MK.data_ptr(), dv.data_ptr(), rows, cols, d, s), "mfill bwd")
+    close(dv, rt(x, dtype)[mask.bool()].sum(0), dtype, what="mask_emb grad")
+    assert float(DXm[mask.bool().to(cuda)].abs().sum()) == 0
+    # table add / embedding
+    table = torch.randn(50, cols)
+    idx = torch.randint(0, 50, (rows,), dtype=torch.int32)
+    Y = torch.empty_like(X)
+    TB, IX = table.to(cuda), idx.to(cuda)
+    hip.check(L.st5_add_table_rows(X.data_ptr(), TB.data_ptr(), IX.data_ptr(), Y.data_ptr(), rows, cols, 0.5, d, s), "addtab")
+    close(Y, rt(x, dtype) + 0.5 * table[idx.long()], dtype, what="add table rows")
+    hip.check(L.st5_embed_rows(TB.data_ptr(), IX.data_ptr(), TB.data_ptr(), IX.data_ptr(), Y.data_ptr(), rows, cols, 2.0, 1.0, d, s), "embed")
+    close(Y, 3.0 * table[idx.long()], dtype, what="embed rows")
+    dT = torch.zeros(50, cols, device=cuda)
+    hip.check(L.st5_embed_rows_bwd(X.data_ptr(), IX.data_ptr(), dT.data_ptr(), rows, cols, 1.0, d, s), "embed bwd")
+    refT = torch.zeros(50, cols).index_add_(0, idx.long(), rt(x, dtype))
+    close(dT, refT, dtype, what="embed bwd")
+    # cross entropy (label smoothing, ignore index, -inf logits)
+    V, ld = 83, 88
+    logits = torch.randn(rows, V) * 3
+    logits[:, 5] = float("-inf")
+    tgt = torch.randint(0, V, (rows,), dtype=torch.int32); tgt[tgt == 5] = 6; tgt[:7] = 1
+    Lg = torch.zeros(rows, ld); Lg[:, :V] = logits
+    LG = dev(Lg, dtype, cuda)
+    loss = torch.zeros(1, device=cuda); nll = torch.zeros(1, device=cuda)
+    DL = torch.empty_like(LG)
+    TG = tgt.to(cuda)
+    hip.check(L.st5_cross_entropy(LG.data_ptr(), TG.data_ptr(), loss.data_ptr(), nll.data_ptr(), DL.data_ptr(), rows, V, ld, 0.0, 1, 0.5, d, s), "ce")
+    lr = rt(logits, dtype).requires_grad_(True)
+    ref = F.nll_loss(F.log_softmax(lr, -1), tgt.long(), ignore_index=1, reduction="sum")
+    close(loss, ref.view(1), dtype, what="ce loss")
+    (0.5 * ref).backward()
+    close(DL[:, :V], lr.grad, dtype, scale=1.0, what="ce grad")
