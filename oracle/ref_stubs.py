@@ -437,6 +437,46 @@ def install():
        lengths_to_padding_mask=lengths_to_padding_mask)
     fs.modules = modules
 
+    # ---- criterion-side stubs (only what the verbatim criterion files touch at import/forward time) ----
+    class FairseqCriterion(nn.Module):
+        def __init__(self, task):
+            super().__init__()
+            self.task = task
+            if hasattr(task, "target_dictionary"):
+                tgt_dict = task.target_dictionary
+                self.padding_idx = tgt_dict.pad() if tgt_dict is not None else -100
+
+    class _Metrics:
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+
+    import dataclasses
+
+    @dataclasses.dataclass
+    class FairseqDataclass:
+        pass
+
+    @dataclasses.dataclass
+    class LabelSmoothedCrossEntropyCriterionConfig(FairseqDataclass):
+        label_smoothing: float = 0.0
+        report_accuracy: bool = False
+        ignore_prefix_size: int = 0
+        sentence_avg: bool = False
+
+    fs.metrics = _Metrics()
+    mk("fairseq.metrics")
+    mk("fairseq.criterions", FairseqCriterion=FairseqCriterion,
+       register_criterion=lambda name, dataclass=None: (lambda cls: cls))
+    mk("fairseq.criterions.label_smoothed_cross_entropy",
+       LabelSmoothedCrossEntropyCriterionConfig=LabelSmoothedCrossEntropyCriterionConfig)
+    mk("fairseq.dataclass", FairseqDataclass=FairseqDataclass)
+    mk("fairseq.tasks", FairseqTask=object)
+    mk("fairseq.logging")
+    mk("fairseq.logging.meters", safe_round=lambda x, n: round(float(x), n))
+    sys.modules["fairseq.data.data_utils"].post_process = lambda s, sym: s
+    if "omegaconf" not in sys.modules:
+        mk("omegaconf", II=lambda key: False)
+
     mk("espnet")
     mk("espnet.nets")
     mk("espnet.nets.pytorch_backend")
@@ -449,6 +489,28 @@ def install():
        make_pad_mask=make_pad_mask)
     mk("espnet.nets.pytorch_backend.e2e_tts_tacotron2", GuidedAttentionLoss=GuidedAttentionLoss)
     return v
+
+
+def load_reference_criterions():
+    """Import the verbatim reference criterion modules (after load_reference_models())."""
+    load_reference_models()
+    root = f"{REFERENCE_ROOT}/SpeechT5/speecht5"
+    if "speecht5.criterions" not in sys.modules:
+        m = types.ModuleType("speecht5.criterions")
+        m.__path__ = [f"{root}/criterions"]
+        sys.modules["speecht5.criterions"] = m
+    import importlib
+    return SimpleNamespaceLike(
+        tts=importlib.import_module("speecht5.criterions.text_to_speech_loss"),
+        speech_pretrain=importlib.import_module("speecht5.criterions.speech_pretrain_criterion"),
+        text_pretrain=importlib.import_module("speecht5.criterions.text_pretrain_criterion"),
+        s2t=importlib.import_module("speecht5.criterions.speech_to_text_loss"),
+    )
+
+
+class SimpleNamespaceLike:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
 
 
 def load_reference_models():

@@ -1,0 +1,76 @@
+"""Micro-benchmarks of the individual HIP kernels at SpeechT5-Base cfg-2 shapes (B=8 x 10 s).
+Prints one line per kernel: time, achieved TFLOP/s or GB/s.  Run on the GPU box via gpurun."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from speecht5_amd import hip
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def gemm_case(name, M, N, K, dtype, aks=False, bks=False, out_f32=False, act=0, batch=1):
+    es = torch.tensor([], dtype=dtype).element_size()
+    A = torch.randn((K, M) if aks else (M, K), device=dev).to(dtype)
+    B = torch.randn((K, N) if bks else (N, K), device=dev).to(dtype)
+    C = torch.empty(M, N, device=dev, dtype=torch.float32 if out_f32 else dtype)
+    bias = torch.randn(N, device=dev)
+    flags = (hip.A_KSTRIDED if aks else 0) | (hip.B_KSTRIDED if bks else 0) | (hip.OUT_F32 if out_f32 else 0)
+    opA = hip.operand(A, M if aks else K)
+    opB = hip.operand(B, N if bks else K)
+    opC = hip.operand(C, N)
+    t = timeit(lambda: hip.gemm(opA, opB, opC, M, N, K, hip.dt(dtype), bias=bias, act=act, flags=flags))
+    print(f"{name:34s} M={M:6d} N={N:5d} K={K:6d} {str(dtype)[6:]:9s} {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    M = 8 * 499
+    for dtype in (torch.bfloat16, torch.float32):
+        gemm_case("qkv proj (NT)", M, 2304, 768, dtype)
+        gemm_case("out proj (NT)", M, 768, 768, dtype)
+        gemm_case("fc1+gelu (NT)", M, 3072, 768, dtype, act=1)
+        gemm_case("fc2 (NT)", M, 768, 3072, dtype)
+        gemm_case("fc1 dgrad (NN)", M, 768, 3072, dtype, bks=True)
+        gemm_case("fc1 wgrad (TN) f32 out", 3072, 768, M, dtype, aks=True, bks=True, out_f32=True)
+        gemm_case("fc2 wgrad (TN) f32 out", 768, 3072, M, dtype, aks=True, bks=True, out_f32=True)
+        gemm_case("conv1 (k3 s2) as gemm", 8 * 15999, 512, 1536, dtype, act=1)
+        gemm_case("conv1 wgrad", 512, 1536, 8 * 15999, dtype, aks=True, bks=True, out_f32=True)
+        gemm_case("big square", 8192, 8192, 8192, dtype)
+    # LayerNorm / softmax / conv0 bandwidth
+    L = hip.lib()
+    for dtype in (torch.bfloat16,):
+        rows, cols = M, 768
+        x = torch.randn(rows, cols, device=dev).to(dtype); y = torch.empty_like(x)
+        g = torch.ones(cols, device=dev); b = torch.zeros(cols, device=dev)
+        mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
+        t = timeit(lambda: L.st5_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, cols, 1e-5, hip.dt(dtype), hip.stream()))
+        print(f"layernorm fwd {rows}x{cols}: {t*1e6:.1f} us  {2*rows*cols*2/t/1e9:.0f} GB/s")
+        BH, T = 96, 499; lds = 504
+        sc = torch.randn(BH, T, lds, device=dev).to(dtype); qp = torch.randn(BH, T, 320, device=dev).to(dtype)
+        P = torch.empty_like(sc)
+        t = timeit(lambda: L.st5_softmax_fwd(sc.data_ptr(), qp.data_ptr(), 0, P.data_ptr(), 0, BH, 12, T, T, lds, 320, 160, 0, 0.0, 0, hip.dt(dtype), hip.stream()))
+        print(f"softmax+relpos fwd {BH}x{T}x{T}: {t*1e6:.1f} us  {2*BH*T*lds*2/t/1e9:.0f} GB/s")
+        B, S, C = 8, 160000, 512
+        wav = torch.randn(B, S, device=dev); w = torch.randn(C, 10, device=dev) * 0.4
+        gm = torch.ones(C, device=dev); bt = torch.zeros(C, device=dev)
+        Lo = (S - 10) // 5 + 1
+        out = torch.empty(B, Lo, C, device=dev, dtype=dtype); stats = torch.empty(B, C, 2, device=dev)
+        ws = hip.workspace(L.st5_conv0_ws_bytes(B, S, C, 10, 5), dev)
+        t = timeit(lambda: L.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w.data_ptr(), gm.data_ptr(), bt.data_ptr(), out.data_ptr(), stats.data_ptr(), ws.data_ptr(), B, S, C, 10, 5, 1e-5, hip.dt(dtype), hip.stream()))
+        print(f"conv0+GN+GELU fwd B={B}: {t*1e6:.1f} us  {(B*S*4+B*Lo*C*2)/t/1e9:.0f} GB/s (algorithmic)")
+        dY = torch.randn(B, Lo, C, device=dev).to(dtype)
+        dw = torch.zeros(C, 10, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+        t = timeit(lambda: L.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w.data_ptr(), gm.data_ptr(), bt.data_ptr(), stats.data_ptr(), dY.data_ptr(), dw.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), B, S, C, 10, 5, 0.1, hip.dt(dtype), hip.stream()))
+        print(f"conv0+GN+GELU bwd B={B}: {t*1e6:.1f} us  {(B*S*4+B*Lo*C*2)/t/1e9:.0f} GB/s (algorithmic, 1 dY read)")
