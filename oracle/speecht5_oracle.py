@@ -452,17 +452,19 @@ def tacotron_loss(before, after, logits, sample, reduction_factor, bce_pos_weigh
     """text_to_speech_loss.py:154-214 (+ Tacotron2Loss :296-345, use_masking=True)."""
     ys, labels, olens = sample["dec_target"], sample["labels"], sample["dec_target_lengths"]
     r = reduction_factor
+    dev = ys.device
+    olens = torch.as_tensor(olens).to(dev)
     if r > 1:
-        olens = torch.as_tensor([int(o) - int(o) % r for o in olens])
+        olens = torch.as_tensor([int(o) - int(o) % r for o in olens], device=dev)
         mx = int(olens.max())
         ys, labels = ys[:, :mx], labels[:, :mx]
         labels = torch.scatter(labels, 1, (olens - 1).unsqueeze(1), 1.0)
-    m = (torch.arange(ys.shape[1])[None, :] < olens[:, None]).unsqueeze(-1)
+    m = (torch.arange(ys.shape[1], device=dev)[None, :] < olens[:, None]).unsqueeze(-1)
     ysm, am, bm = ys.masked_select(m), after.masked_select(m), before.masked_select(m)
     lm, lg = labels.masked_select(m[:, :, 0]), logits.masked_select(m[:, :, 0])
     l1 = F.l1_loss(am, ysm) + F.l1_loss(bm, ysm)
     l2 = F.mse_loss(am, ysm) + F.mse_loss(bm, ysm)
-    bce = F.binary_cross_entropy_with_logits(lg, lm, pos_weight=torch.tensor(bce_pos_weight))
+    bce = F.binary_cross_entropy_with_logits(lg, lm, pos_weight=torch.tensor(bce_pos_weight, device=dev))
     return l1 + bce, l1, l2, bce
 
 

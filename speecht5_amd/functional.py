@@ -1,0 +1,1045 @@
+"""Autograd functions of the SpeechT5 hot path, implemented on libspeecht5_hip.so (no torch math).
+
+Every forward/backward below is a sequence of C-ABI kernel launches on the current HIP stream;
+PyTorch only owns the buffers and threads the autograd graph.  Activations live in the global
+compute dtype (bf16 for training/benchmarks, fp32 for the parity mode); parameters, statistics and
+weight gradients are fp32.  Weight gradients are accumulated straight into `param.grad` by the
+wgrad GEMM epilogue (beta = 1), so no temporary full-size gradient tensors exist; a registered
+callback (`set_grad_ready_hook`) tells the data-parallel layer when a parameter's gradient is final.
+
+Row convention: activations are 2-D `[rows, channels]` with rows ordered batch-major (b, t).
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+
+from . import hip
+from .hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH  # noqa: F401
+
+_S = SimpleNamespace(dtype=torch.float32, seed=0x5EED, counter=0, grad_hook=None)
+
+
+def set_compute_dtype(dtype):
+    assert dtype in (torch.float32, torch.bfloat16)
+    _S.dtype = dtype
+
+
+def compute_dtype():
+    return _S.dtype
+
+
+def manual_seed(seed):
+    _S.seed = int(seed) & 0xFFFFFFFF
+    _S.counter = 0
+
+
+def next_seed():
+    """A fresh 64-bit dropout seed (host-side counter; the kernels hash (seed, element index))."""
+    _S.counter += 1
+    return ((_S.seed << 32) | (_S.counter & 0xFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+
+
+def set_grad_ready_hook(fn):
+    """fn(param) is called when a parameter's .grad has received its last contribution of this backward
+    from this library (used to launch bucketed all-reduces while backward is still running)."""
+    _S.grad_hook = fn
+
+
+def _ceil8(n):
+    return (n + 7) // 8 * 8
+
+
+def _dt(t):
+    return hip.dt(t)
+
+
+# -------------------------------------------------------------------------------------------------
+# parameter handling: compute-dtype weight cache + direct gradient accumulation
+# -------------------------------------------------------------------------------------------------
+class _WeightCache:
+    """Compute-dtype (optionally fused / re-laid-out) copies of fp32 parameters, rebuilt when any
+    source parameter changes (torch's in-place version counter)."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, key, params, build):
+        ver = tuple((p.data_ptr(), p._version) for p in params)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        val = build()
+        self.store[key] = (ver, val)
+        return val
+
+    def clear(self):
+        self.store.clear()
+
+
+weight_cache = _WeightCache()
+
+
+def _cast_into(src, dst, transpose=False):
+    """dst (compute dtype) <- src (fp32 [rows, cols]); transpose writes dst[c, r]."""
+    rows, cols = src.shape
+    hip.check(hip.lib().st5_cast_from_f32(src.data_ptr(), dst.data_ptr(), rows, cols, 1 if transpose else 0,
+                                          _dt(dst), hip.stream()), "st5_cast_from_f32")
+
+
+def fused_weight(weights, dtype):
+    """[sum N_i, K] compute-dtype matrix stacking the given nn.Linear weights (cached)."""
+    if len(weights) == 1 and dtype == torch.float32 and weights[0].is_contiguous():
+        return weights[0].detach()
+
+    def build():
+        K = weights[0].shape[1]
+        out = torch.empty(sum(w.shape[0] for w in weights), K, dtype=dtype, device=weights[0].device)
+        o = 0
+        for w in weights:
+            src = w.detach().reshape(w.shape[0], -1).contiguous()
+            _cast_into(src, out[o:o + w.shape[0]])
+            o += w.shape[0]
+        return out
+
+    return weight_cache.get(("w", dtype) + tuple(id(w) for w in weights), weights, build)
+
+
+def fused_bias(biases):
+    if all(b is None for b in biases):
+        return None
+    if len(biases) == 1:
+        return biases[0].detach()
+    return weight_cache.get(("b",) + tuple(id(b) for b in biases), biases,
+                            lambda: torch.cat([b.detach() for b in biases]))
+
+
+def cast_param(p, dtype):
+    """compute-dtype copy of a (small) fp32 parameter tensor, cached."""
+    if dtype == torch.float32:
+        return p.detach()
+
+    def build():
+        out = torch.empty(p.shape, dtype=dtype, device=p.device)
+        src = p.detach().reshape(-1, p.shape[-1]).contiguous()
+        _cast_into(src, out.view(src.shape))
+        return out
+
+    return weight_cache.get(("c", dtype, id(p)), [p], build)
+
+
+def grad_buffer(p):
+    """fp32 .grad of a parameter, allocated (zeroed) on first use; kernels accumulate into it."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+def _grad_done(p):
+    if _S.grad_hook is not None:
+        _S.grad_hook(p)
+
+
+def to_compute(x):
+    """Cast an input tensor (fp32) to the compute dtype through the library's cast kernel."""
+    if x.dtype == _S.dtype:
+        return x.contiguous()
+    assert x.dtype == torch.float32, x.dtype
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=_S.dtype, device=x.device)
+    hip.check(hip.lib().st5_cast_from_f32(x.data_ptr(), out.data_ptr(), 1, x.numel(), 0, _dt(out), hip.stream()),
+              "st5_cast_from_f32")
+    return out
+
+
+def to_float(x):
+    if x.dtype == torch.float32:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().st5_cast_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), _dt(x), hip.stream()),
+              "st5_cast_to_f32")
+    return out
+
+
+class _ToCompute(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return to_compute(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_float(g)
+
+
+class _ToFloat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return to_float(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_compute(g)
+
+
+def as_compute(x):
+    """Differentiable cast fp32 -> compute dtype."""
+    return x if x.dtype == _S.dtype else _ToCompute.apply(x)
+
+
+def as_float(x):
+    """Differentiable cast compute dtype -> fp32 (model outputs consumed by the criterion)."""
+    return x if x.dtype == torch.float32 else _ToFloat.apply(x)
+
+
+# -------------------------------------------------------------------------------------------------
+# raw kernel wrappers (no autograd)
+# -------------------------------------------------------------------------------------------------
+def _colsum_into(x2d, ld, cols, out, col_off=0, scale=1.0):
+    """out[c] += scale * sum_r x2d[r, col_off + c]"""
+    rows = x2d.shape[0]
+    L = hip.lib()
+    ws = hip.workspace(L.st5_colsum_ws_bytes(rows, cols), x2d.device)
+    hip.check(L.st5_colsum_ws(x2d.data_ptr() + col_off * x2d.element_size(), out.data_ptr(), ws.data_ptr(), rows, cols,
+                              ld, scale, 1, _dt(x2d), hip.stream()), "st5_colsum_ws")
+
+
+def _dropout(x, p, seed):
+    y = torch.empty_like(x)
+    hip.check(hip.lib().st5_dropout(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _dt(x), hip.stream()), "st5_dropout")
+    return y
+
+
+def _padded(x2d, ld):
+    """Copy [M, N] into a zero-padded [M, ld] buffer (only for odd widths such as the vocabulary)."""
+    M, N = x2d.shape
+    if x2d.is_contiguous() and N == ld:
+        return x2d
+    out = torch.zeros(M, ld, dtype=x2d.dtype, device=x2d.device)
+    out[:, :N] = x2d  # strided device copy (glue; tiny tensors only)
+    return out
+
+
+def _rows(x):
+    """Dense row view [rows, C] of a contiguous tensor."""
+    assert x.is_contiguous()
+    return x.view(-1, x.shape[-1])
+
+
+# -------------------------------------------------------------------------------------------------
+# Linear (+ fused bias / activation / dropout / residual), N-fused over several weight matrices
+# -------------------------------------------------------------------------------------------------
+class LinearFunction(torch.autograd.Function):
+    """y = dropout(act(x W^T + b)) + residual with W = stack(weights).  Reference call sites: nn.Linear
+    in multihead_attention.py:213-231,397, speech_encoder_prenet.py:177, speech_decoder_prenet.py,
+    speech_decoder_postnet.py:61-63, text_decoder_postnet.py:59-65, speech_encoder_postnet.py:88."""
+
+    @staticmethod
+    def forward(ctx, x, residual, act, dropout_p, nw, *wb):
+        weights, biases = wb[:nw], wb[nw:]
+        dtype = x.dtype
+        x2 = _rows(x)
+        M, K = x2.shape
+        N = sum(w.shape[0] for w in weights)
+        ldn = _ceil8(N)
+        Wc = fused_weight(weights, dtype)
+        bc = fused_bias(biases)
+        y = torch.empty(M, ldn, dtype=dtype, device=x.device)
+        need_pre = act != ACT_NONE and any(ctx.needs_input_grad)
+        pre = torch.empty(M, ldn, dtype=dtype, device=x.device) if need_pre else None
+        seed = next_seed() if dropout_p > 0 else 0
+        if dropout_p > 0:
+            assert ldn == N, "dropout epilogue requires an 8-aligned output width"
+        res2 = None
+        if residual is not None:
+            res2 = _rows(residual)
+            assert res2.shape == (M, N) and ldn == N
+        if M > 0:
+            hip.gemm(hip.operand(x2, K), hip.operand(Wc, Wc.shape[1]), hip.operand(y, ldn), M, N, K, _dt(dtype),
+                     R=hip.operand(res2, ldn) if res2 is not None else None,
+                     Cpre=hip.operand(pre, ldn) if pre is not None else None,
+                     bias=bc, act=act, dropout_p=dropout_p, seed=seed)
+        ctx.save_for_backward(x2, pre, Wc)
+        ctx.meta = (weights, biases, act, dropout_p, seed, M, N, K, ldn, x.shape, residual is not None)
+        out = y if ldn == N else y[:, :N]
+        return out.reshape(x.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, pre, Wc = ctx.saved_tensors
+        weights, biases, act, p, seed, M, N, K, ldn, xshape, has_res = ctx.meta
+        dtype = x2.dtype
+        dy2 = dy.reshape(M, N)
+        d_res = dy if has_res else None
+        g = _padded(dy2, ldn) if (not dy2.is_contiguous() or ldn != N) else dy2
+        if M == 0:
+            return (torch.zeros(xshape, dtype=dtype, device=x2.device), d_res, None, None, None) + (None,) * (2 * len(weights))
+        if p > 0:
+            g = _dropout(g, p, seed)
+        if act != ACT_NONE:
+            g2 = torch.empty_like(g)
+            hip.check(hip.lib().st5_act_bwd(g.data_ptr(), pre.data_ptr(), g2.data_ptr(), g.numel(), act, _dt(g),
+                                            hip.stream()), "st5_act_bwd")
+            g = g2
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=dtype, device=x2.device)
+            # dX = G . W   (B operand k-strided: W is [N, K], reduction over N)
+            hip.gemm(hip.operand(g, ldn), hip.operand(Wc, Wc.shape[1]), hip.operand(dx, K), M, K, N, _dt(dtype),
+                     flags=hip.B_KSTRIDED)
+            dx = dx.view(xshape)
+        off = 0
+        for i, w in enumerate(weights):
+            n_i = w.shape[0]
+            if w.requires_grad:
+                gw = grad_buffer(w)
+                # dW_i += G[:, off:off+n_i]^T . X   (both operands k-strided, fp32 accumulate in place)
+                hip.gemm(hip.operand(g, ldn, off=off), hip.operand(x2, K), hip.operand(gw, K), n_i, K, M, _dt(dtype),
+                         flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0)
+                _grad_done(w)
+            b = biases[i]
+            if b is not None and b.requires_grad:
+                _colsum_into(g, ldn, n_i, grad_buffer(b), col_off=off)
+                _grad_done(b)
+            off += n_i
+        return (dx, d_res, None, None, None) + (None,) * (2 * len(weights))
+
+
+def linear(x, weights, biases=None, act=ACT_NONE, residual=None, dropout_p=0.0):
+    """x [..., K] (compute dtype); weights: a Parameter [N,K] or a list of them (outputs concatenated)."""
+    if isinstance(weights, torch.Tensor):
+        weights, biases = [weights], [biases]
+    if biases is None:
+        biases = [None] * len(weights)
+    x = x.contiguous()
+    y = LinearFunction.apply(x, residual, act, float(dropout_p), len(weights), *weights, *biases)
+    return y
+
+
+# -------------------------------------------------------------------------------------------------
+# Feed-forward block: fc1 + GELU (+dropout) + fc2 (+dropout) + residual, activation derivative fused
+# into the fc2 dgrad epilogue (transformer_layer.py:127-131, 385-389)
+# -------------------------------------------------------------------------------------------------
+class FFNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, w1, b1, w2, b2, act, p_act, p_out):
+        dtype = x.dtype
+        x2 = _rows(x)
+        M, d = x2.shape
+        Fd = w1.shape[0]
+        W1, W2 = fused_weight([w1], dtype), fused_weight([w2], dtype)
+        h = torch.empty(M, Fd, dtype=dtype, device=x.device)
+        hpre = torch.empty(M, Fd, dtype=dtype, device=x.device)
+        y = torch.empty(M, w2.shape[0], dtype=dtype, device=x.device)
+        s1 = next_seed() if p_act > 0 else 0
+        s2 = next_seed() if p_out > 0 else 0
+        res2 = _rows(residual) if residual is not None else None
+        hip.gemm(hip.operand(x2, d), hip.operand(W1, d), hip.operand(h, Fd), M, Fd, d, _dt(dtype), Cpre=hip.operand(hpre, Fd),
+                 bias=b1.detach(), act=act, dropout_p=p_act, seed=s1)
+        hip.gemm(hip.operand(h, Fd), hip.operand(W2, Fd), hip.operand(y, w2.shape[0]), M, w2.shape[0], Fd, _dt(dtype),
+                 R=hip.operand(res2, w2.shape[0]) if res2 is not None else None, bias=b2.detach(), dropout_p=p_out, seed=s2)
+        ctx.save_for_backward(x2, h, hpre, W1, W2)
+        ctx.meta = (w1, b1, w2, b2, act, p_act, p_out, s1, s2, x.shape, residual is not None)
+        return y.view(x.shape[:-1] + (w2.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, hpre, W1, W2 = ctx.saved_tensors
+        w1, b1, w2, b2, act, p_act, p_out, s1, s2, xshape, has_res = ctx.meta
+        dtype = x2.dtype
+        M, d = x2.shape
+        Fd, dout = w1.shape[0], w2.shape[0]
+        g = dy.contiguous().view(M, dout)
+        d_res = dy if has_res else None
+        if p_out > 0:
+            g = _dropout(g, p_out, s2)
+        # dHpre = (G . W2) * act'(Hpre) [* activation-dropout mask]   (fused epilogue)
+        dh = torch.empty(M, Fd, dtype=dtype, device=x2.device)
+        hip.gemm(hip.operand(g, dout), hip.operand(W2, Fd), hip.operand(dh, Fd), M, Fd, dout, _dt(dtype),
+                 P=hip.operand(hpre, Fd), act=act, flags=hip.B_KSTRIDED | hip.DACT, dropout_p=p_act, seed=s1)
+        if w2.requires_grad:
+            hip.gemm(hip.operand(g, dout), hip.operand(h, Fd), hip.operand(grad_buffer(w2), Fd), dout, Fd, M, _dt(dtype),
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0)
+            _grad_done(w2)
+        if b2.requires_grad:
+            _colsum_into(g, dout, dout, grad_buffer(b2))
+            _grad_done(b2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, d, dtype=dtype, device=x2.device)
+            hip.gemm(hip.operand(dh, Fd), hip.operand(W1, d), hip.operand(dx, d), M, d, Fd, _dt(dtype), flags=hip.B_KSTRIDED)
+            dx = dx.view(xshape)
+        if w1.requires_grad:
+            hip.gemm(hip.operand(dh, Fd), hip.operand(x2, d), hip.operand(grad_buffer(w1), d), Fd, d, M, _dt(dtype),
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0)
+            _grad_done(w1)
+        if b1.requires_grad:
+            _colsum_into(dh, Fd, Fd, grad_buffer(b1))
+            _grad_done(b1)
+        return dx, d_res, None, None, None, None, None, None, None
+
+
+def ffn(x, residual, fc1, fc2, act=ACT_GELU, p_act=0.0, p_out=0.0):
+    return FFNFunction.apply(x.contiguous(), residual, fc1.weight, fc1.bias, fc2.weight, fc2.bias, act, float(p_act), float(p_out))
+
+
+# -------------------------------------------------------------------------------------------------
+# LayerNorm
+# -------------------------------------------------------------------------------------------------
+class LayerNormFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x2 = _rows(x)
+        rows, cols = x2.shape
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().st5_layernorm_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                              rstd.data_ptr(), rows, cols, eps, _dt(x), hip.stream()), "st5_layernorm_fwd")
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.meta = (weight, bias, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        weight, bias, xshape = ctx.meta
+        rows, cols = x2.shape
+        g = dy.contiguous().view(rows, cols)
+        L = hip.lib()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gw = grad_buffer(weight) if weight.requires_grad else None
+        gb = grad_buffer(bias) if bias.requires_grad else None
+        ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows, cols), x2.device)
+        hip.check(L.st5_layernorm_bwd(g.data_ptr(), x2.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      hip.ptr(dx), hip.ptr(gw), hip.ptr(gb), ws.data_ptr(), rows, cols, _dt(x2),
+                                      hip.stream()), "st5_layernorm_bwd")
+        if gw is not None:
+            _grad_done(weight)
+        if gb is not None:
+            _grad_done(bias)
+        return (dx.view(xshape) if dx is not None else None), None, None, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    return LayerNormFunction.apply(x.contiguous(), weight, bias, float(eps))
+
+
+# -------------------------------------------------------------------------------------------------
+# Attention core (scores, rel-pos bias, masks, softmax, dropout, P.V) on projected q / k / v buffers
+# -------------------------------------------------------------------------------------------------
+def _attn_fwd(q, k, v, B, H, T, S, hd, pe, maxrel, kpm, causal, p_drop, seed):
+    """q/k/v: (tensor, ld, col_off) of projected activations, rows batch-major.  Returns ctx [B*T, H*hd],
+    probs [B*H, T, lds], probs_drop (or None)."""
+    qt, qld, qoff = q
+    kt, kld, koff = k
+    vt, vld, voff = v
+    dtype = qt.dtype
+    dev = qt.device
+    d = H * hd
+    lds = _ceil8(S)
+    alpha = hd ** -0.5
+    BH = B * H
+    scores = torch.empty(BH, T, lds, dtype=dtype, device=dev)
+    if lds != S:
+        scores[:, :, S:].zero_()
+    hip.gemm(hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd), hip.operand(kt, kld, off=koff, zs0=S * kld, zs1=hd),
+             hip.operand(scores, lds, zs0=H * T * lds, zs1=T * lds), T, S, hd, _dt(dtype), batch=BH, zdiv=H, alpha=alpha)
+    qp, nb = None, 0
+    if pe is not None:
+        nb = pe.shape[0]
+        qp = torch.empty(BH, T, nb, dtype=dtype, device=dev)
+        hip.gemm(hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd), hip.operand(pe, hd),
+                 hip.operand(qp, nb, zs0=H * T * nb, zs1=T * nb), T, nb, hd, _dt(dtype), batch=BH, zdiv=H, alpha=alpha)
+    probs = torch.empty(BH, T, lds, dtype=dtype, device=dev)
+    pdrop = torch.empty(BH, T, lds, dtype=dtype, device=dev) if p_drop > 0 else None
+    hip.check(hip.lib().st5_softmax_fwd(scores.data_ptr(), hip.ptr(qp), hip.ptr(kpm), probs.data_ptr(), hip.ptr(pdrop), BH, H,
+                                        T, S, lds, nb, maxrel, 1 if causal else 0, p_drop, seed, _dt(dtype), hip.stream()),
+              "st5_softmax_fwd")
+    ctx = torch.empty(B * T, d, dtype=dtype, device=dev)
+    pa = pdrop if pdrop is not None else probs
+    hip.gemm(hip.operand(pa, lds, zs0=H * T * lds, zs1=T * lds), hip.operand(vt, vld, off=voff, zs0=S * vld, zs1=hd),
+             hip.operand(ctx, d, zs0=T * d, zs1=hd), T, hd, S, _dt(dtype), batch=BH, zdiv=H, flags=hip.B_KSTRIDED)
+    return ctx, probs, pdrop
+
+
+def _attn_bwd(dctx, q, k, v, dq, dk, dv, probs, pdrop, dP_extra, B, H, T, S, hd, pe, want_dpe, maxrel, p_drop, seed):
+    """Writes dq/dk/dv = (tensor, ld, col_off) slices; returns dPE (fp32 [nb, hd]) or None."""
+    qt, qld, qoff = q
+    kt, kld, koff = k
+    vt, vld, voff = v
+    dqt, dqld, dqoff = dq
+    dkt, dkld, dkoff = dk
+    dvt, dvld, dvoff = dv
+    dtype = qt.dtype
+    dev = qt.device
+    d = H * hd
+    lds = probs.shape[2]
+    alpha = hd ** -0.5
+    BH = B * H
+    zP = dict(zs0=H * T * lds, zs1=T * lds)
+    # dP = dCtx . V^T
+    dP = torch.empty(BH, T, lds, dtype=dtype, device=dev)
+    hip.gemm(hip.operand(dctx, d, zs0=T * d, zs1=hd), hip.operand(vt, vld, off=voff, zs0=S * vld, zs1=hd),
+             hip.operand(dP, lds, **zP), T, S, hd, _dt(dtype), batch=BH, zdiv=H)
+    # dV = Pdrop^T . dCtx
+    pa = pdrop if pdrop is not None else probs
+    hip.gemm(hip.operand(pa, lds, **zP), hip.operand(dctx, d, zs0=T * d, zs1=hd),
+             hip.operand(dvt, dvld, off=dvoff, zs0=S * dvld, zs1=hd), S, hd, T, _dt(dtype), batch=BH, zdiv=H,
+             flags=hip.A_KSTRIDED | hip.B_KSTRIDED)
+    nb = pe.shape[0] if pe is not None else 0
+    dqp = torch.empty(BH, T, nb, dtype=dtype, device=dev) if pe is not None else None
+    hip.check(hip.lib().st5_softmax_bwd(dP.data_ptr(), probs.data_ptr(), hip.ptr(dP_extra), hip.ptr(dqp), BH, T, S, lds, nb,
+                                        maxrel, p_drop, seed, _dt(dtype), hip.stream()), "st5_softmax_bwd")
+    dS = dP
+    # dQ = alpha * dS . K  (+ alpha * dQP . PE)
+    hip.gemm(hip.operand(dS, lds, **zP), hip.operand(kt, kld, off=koff, zs0=S * kld, zs1=hd),
+             hip.operand(dqt, dqld, off=dqoff, zs0=T * dqld, zs1=hd), T, hd, S, _dt(dtype), batch=BH, zdiv=H,
+             flags=hip.B_KSTRIDED, alpha=alpha)
+    if pe is not None:
+        hip.gemm(hip.operand(dqp, nb, zs0=H * T * nb, zs1=T * nb), hip.operand(pe, hd),
+                 hip.operand(dqt, dqld, off=dqoff, zs0=T * dqld, zs1=hd), T, hd, nb, _dt(dtype), batch=BH, zdiv=H,
+                 flags=hip.B_KSTRIDED, alpha=alpha, beta=1.0)
+    # dK = alpha * dS^T . Q
+    hip.gemm(hip.operand(dS, lds, **zP), hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd),
+             hip.operand(dkt, dkld, off=dkoff, zs0=S * dkld, zs1=hd), S, hd, T, _dt(dtype), batch=BH, zdiv=H,
+             flags=hip.A_KSTRIDED | hip.B_KSTRIDED, alpha=alpha)
+    if pe is not None and want_dpe:
+        # dPE[h] = alpha * sum_b dQP[b,h]^T . Q[b,h]; then reduce over heads (fp32)
+        part = torch.empty(H, nb, hd, dtype=torch.float32, device=dev)
+        hip.gemm(hip.operand(dqp, nb, rpb=T, bstride=H * T * nb, zs0=T * nb),
+                 hip.operand(qt, qld, off=qoff, rpb=T, bstride=T * qld, zs0=hd),
+                 hip.operand(part, hd, zs0=nb * hd), nb, hd, B * T, _dt(dtype), batch=H, zdiv=1,
+                 flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, alpha=alpha)
+        g = torch.empty(nb, hd, dtype=torch.float32, device=dev)
+        L = hip.lib()
+        ws = hip.workspace(L.st5_colsum_ws_bytes(H, nb * hd), dev)
+        hip.check(L.st5_colsum_ws(part.data_ptr(), g.data_ptr(), ws.data_ptr(), H, nb * hd, nb * hd, 1.0, 0, hip.F32,
+                                  hip.stream()), "st5_colsum_ws")
+        return g
+    return None
+
+
+class SelfAttentionFunction(torch.autograd.Function):
+    """Fused-QKV self-attention core.  qkv [B*T, 3d] -> ctx [B*T, d].  `pe` is the relative-position key
+    table [2*maxrel, hd] in the compute dtype (a differentiable cast / norm_k of the parameter) or None."""
+
+    @staticmethod
+    def forward(ctx_, qkv, pe, kpm, cfg):
+        B, H, T, hd, maxrel, causal, p_drop = cfg
+        d = H * hd
+        seed = next_seed() if p_drop > 0 else 0
+        ctx, probs, pdrop = _attn_fwd((qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), B, H, T, T, hd, pe, maxrel,
+                                      kpm, causal, p_drop, seed)
+        ctx_.save_for_backward(qkv, probs, pdrop, pe)
+        ctx_.meta = (cfg, seed)
+        return ctx
+
+    @staticmethod
+    def backward(ctx_, dctx):
+        qkv, probs, pdrop, pe = ctx_.saved_tensors
+        (B, H, T, hd, maxrel, causal, p_drop), seed = ctx_.meta
+        d = H * hd
+        dqkv = torch.empty_like(qkv)
+        dpe = _attn_bwd(dctx.contiguous(), (qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), (dqkv, 3 * d, 0),
+                        (dqkv, 3 * d, d), (dqkv, 3 * d, 2 * d), probs, pdrop, None, B, H, T, T, hd, pe,
+                        pe is not None and ctx_.needs_input_grad[1], maxrel, p_drop, seed)
+        if dpe is not None and pe.dtype != torch.float32:
+            dpe = to_compute(dpe)
+        return dqkv, dpe, None, None
+
+
+class CrossAttentionFunction(torch.autograd.Function):
+    """q [B*T, d], kv [B*S, 2d] -> ctx [B*T, d] (+ probabilities [B*H, T, lds], differentiable: the
+    guided-attention loss of TTS fine-tuning back-propagates through them)."""
+
+    @staticmethod
+    def forward(ctx_, q, kv, kpm, cfg):
+        B, H, T, S, hd, p_drop, want_probs = cfg
+        d = H * hd
+        seed = next_seed() if p_drop > 0 else 0
+        ctx, probs, pdrop = _attn_fwd((q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), B, H, T, S, hd, None, 0, kpm, False, p_drop, seed)
+        ctx_.save_for_backward(q, kv, probs, pdrop)
+        ctx_.meta = (cfg, seed)
+        if want_probs:
+            pf = to_float(probs)[:, :, :S] if probs.shape[2] != S or probs.dtype != torch.float32 else probs
+            return ctx, pf.reshape(B, H, T, S)
+        return ctx, None
+
+    @staticmethod
+    def backward(ctx_, dctx, dprobs):
+        q, kv, probs, pdrop = ctx_.saved_tensors
+        (B, H, T, S, hd, p_drop, _), seed = ctx_.meta
+        d = H * hd
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        extra = None
+        if dprobs is not None:
+            extra = dprobs.reshape(B * H, T, S).float().contiguous()
+        if dctx is None:
+            dctx = torch.zeros(B * T, d, dtype=q.dtype, device=q.device)
+        _attn_bwd(dctx.contiguous(), (q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), (dq, d, 0), (dkv, 2 * d, 0), (dkv, 2 * d, d),
+                  probs, pdrop, extra, B, H, T, S, hd, None, False, 0, p_drop, seed)
+        return dq, dkv, None, None
+
+
+# -------------------------------------------------------------------------------------------------
+# element-wise helpers with autograd
+# -------------------------------------------------------------------------------------------------
+class ActFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        y = torch.empty_like(x)
+        hip.check(hip.lib().st5_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), act, _dt(x), hip.stream()), "st5_act_fwd")
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        hip.check(hip.lib().st5_act_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), ctx.act, _dt(x), hip.stream()),
+                  "st5_act_bwd")
+        return dx, None
+
+
+def activation(x, act):
+    return ActFunction.apply(x.contiguous(), act)
+
+
+class DropoutFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        ctx.p, ctx.seed = p, next_seed()
+        return _dropout(x, p, ctx.seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _dropout(dy.contiguous(), ctx.p, ctx.seed), None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFunction.apply(x.contiguous(), float(p))
+
+
+class AddScaledFunction(torch.autograd.Function):
+    """y = a + s * b (same shapes, compute dtype); s is a python float."""
+
+    @staticmethod
+    def forward(ctx, a, b, s):
+        y = a.clone()
+        hip.check(hip.lib().st5_axpby(b.data_ptr(), y.data_ptr(), y.numel(), s, 1.0, _dt(y), hip.stream()), "st5_axpby")
+        ctx.s = s
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        db = None
+        if ctx.needs_input_grad[1]:
+            db = torch.zeros_like(dy, memory_format=torch.contiguous_format)
+            dyc = dy.contiguous()
+            hip.check(hip.lib().st5_axpby(dyc.data_ptr(), db.data_ptr(), db.numel(), ctx.s, 0.0, _dt(db), hip.stream()), "st5_axpby")
+        return dy, db, None
+
+
+def add(a, b, scale=1.0):
+    return AddScaledFunction.apply(a.contiguous(), b.contiguous(), float(scale))
+
+
+class MaskedFillRowsFunction(torch.autograd.Function):
+    """x[mask] = v   (apply_hubert_mask, speech_encoder_prenet.py:249); v fp32 parameter [C]."""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8, v):
+        y = x.clone()
+        rows = y.numel() // y.shape[-1]
+        hip.check(hip.lib().st5_masked_fill_rows(y.data_ptr(), mask_u8.data_ptr(), v.data_ptr(), rows, y.shape[-1], _dt(y),
+                                                 hip.stream()), "st5_masked_fill_rows")
+        ctx.save_for_backward(mask_u8)
+        ctx.v = v
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask_u8,) = ctx.saved_tensors
+        dx = dy.clone(memory_format=torch.contiguous_format)
+        rows = dx.numel() // dx.shape[-1]
+        v = ctx.v
+        gv = grad_buffer(v) if v.requires_grad else None
+        hip.check(hip.lib().st5_masked_fill_rows_bwd(dx.data_ptr(), mask_u8.data_ptr(), hip.ptr(gv), rows, dx.shape[-1], _dt(dx),
+                                                     hip.stream()), "st5_masked_fill_rows_bwd")
+        if gv is not None:
+            _grad_done(v)
+        return dx, None, None
+
+
+def masked_fill_rows(x, mask_bool, v):
+    return MaskedFillRowsFunction.apply(x.contiguous(), mask_bool.to(torch.uint8).contiguous(), v)
+
+
+class AddTableRowsFunction(torch.autograd.Function):
+    """y[r] = x[r] + scale * table[idx[r]] with a constant fp32 table (sinusoidal positions)."""
+
+    @staticmethod
+    def forward(ctx, x, table, idx, scale):
+        y = torch.empty_like(x)
+        rows = x.numel() // x.shape[-1]
+        hip.check(hip.lib().st5_add_table_rows(x.data_ptr(), table.data_ptr(), idx.data_ptr(), y.data_ptr(), rows, x.shape[-1],
+                                               scale, _dt(x), hip.stream()), "st5_add_table_rows")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None, None
+
+
+def add_table_rows(x, table, idx, scale=1.0):
+    return AddTableRowsFunction.apply(x.contiguous(), table, idx.to(torch.int32).contiguous(), float(scale))
+
+
+class EmbedRowsFunction(torch.autograd.Function):
+    """y[r] = emb_scale * table[tok[r]] + pos_scale * pos[pidx[r]] (table: fp32 parameter, pos: constant)."""
+
+    @staticmethod
+    def forward(ctx, table, tok, pos, pidx, emb_scale, pos_scale, dtype):
+        rows, cols = tok.numel(), table.shape[1]
+        y = torch.empty(tuple(tok.shape) + (cols,), dtype=dtype, device=table.device)
+        hip.check(hip.lib().st5_embed_rows(table.data_ptr(), tok.data_ptr(), hip.ptr(pos), hip.ptr(pidx), y.data_ptr(), rows, cols,
+                                           emb_scale, pos_scale, _dt(dtype), hip.stream()), "st5_embed_rows")
+        ctx.save_for_backward(tok)
+        ctx.meta = (table, emb_scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tok,) = ctx.saved_tensors
+        table, emb_scale = ctx.meta
+        if table.requires_grad:
+            dy = dy.contiguous()
+            g = grad_buffer(table)
+            hip.check(hip.lib().st5_embed_rows_bwd(dy.data_ptr(), tok.data_ptr(), g.data_ptr(), tok.numel(), table.shape[1],
+                                                   emb_scale, _dt(dy), hip.stream()), "st5_embed_rows_bwd")
+            _grad_done(table)
+        return None, None, None, None, None, None, None
+
+
+def embed_rows(table, tok, pos=None, pidx=None, emb_scale=1.0, pos_scale=1.0):
+    return EmbedRowsFunction.apply(table, tok.to(torch.int32).contiguous(), pos,
+                                   pidx.to(torch.int32).contiguous() if pidx is not None else None,
+                                   float(emb_scale), float(pos_scale), _S.dtype)
+
+
+class SumSqFunction(torch.autograd.Function):
+    """mean(x^2) as an fp32 scalar (features_pen, speech_encoder_prenet.py:172)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        out = torch.zeros(1, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().st5_sumsq(x.data_ptr(), out.data_ptr(), x.numel(), 1.0 / x.numel(), 0, _dt(x), hip.stream()), "st5_sumsq")
+        ctx.save_for_backward(x)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        # d/dx mean(x^2) = 2x/n * g : g is a device scalar -> scale on device without a host sync
+        s = (g.float() * (2.0 / x.numel())).to(x.dtype)
+        return x * s  # (glue: one fused elementwise torch op on a tensor we already hold)
+
+
+def mean_square(x):
+    return SumSqFunction.apply(x.contiguous())
+
+
+# -------------------------------------------------------------------------------------------------
+# Speech feature extractor: conv0+GroupNorm+GELU kernel, then 6 strided Conv1d+GELU layers as implicit
+# GEMMs on channels-last activations (speech_encoder_prenet.py:290-354, mode "default")
+# -------------------------------------------------------------------------------------------------
+def _conv_w_fwd(w, dtype):
+    """[Cout, Cin, k] -> [Cout, k*Cin] compute dtype (cached)."""
+    def build():
+        src = w.detach().permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
+        out = torch.empty(src.shape, dtype=dtype, device=w.device)
+        _cast_into(src, out)
+        return out
+    return weight_cache.get(("convw", dtype, id(w)), [w], build)
+
+
+def _conv_w_even_odd(w, dtype):
+    """k=3, stride 2 transposed-conv weights: even rows use [W2; W0] ([2*Cout, Cin]), odd rows W1 ([Cout, Cin])."""
+    def build():
+        wd = w.detach()
+        ev = torch.cat([wd[:, :, 2], wd[:, :, 0]], 0).contiguous()
+        od = wd[:, :, 1].contiguous()
+        e = torch.empty(ev.shape, dtype=dtype, device=w.device)
+        o = torch.empty(od.shape, dtype=dtype, device=w.device)
+        _cast_into(ev, e)
+        _cast_into(od, o)
+        return e, o
+    return weight_cache.get(("convw_eo", dtype, id(w)), [w], build)
+
+
+class ConvFeatureExtractorFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wav, layers, gscale, w0, gn_w, gn_b, *ws):
+        """wav fp32 [B,S]; layers = [(dim,k,stride)]*; returns channels-last features [B,T,C] (compute dtype)."""
+        dtype = _S.dtype
+        dev = wav.device
+        B, S = wav.shape
+        L = hip.lib()
+        C0, k0, s0 = layers[0]
+        wav = wav.contiguous()
+        L0 = (S - k0) // s0 + 1
+        y = torch.empty(B, L0, C0, dtype=dtype, device=dev)
+        stats = torch.empty(B, C0, 2, dtype=torch.float32, device=dev)
+        wsb = hip.workspace(L.st5_conv0_ws_bytes(B, S, C0, k0, s0), dev)
+        w0f = w0.detach().reshape(C0, k0).contiguous()
+        hip.check(L.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), y.data_ptr(),
+                                          stats.data_ptr(), wsb.data_ptr(), B, S, C0, k0, s0, 1e-5, _dt(dtype), hip.stream()),
+                  "st5_conv0_gn_gelu_fwd")
+        acts, pres, lens = [y], [None], [L0]
+        x, Lin, Cin = y, L0, C0
+        for i, (C, k, s) in enumerate(layers[1:]):
+            Lo = (Lin - k) // s + 1
+            Wk = _conv_w_fwd(ws[i], dtype)
+            out = torch.empty(B, Lo, C, dtype=dtype, device=dev)
+            pre = torch.empty(B, Lo, C, dtype=dtype, device=dev)
+            hip.gemm(hip.operand(x, s * Cin, rpb=Lo, bstride=Lin * Cin), hip.operand(Wk, k * Cin), hip.operand(out, C),
+                     B * Lo, C, k * Cin, _dt(dtype), Cpre=hip.operand(pre, C), act=ACT_GELU)
+            acts.append(out); pres.append(pre); lens.append(Lo)
+            x, Lin, Cin = out, Lo, C
+        ctx.save_for_backward(wav, stats, *acts[:-1], *pres[1:])
+        ctx.meta = (layers, gscale, w0, gn_w, gn_b, ws, lens, B, S)
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        layers, gscale, w0, gn_w, gn_b, ws, lens, B, S = ctx.meta
+        saved = ctx.saved_tensors
+        wav, stats = saved[0], saved[1]
+        n = len(layers)
+        acts = saved[2:2 + n - 1]          # outputs of layers 0..n-2 (inputs of layers 1..n-1)
+        pres = (None,) + tuple(saved[2 + n - 1:])  # pre-activations of layers 1..n-1
+        dtype = dy.dtype
+        dev = dy.device
+        L = hip.lib()
+        C = layers[-1][0]
+        # top gradient: scale by feature_grad_mult (GradMultiply, :158-160) and apply GELU' of the last layer,
+        # written into the interior of a time-padded buffer (one zero row each side, used by the k=3 layers)
+        Ln = lens[-1]
+        g = dy.contiguous()
+        if gscale != 1.0:
+            g2 = torch.zeros_like(g)
+            hip.check(L.st5_axpby(g.data_ptr(), g2.data_ptr(), g.numel(), gscale, 0.0, _dt(g), hip.stream()), "st5_axpby")
+            g = g2
+        dpre = torch.empty(B, Ln + 2, C, dtype=dtype, device=dev)
+        dpre[:, 0].zero_(); dpre[:, -1].zero_()
+        tmp = torch.empty(B, Ln, C, dtype=dtype, device=dev)
+        hip.check(L.st5_act_bwd(g.data_ptr(), pres[-1].data_ptr(), tmp.data_ptr(), g.numel(), ACT_GELU, _dt(g), hip.stream()),
+                  "st5_act_bwd")
+        dpre[:, 1:-1] = tmp  # (glue copy of the smallest activation in the stack)
+        for li in range(n - 1, 0, -1):
+            Cout, k, s = layers[li]
+            Cin = layers[li - 1][0]
+            Lo, Lin = lens[li], lens[li - 1]
+            w = ws[li - 1]
+            xin = acts[li - 1]  # [B, Lin, Cin]
+            dint = dpre[:, 1:-1]  # interior view, row stride Cout, batch stride (Lo+2)*Cout
+            ioff = Cout  # element offset of the interior
+            if w.requires_grad:
+                tmpw = torch.empty(Cout, k * Cin, dtype=torch.float32, device=dev)
+                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout),
+                         hip.operand(xin, s * Cin, rpb=Lo, bstride=Lin * Cin), hip.operand(tmpw, k * Cin),
+                         Cout, k * Cin, B * Lo, _dt(dtype), flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
+                grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))  # (glue: layout permute of a 3 MB tensor)
+                _grad_done(w)
+            # data gradient into the (padded) pre-activation gradient of the previous layer
+            last = li == 1
+            if last:
+                nxt = torch.empty(B, Lin, Cin, dtype=dtype, device=dev)
+                noff, nbs = 0, Lin * Cin
+                P = None
+            else:
+                nxt = torch.empty(B, Lin + 2, Cin, dtype=dtype, device=dev)
+                nxt[:, 0].zero_(); nxt[:, -1].zero_()
+                noff, nbs = Cin, (Lin + 2) * Cin
+                P = pres[li - 1]
+            flags_d = 0 if last else hip.DACT
+            act_d = ACT_NONE if last else ACT_GELU
+            Wk = _conv_w_fwd(w, dtype)
+            if k == 2 and s == 2:
+                covered = 2 * Lo
+                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wk, k * Cin),
+                         hip.operand(nxt, 2 * Cin, off=noff, rpb=Lo, bstride=nbs), B * Lo, 2 * Cin, Cout, _dt(dtype),
+                         P=hip.operand(P, 2 * Cin, rpb=Lo, bstride=Lin * Cin) if P is not None else None,
+                         act=act_d, flags=hip.B_KSTRIDED | flags_d)
+            elif k == 3 and s == 2:
+                covered = 2 * Lo + 1
+                We, Wo = _conv_w_even_odd(w, dtype)
+                # even rows 2t' (t' = 0..Lo): [dpre[t'-1], dpre[t']] . [W2; W0]
+                hip.gemm(hip.operand(dpre, Cout, rpb=Lo + 1, bstride=(Lo + 2) * Cout), hip.operand(We, Cin),
+                         hip.operand(nxt, 2 * Cin, off=noff, rpb=Lo + 1, bstride=nbs), B * (Lo + 1), Cin, 2 * Cout, _dt(dtype),
+                         P=hip.operand(P, 2 * Cin, rpb=Lo + 1, bstride=Lin * Cin) if P is not None else None,
+                         act=act_d, flags=hip.B_KSTRIDED | flags_d)
+                # odd rows 2t'+1: dpre[t'] . W1
+                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wo, Cin),
+                         hip.operand(nxt, 2 * Cin, off=noff + Cin, rpb=Lo, bstride=nbs), B * Lo, Cin, Cout, _dt(dtype),
+                         P=hip.operand(P, 2 * Cin, off=Cin, rpb=Lo, bstride=Lin * Cin) if P is not None else None,
+                         act=act_d, flags=hip.B_KSTRIDED | flags_d)
+            else:
+                raise NotImplementedError(f"conv feature layer (k={k}, stride={s}) backward")
+            if covered < Lin:  # trailing input rows no output window touches
+                (nxt if last else nxt[:, 1:-1])[:, covered:].zero_()
+            dpre = nxt
+        # layer 0: conv(1->C) + GroupNorm + GELU backward (weights only; the waveform needs no gradient)
+        C0, k0, s0 = layers[0]
+        w0f = w0.detach().reshape(C0, k0).contiguous()
+        need = w0.requires_grad or gn_w.requires_grad or gn_b.requires_grad
+        if need:
+            wsb = hip.workspace(L.st5_conv0_ws_bytes(B, S, C0, k0, s0), dev)
+            gw0 = grad_buffer(w0) if w0.requires_grad else None
+            hip.check(L.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), stats.data_ptr(),
+                                              dpre.data_ptr(), hip.ptr(gw0), hip.ptr(grad_buffer(gn_w)) if gn_w.requires_grad else 0,
+                                              hip.ptr(grad_buffer(gn_b)) if gn_b.requires_grad else 0, wsb.data_ptr(), B, S, C0, k0, s0,
+                                              1.0, _dt(dtype), hip.stream()), "st5_conv0_gn_gelu_bwd")
+            for p in (w0, gn_w, gn_b):
+                if p.requires_grad:
+                    _grad_done(p)
+        return (None, None, None, None, None, None) + (None,) * len(ws)
+
+
+def conv_feature_extractor(wav, layers, gscale, w0, gn_w, gn_b, ws):
+    return ConvFeatureExtractorFunction.apply(wav, tuple(layers), float(gscale), w0, gn_w, gn_b, *ws)
+
+
+# -------------------------------------------------------------------------------------------------
+# Positional convolution: x + GELU(grouped Conv1d(k, groups, pad k//2) [SamePad]) (speech_encoder_prenet.py:187-192)
+# -------------------------------------------------------------------------------------------------
+class PosConvFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, groups):
+        """x [B,T,d] compute dtype; w fp32 [d, d/groups, k] (already weight-normalised, differentiable)."""
+        dtype = x.dtype
+        dev = x.device
+        B, T, d = x.shape
+        k = w.shape[2]
+        cg = d // groups
+        assert k % 2 == 0 and cg % 8 == 0
+        L = hip.lib()
+        pl, pr = k // 2, k // 2
+        xp = torch.empty(B, T + pl + pr, d, dtype=dtype, device=dev)
+        hip.check(L.st5_pad_time(x.data_ptr(), xp.data_ptr(), B, T, d, pl, pr, _dt(dtype), hip.stream()), "st5_pad_time")
+        # [G][cg_out][k][cg_in]
+        wf = w.detach().view(groups, cg, cg, k).permute(0, 1, 3, 2).contiguous().view(groups * cg, k * cg)
+        Wg = torch.empty(wf.shape, dtype=dtype, device=dev)
+        _cast_into(wf, Wg)
+        y = torch.empty(B, T, d, dtype=dtype, device=dev)
+        pre = torch.empty(B, T, d, dtype=dtype, device=dev)
+        hip.gemm(hip.operand(xp, d, rpb=T, bstride=(T + pl + pr) * d, seg=cg, seg_stride=d, zs0=cg),
+                 hip.operand(Wg, k * cg, zs0=cg * k * cg), hip.operand(y, d, zs0=cg), B * T, cg, k * cg, _dt(dtype), batch=groups,
+                 R=hip.operand(x, d, zs0=cg), Cpre=hip.operand(pre, d, zs0=cg), bias=bias.detach(), bias_zs=cg, act=ACT_GELU)
+        ctx.save_for_backward(xp, pre, w)
+        ctx.meta = (bias, groups, B, T, d, k, cg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, pre, w = ctx.saved_tensors
+        bias, groups, B, T, d, k, cg = ctx.meta
+        dtype = dy.dtype
+        dev = dy.device
+        L = hip.lib()
+        dy = dy.contiguous()
+        dpre = torch.empty_like(dy)
+        hip.check(L.st5_act_bwd(dy.data_ptr(), pre.data_ptr(), dpre.data_ptr(), dy.numel(), ACT_GELU, _dt(dtype), hip.stream()),
+                  "st5_act_bwd")
+        if bias.requires_grad:
+            _colsum_into(dpre.view(B * T, d), d, d, grad_buffer(bias))
+            _grad_done(bias)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dwg = torch.empty(groups, cg, k * cg, dtype=torch.float32, device=dev)
+            hip.gemm(hip.operand(dpre, d, zs0=cg),
+                     hip.operand(xp, d, rpb=T, bstride=xp.shape[1] * d, seg=cg, seg_stride=d, zs0=cg),
+                     hip.operand(dwg, k * cg, zs0=cg * k * cg), cg, k * cg, B * T, _dt(dtype), batch=groups,
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
+            dw = dwg.view(groups, cg, k, cg).permute(0, 1, 3, 2).reshape(d, cg, k)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dx[t'] = dy[t'] + sum_{jj,o} dpre_pad[t'+jj, o] * W[o, c, k-1-jj]   (window of k rows starting at t')
+            pl = k // 2 - 1
+            pr = k // 2
+            dpp = torch.empty(B, T + pl + pr, d, dtype=dtype, device=dev)
+            hip.check(L.st5_pad_time(dpre.data_ptr(), dpp.data_ptr(), B, T, d, pl, pr, _dt(dtype), hip.stream()), "st5_pad_time")
+            wf = w.detach().view(groups, cg, cg, k).flip(-1).permute(0, 2, 3, 1).contiguous().view(groups * cg, k * cg)
+            Wf = torch.empty(wf.shape, dtype=dtype, device=dev)
+            _cast_into(wf, Wf)
+            dx = torch.empty(B, T, d, dtype=dtype, device=dev)
+            hip.gemm(hip.operand(dpp, d, rpb=T, bstride=(T + pl + pr) * d, seg=cg, seg_stride=d, zs0=cg),
+                     hip.operand(Wf, k * cg, zs0=cg * k * cg), hip.operand(dx, d, zs0=cg), B * T, cg, k * cg, _dt(dtype),
+                     batch=groups, R=hip.operand(dy, d, zs0=cg))
+        return dx, dw, None, None
+
+
+def pos_conv(x, w, bias, groups):
+    return PosConvFunction.apply(x.contiguous(), w, bias, int(groups))
+
+
+# -------------------------------------------------------------------------------------------------
+# Conv1d(k odd, stride 1, "same" zero padding, no bias) on channels-last activations as implicit GEMM
+# (espnet Postnet convs, speech_decoder_postnet.py:39-51)
+# -------------------------------------------------------------------------------------------------
+class Conv1dSameFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        """x [B,L,Cin] compute dtype; w fp32 parameter [Cout,Cin,k] -> [B,L,Cout]."""
+        dtype = x.dtype
+        B, Lx, Cin = x.shape
+        Cout, _, k = w.shape
+        p = (k - 1) // 2
+        xp = torch.empty(B, Lx + 2 * p, Cin, dtype=dtype, device=x.device)
+        hip.check(hip.lib().st5_pad_time(x.data_ptr(), xp.data_ptr(), B, Lx, Cin, p, p, _dt(dtype), hip.stream()), "st5_pad_time")
+        Wk = _conv_w_fwd(w, dtype)
+        y = torch.empty(B, Lx, Cout, dtype=dtype, device=x.device)
+        hip.gemm(hip.operand(xp, Cin, rpb=Lx, bstride=(Lx + 2 * p) * Cin), hip.operand(Wk, k * Cin), hip.operand(y, Cout),
+                 B * Lx, Cout, k * Cin, _dt(dtype))
+        ctx.save_for_backward(xp)
+        ctx.meta = (w, B, Lx, Cin, Cout, k, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xp,) = ctx.saved_tensors
+        w, B, Lx, Cin, Cout, k, p = ctx.meta
+        dtype = dy.dtype
+        dev = dy.device
+        dy = dy.contiguous()
+        if w.requires_grad:
+            tmpw = torch.empty(Cout, k * Cin, dtype=torch.float32, device=dev)
+            hip.gemm(hip.operand(dy, Cout), hip.operand(xp, Cin, rpb=Lx, bstride=(Lx + 2 * p) * Cin), hip.operand(tmpw, k * Cin),
+                     Cout, k * Cin, B * Lx, _dt(dtype), flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
+            grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))
+            _grad_done(w)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dyp = torch.empty(B, Lx + 2 * p, Cout, dtype=dtype, device=dev)
+            hip.check(hip.lib().st5_pad_time(dy.data_ptr(), dyp.data_ptr(), B, Lx, Cout, p, p, _dt(dtype), hip.stream()), "st5_pad_time")
+
+            def build():
+                src = w.detach().flip(-1).permute(1, 2, 0).reshape(Cin, k * Cout).contiguous()  # [ci][jj][co]
+                out = torch.empty(src.shape, dtype=dtype, device=dev)
+                _cast_into(src, out)
+                return out
+            Wd = weight_cache.get(("convw_d", dtype, id(w)), [w], build)
+            dx = torch.empty(B, Lx, Cin, dtype=dtype, device=dev)
+            hip.gemm(hip.operand(dyp, Cout, rpb=Lx, bstride=(Lx + 2 * p) * Cout), hip.operand(Wd, k * Cout), hip.operand(dx, Cin),
+                     B * Lx, Cin, k * Cout, _dt(dtype))
+        return dx, None
+
+
+def conv1d_same(x, w):
+    return Conv1dSameFunction.apply(x.contiguous(), w)

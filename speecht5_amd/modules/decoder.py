@@ -1,0 +1,90 @@
+"""TransformerDecoder mirror of SpeechT5/speecht5/models/modules/decoder.py:33-324."""
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from ..fairseq_compat import FairseqIncrementalDecoder
+from .common import LayerNorm
+from .encoder import RelativePositionalEncoding
+from .transformer_layer import TransformerDecoderLayer
+
+
+class TransformerDecoder(FairseqIncrementalDecoder):
+    def __init__(self, args, no_encoder_attn=False):
+        self.args = args
+        super().__init__(None)
+        self.register_buffer("version", torch.Tensor([3]))
+        self.dropout = args.dropout
+        self.decoder_layerdrop = args.decoder_layerdrop
+        self.cross_self_attention = getattr(args, "cross_self_attention", False)
+        assert not self.cross_self_attention
+        self.layers = nn.ModuleList([self.build_decoder_layer(args, no_encoder_attn) for _ in range(args.decoder_layers)])
+        self.num_layers = len(self.layers)
+        if args.decoder_normalize_before and not getattr(args, "no_decoder_final_norm", False):
+            self.layer_norm = LayerNorm(args.decoder_embed_dim, eps=args.layer_norm_eps)
+        else:
+            self.layer_norm = None
+        if args.relative_position_embedding:  # built but unused by the layers (decoder.py:83-84, transformer_layer.py:241)
+            self.pos_emb = RelativePositionalEncoding(args.encoder_embed_dim // args.encoder_attention_heads,
+                                                      args.decoder_max_relative_position)
+
+    def build_decoder_layer(self, args, no_encoder_attn=False):
+        return TransformerDecoderLayer(args, no_encoder_attn=no_encoder_attn,
+                                       has_relative_attention_bias=args.relative_position_embedding)
+
+    def forward(self, prev_output_tokens, tgt_mask, encoder_out=None, incremental_state=None, full_context_alignment=False,
+                alignment_layer=None, alignment_heads=None, src_lengths=None, return_all_hiddens=False):
+        return self.extract_features(prev_output_tokens, tgt_mask, encoder_out=encoder_out, incremental_state=incremental_state,
+                                     full_context_alignment=full_context_alignment, alignment_layer=alignment_layer,
+                                     alignment_heads=alignment_heads)
+
+    def extract_features(self, prev_output_tokens, tgt_mask, encoder_out, incremental_state=None, full_context_alignment=False,
+                         alignment_layer=None, alignment_heads=None):
+        return self.extract_features_scriptable(prev_output_tokens, tgt_mask, encoder_out, incremental_state,
+                                                full_context_alignment, alignment_layer, alignment_heads)
+
+    def extract_features_scriptable(self, prev_output_tokens, tgt_mask, encoder_out, incremental_state=None,
+                                    full_context_alignment=False, alignment_layer=None, alignment_heads=None):
+        """prev_output_tokens: decoder pre-net output [B,T,C].  With `incremental_state` the whole prefix is
+        expected (the pre-nets hand it over) and recomputed: numerically the reference's KV-cache path."""
+        B, T, C = prev_output_tokens.shape
+        if alignment_layer is None:
+            alignment_layer = self.num_layers - 1
+        enc_rows, S, enc_pad = None, None, None
+        if encoder_out is not None and len(encoder_out["encoder_out"]) > 0:
+            enc = encoder_out["encoder_out"][0]  # T x B x C
+            assert enc.size(1) == B, f"Expected enc.shape == (t, {B}, c) got {enc.shape}"
+            S = enc.size(0)
+            enc_rows = Fn.as_compute(enc.transpose(0, 1).contiguous()).view(B * S, -1)
+        if encoder_out is not None and len(encoder_out["encoder_padding_mask"]) > 0:
+            enc_pad = encoder_out["encoder_padding_mask"][0]
+        x = Fn.as_compute(prev_output_tokens.contiguous()).view(B * T, C)
+        causal = not full_context_alignment
+        attn_list, attn = [], None
+        inner_states = [x.view(B, T, C).transpose(0, 1)]
+        for idx, layer in enumerate(self.layers):
+            if self.training and self.decoder_layerdrop > 0 and float(torch.empty(1).uniform_()) <= self.decoder_layerdrop:
+                continue  # LayerDropModuleList semantics (torch RNG)
+            want = bool(idx == alignment_layer or alignment_layer == -1)
+            x, layer_attn = layer.forward_rows(x, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want)
+            inner_states.append(x.view(B, T, C).transpose(0, 1))
+            if layer_attn is not None and want:
+                attn = layer_attn.transpose(0, 1)       # [H,B,T,S] as the reference's per-head weights
+                attn_list.append(layer_attn)             # [B,H,T,S] (= attn.transpose(0,1))
+        if attn is not None and len(attn_list) == 1:
+            if alignment_heads is not None:
+                attn = attn[:alignment_heads]
+            attn = attn.mean(dim=0)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        x = x.view(B, T, C)
+        return x, {"attn": [attn if len(attn_list) <= 1 else attn_list], "inner_states": inner_states}
+
+    def reorder_incremental_state_scripting(self, incremental_state, new_order):
+        return incremental_state  # the prefix is recomputed each step: nothing is cached
+
+    def set_num_updates(self, num_updates):
+        def _apply(m):
+            if hasattr(m, "set_num_updates") and m != self:
+                m.set_num_updates(num_updates)
+        self.apply(_apply)

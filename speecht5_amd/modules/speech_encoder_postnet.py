@@ -1,0 +1,61 @@
+"""SpeechEncoderPostnet (HuBERT NCE head) mirror of
+SpeechT5/speecht5/models/modules/speech_encoder_postnet.py:17-124."""
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+
+
+class SpeechEncoderPostnet(nn.Module):
+    def __init__(self, dictionaries, args):
+        super().__init__()
+        assert not args.target_glu
+        self.target_glu = None
+        self.skip_masked = args.skip_masked
+        self.skip_nomask = args.skip_nomask
+        self.logit_temp = args.logit_temp
+        final_dim = args.final_dim if args.final_dim > 0 else args.encoder_embed_dim
+        if not any(d is None for d in dictionaries):
+            self.num_classes = [len(d) for d in dictionaries]
+            self.label_embs_concat = nn.Parameter(torch.FloatTensor(sum(self.num_classes), final_dim))
+            nn.init.uniform_(self.label_embs_concat)
+        self.untie_final_proj = args.untie_final_proj
+        self.final_proj = nn.Linear(args.encoder_embed_dim, final_dim * len(dictionaries) if self.untie_final_proj else final_dim)
+
+    def compute_nce(self, x, pos, negs_emb, target):
+        """logits[s] = [cos(x_s, pos_s), cos(x_s, e_0), ..., cos(x_s, e_{V-1})] / temp with -inf where e_c == pos_s.
+        The projection x comes from the HIP GEMM; the cosine similarity against the 504 x 256 code book and
+        the [S, 505] assembly are small fp32 torch ops (criterion-side arithmetic)."""
+        xf = torch.nn.functional.normalize(x.float(), dim=-1, eps=1e-8)
+        ef = torch.nn.functional.normalize(negs_emb.float(), dim=-1, eps=1e-8)
+        sim = xf @ ef.t()                                   # [S, V]
+        pos_sim = sim.gather(1, target.long().unsqueeze(1))  # [S, 1]
+        # neg c duplicates the positive iff code-book rows c and target are identical: [V,V] row-equality table
+        same = (negs_emb.unsqueeze(0) == negs_emb.unsqueeze(1)).all(-1)
+        sim = sim.masked_fill(same[target.long()], float("-inf"))
+        return torch.cat([pos_sim, sim], dim=1) / self.logit_temp
+
+    def forward(self, x, padding_mask, mask_indices, target_list):
+        """x [B,T,C] (compute dtype).  Boolean-index gathers are torch glue, the projection is the HIP GEMM."""
+        label_embs_list = self.label_embs_concat.split(self.num_classes, 0)
+
+        def branch(sel):
+            rows = x[sel]  # [S, C]
+            proj = Fn.linear(rows.contiguous(), self.final_proj.weight, self.final_proj.bias)
+            projs = proj.chunk(len(target_list), dim=-1) if self.untie_final_proj else [proj] * len(target_list)
+            outs = []
+            for i, (p, t) in enumerate(zip(projs, target_list)):
+                tg = t[sel]
+                emb = label_embs_list[i]
+                outs.append(self.compute_nce(Fn.as_float(p.contiguous()), emb[tg.long()], emb, tg))
+            return outs
+
+        if not self.skip_masked:
+            logit_m_list = branch(torch.logical_and(~padding_mask, mask_indices))
+        else:
+            logit_m_list = [None for _ in target_list]
+        if not self.skip_nomask:
+            logit_u_list = branch(torch.logical_and(~padding_mask, ~mask_indices))
+        else:
+            logit_u_list = [None for _ in target_list]
+        return {"logit_m_list": logit_m_list, "logit_u_list": logit_u_list, "padding_mask": padding_mask}

@@ -1,0 +1,171 @@
+"""SpeechEncoderPrenet / ConvFeatureExtractionModel mirrors of
+SpeechT5/speecht5/models/modules/speech_encoder_prenet.py:58-374 on the HIP kernels."""
+import contextlib
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from ..data_utils import compute_mask_indices, lengths_to_padding_mask
+from .common import LayerNorm, SinusoidalPositionalEmbedding
+
+
+class ConvFeatureExtractionModel(nn.Module):
+    """Parameter container with the reference's names (conv_layers.{i}.0.weight, conv_layers.0.2.{weight,bias});
+    forward = conv0+GroupNorm+GELU kernel followed by 6 implicit-GEMM conv layers, output channels-last."""
+
+    def __init__(self, conv_layers, dropout=0.0, mode="default", conv_bias=False):
+        super().__init__()
+        assert mode in {"default", "layer_norm"}
+        if mode != "default" or conv_bias or dropout != 0.0:
+            raise NotImplementedError("only extractor_mode=default without conv bias/dropout has HIP kernels (Base configs)")
+        self.conv_layers = nn.ModuleList()
+        self.conv_layers_infos = conv_layers
+        in_d = 1
+        for i, (dim, k, stride) in enumerate(conv_layers):
+            conv = nn.Conv1d(in_d, dim, k, stride=stride, bias=False)
+            nn.init.kaiming_normal_(conv.weight)
+            if i == 0:
+                block = nn.Sequential(conv, nn.Dropout(p=dropout), nn.GroupNorm(dim, dim, affine=True), nn.GELU())
+            else:
+                block = nn.Sequential(conv, nn.Dropout(p=dropout), nn.GELU())
+            self.conv_layers.append(block)
+            in_d = dim
+
+    def forward(self, x, grad_scale=1.0):
+        """x: waveform [B, S] fp32 -> features [B, T, C] (channels-last, compute dtype)."""
+        l0 = self.conv_layers[0]
+        ws = [blk[0].weight for blk in list(self.conv_layers)[1:]]
+        return Fn.conv_feature_extractor(x.float(), self.conv_layers_infos, grad_scale, l0[0].weight, l0[2].weight, l0[2].bias, ws)
+
+    def get_out_seq_lens_tensor(self, in_seq_lens_tensor):
+        out = in_seq_lens_tensor.clone()
+        for _, k, s in self.conv_layers_infos:
+            out = ((out.float() - (k - 1) - 1) / s + 1).floor().long()
+        return out
+
+    def get_out_seq_lens_nonmask_after_a_layer(self, in_seq_lens_tensor, i):
+        out = in_seq_lens_tensor.clone()
+        out = ((out.float() - (self.conv_layers_infos[i][1] - 1) - 1) / self.conv_layers_infos[i][-1] + 1).floor().long()
+        return (~lengths_to_padding_mask(out)).float(), out
+
+
+class SpeechEncoderPrenet(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.dropout = args.dropout
+        self.padding_idx = 1
+        self.freeze_encoder_updates = args.freeze_encoder_updates
+        self.num_updates = 0
+        assert args.encoder_speech_prenet == "conv", args.encoder_speech_prenet
+        feature_enc_layers = eval(args.conv_feature_layers)  # noqa
+        self.embed = feature_enc_layers[-1][0]
+        self.feature_extractor = ConvFeatureExtractionModel(conv_layers=feature_enc_layers, dropout=0.0,
+                                                            mode=args.extractor_mode, conv_bias=args.conv_bias)
+        feature_ds_rate = np.prod([s for _, _, s in feature_enc_layers])
+        self.feat2tar_ratio = args.label_rates * feature_ds_rate / args.sample_rate
+        self.post_extract_proj = nn.Linear(self.embed, args.encoder_embed_dim) if self.embed != args.encoder_embed_dim else None
+        self.use_conv_pos = args.use_conv_pos
+        self.use_sinc_pos = args.use_sinc_pos
+        self.use_abs_pos = getattr(args, "use_abs_pos", False)
+        assert not self.use_abs_pos
+        self.feature_grad_mult = args.feature_grad_mult
+        self.conv_pos_groups = args.conv_pos_groups
+        if self.use_conv_pos:
+            self.layer_norm = LayerNorm(self.embed)
+            pos_conv = nn.Conv1d(args.encoder_embed_dim, args.encoder_embed_dim, kernel_size=args.conv_pos,
+                                 padding=args.conv_pos // 2, groups=args.conv_pos_groups)
+            std = math.sqrt(4 / (args.conv_pos * args.encoder_embed_dim))
+            nn.init.normal_(pos_conv.weight, mean=0, std=std)
+            nn.init.constant_(pos_conv.bias, 0)
+            pos_conv = nn.utils.weight_norm(pos_conv, name="weight", dim=2)
+            self.pos_conv = nn.Sequential(pos_conv, nn.Identity(), nn.GELU())  # index 0 keeps "pos_conv.0.*" names
+        if self.use_sinc_pos:
+            self.embed_positions = SinusoidalPositionalEmbedding(args.encoder_embed_dim, self.padding_idx)
+        self.mask_prob = args.mask_prob
+        self.mask_selection = args.mask_selection
+        self.mask_other = args.mask_other
+        self.hubert_mask_length = args.hubert_mask_length
+        self.no_mask_overlap = args.no_mask_overlap
+        self.mask_min_space = args.mask_min_space
+        self.mask_channel_prob = args.mask_channel_prob
+        self.mask_channel_selection = args.mask_channel_selection
+        self.mask_channel_other = args.mask_channel_other
+        self.mask_channel_length = args.mask_channel_length
+        self.no_mask_channel_overlap = args.no_mask_channel_overlap
+        self.mask_channel_min_space = args.mask_channel_min_space
+        self.mask_emb = nn.Parameter(torch.FloatTensor(args.encoder_embed_dim).uniform_())
+
+    def forward(self, src_tokens, require_feat_pen=False, target_list=None, padding_mask=None, mask=True):
+        ft = self.freeze_encoder_updates <= self.num_updates
+        with torch.no_grad() if not ft else contextlib.ExitStack():
+            return self._forward(src_tokens, require_feat_pen, target_list, padding_mask, mask)
+
+    def _forward(self, src_tokens, require_feat_pen=False, target_list=None, padding_mask=None, mask=True):
+        if self.feature_grad_mult > 0:
+            x = self.feature_extractor(src_tokens, grad_scale=self.feature_grad_mult)  # [B, T, C]
+        else:
+            with torch.no_grad():
+                x = self.feature_extractor(src_tokens)
+        if target_list is not None:
+            x, target_list = self.forward_targets(x, target_list)
+        features_pen = Fn.mean_square(x) if require_feat_pen else None
+        x = self.layer_norm(x)
+        encoder_padding_mask = self.forward_padding_mask(x, padding_mask)
+        if self.post_extract_proj is not None:
+            x = Fn.linear(x, self.post_extract_proj.weight, self.post_extract_proj.bias)
+        x = Fn.dropout(x, self.dropout, self.training)
+        if mask:
+            x, mask_indices = self.apply_hubert_mask(x, encoder_padding_mask)
+        else:
+            mask_indices = None
+        if self.use_conv_pos:
+            conv = self.pos_conv[0]
+            w = torch._weight_norm(conv.weight_v, conv.weight_g, 2)  # g * v / ||v||  (parameter glue, 4.7 M elements)
+            x = Fn.pos_conv(x, w, conv.bias, self.conv_pos_groups)
+        if self.use_sinc_pos:
+            positions = self.embed_positions.positions(~encoder_padding_mask)
+            table = self.embed_positions.table(x.shape[1] + self.padding_idx + 2, x.device)
+            x = Fn.add_table_rows(x, table, positions.reshape(-1))
+        if require_feat_pen:
+            return (x, features_pen, mask_indices, target_list), encoder_padding_mask
+        return x, encoder_padding_mask
+
+    def forward_targets(self, features, target_list):
+        """features are channels-last here ([B,T,C]); same trimming rule as the reference (:206-217)."""
+        feat_tsz = features.size(1)
+        targ_tsz = min([t.size(1) for t in target_list])
+        if self.feat2tar_ratio * feat_tsz > targ_tsz:
+            feat_tsz = int(targ_tsz / self.feat2tar_ratio)
+            features = features[:, :feat_tsz].contiguous()
+        target_inds = torch.arange(feat_tsz).float() * self.feat2tar_ratio
+        target_list = [t[:, target_inds.long()] for t in target_list]
+        return features, target_list
+
+    def forward_padding_mask(self, features, padding_mask):
+        extra = padding_mask.size(1) % features.size(1)
+        if extra > 0:
+            padding_mask = padding_mask[:, :-extra]
+        padding_mask = padding_mask.view(padding_mask.size(0), features.size(1), -1)
+        return padding_mask.all(-1)
+
+    def get_src_lengths(self, src_lengths):
+        return self.feature_extractor.get_out_seq_lens_tensor(src_lengths)
+
+    def apply_hubert_mask(self, x, padding_mask):
+        B, T, C = x.shape
+        mask_indices = None
+        if self.mask_prob > 0:
+            m = compute_mask_indices((B, T), padding_mask.cpu() if padding_mask is not None else None, self.mask_prob,
+                                     self.hubert_mask_length, self.mask_selection, self.mask_other, min_masks=2,
+                                     no_overlap=self.no_mask_overlap, min_space=self.mask_min_space)
+            mask_indices = torch.from_numpy(m).to(x.device)
+            x = Fn.masked_fill_rows(x, mask_indices.reshape(-1), self.mask_emb)
+        if self.mask_channel_prob > 0:
+            raise NotImplementedError("channel masking (ASR fine-tuning regulariser) has no HIP kernel yet")
+        return x, mask_indices
+
+    def set_num_updates(self, num_updates):
+        self.num_updates = num_updates

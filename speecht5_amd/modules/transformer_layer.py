@@ -1,0 +1,142 @@
+"""Encoder / decoder layer mirrors of SpeechT5/speecht5/models/modules/transformer_layer.py:23-411."""
+import contextlib
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .common import LayerNorm
+from .multihead_attention import MultiheadAttention, RelPosKeys
+
+_ACTS = {"gelu": Fn.ACT_GELU, "relu": Fn.ACT_RELU, "tanh": Fn.ACT_TANH, "linear": Fn.ACT_NONE}
+
+
+class TransformerSentenceEncoderLayer(nn.Module):
+    def __init__(self, embedding_dim=768, ffn_embedding_dim=3072, num_attention_heads=8, dropout=0.1,
+                 attention_dropout=0.1, activation_dropout=0.1, activation_fn="relu", layer_norm_first=False,
+                 has_relative_attention_bias=False):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.dropout = dropout
+        self.activation_dropout = activation_dropout
+        self.act = _ACTS[activation_fn]
+        self.self_attn = MultiheadAttention(embedding_dim, num_attention_heads, dropout=attention_dropout,
+                                            self_attention=True, has_relative_attention_bias=has_relative_attention_bias)
+        self.layer_norm_first = layer_norm_first
+        self.self_attn_layer_norm = LayerNorm(embedding_dim)
+        self.fc1 = nn.Linear(embedding_dim, ffn_embedding_dim)
+        self.fc2 = nn.Linear(ffn_embedding_dim, embedding_dim)
+        self.final_layer_norm = LayerNorm(embedding_dim)
+        if has_relative_attention_bias:
+            self.norm_k = LayerNorm(embedding_dim // num_attention_heads)
+
+    def forward_rows(self, x, B, T, padding_mask=None, pos_bias=None):
+        """x rows [B*T, C] -> rows.  Post-LN (:112-132) or pre-LN (:90-111)."""
+        tr = self.training
+        p, pa = (self.dropout if tr else 0.0), (self.activation_dropout if tr else 0.0)
+        if self.layer_norm_first:
+            h = self.self_attn_layer_norm(x)
+            pb = pos_bias
+            if pos_bias is not None:
+                pb = RelPosKeys(self.norm_k(pos_bias.table), pos_bias.maxlen)
+            x, _ = self.self_attn.forward_rows(h, B, T, key_padding_mask=padding_mask, position_bias=pb, residual=x, out_dropout=p)
+            h = self.final_layer_norm(x)
+            x = Fn.ffn(h, x, self.fc1, self.fc2, self.act, pa, p)
+        else:
+            x, _ = self.self_attn.forward_rows(x, B, T, key_padding_mask=padding_mask, position_bias=pos_bias, residual=x,
+                                               out_dropout=p)
+            x = self.self_attn_layer_norm(x)
+            x = Fn.ffn(x, x, self.fc1, self.fc2, self.act, pa, p)
+            x = self.final_layer_norm(x)
+        return x
+
+    def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, need_weights=False, att_args=None, pos_bias=None):
+        T, B, C = x.shape
+        rows = Fn.as_compute(x.transpose(0, 1).contiguous()).view(B * T, C)
+        y = self.forward_rows(rows, B, T, self_attn_padding_mask, pos_bias)
+        return y.view(B, T, C).transpose(0, 1), None
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, args, no_encoder_attn=False, add_bias_kv=False, add_zero_attn=False, has_relative_attention_bias=False):
+        super().__init__()
+        self.embed_dim = args.decoder_embed_dim
+        self.num_updates = 0
+        self.dropout = args.dropout
+        self.freeze_decoder_updates = getattr(args, "freeze_decoder_updates", 0)
+        self.self_attn = MultiheadAttention(self.embed_dim, args.decoder_attention_heads, dropout=args.attention_dropout,
+                                            self_attention=True)
+        self.act = _ACTS[str(getattr(args, "activation_fn", None) or "relu")]
+        pa = getattr(args, "activation_dropout", 0) or 0
+        if pa == 0:
+            pa = getattr(args, "relu_dropout", 0) or 0
+        self.activation_dropout = float(pa)
+        self.normalize_before = args.decoder_normalize_before
+        self.self_attn_layer_norm = LayerNorm(self.embed_dim)
+        if no_encoder_attn:
+            self.encoder_attn = None
+            self.encoder_attn_layer_norm = None
+        else:
+            self.encoder_attn = MultiheadAttention(self.embed_dim, args.decoder_attention_heads,
+                                                   kdim=getattr(args, "encoder_embed_dim", None),
+                                                   vdim=getattr(args, "encoder_embed_dim", None),
+                                                   dropout=args.attention_dropout, encoder_decoder_attention=True)
+            self.encoder_attn_layer_norm = LayerNorm(self.embed_dim)
+        self.fc1 = nn.Linear(self.embed_dim, args.decoder_ffn_embed_dim)
+        self.fc2 = nn.Linear(args.decoder_ffn_embed_dim, self.embed_dim)
+        self.final_layer_norm = LayerNorm(self.embed_dim)
+        self.need_attn = True
+        self.has_relative_attention_bias = has_relative_attention_bias
+        if has_relative_attention_bias:
+            self.norm_k = LayerNorm(self.embed_dim // args.decoder_attention_heads)  # unused (:241), kept for checkpoints
+
+    def forward_rows(self, x, B, T, enc_rows, S, enc_padding_mask, self_padding_mask, causal, need_attn):
+        """transformer_layer.py:262-404 without incremental state.  Returns (rows, cross-attn probs [B,H,T,S] or None)."""
+        ft = self.freeze_decoder_updates <= self.num_updates
+        tr = self.training
+        p, pa = (self.dropout if tr else 0.0), (self.activation_dropout if tr else 0.0)
+        nb = self.normalize_before
+        with torch.no_grad() if not ft else contextlib.ExitStack():
+            h = self.self_attn_layer_norm(x) if nb else x
+            x, _ = self.self_attn.forward_rows(h, B, T, key_padding_mask=self_padding_mask, causal=causal, residual=x,
+                                               out_dropout=p)
+            if not nb:
+                x = self.self_attn_layer_norm(x)
+        attn = None
+        if self.encoder_attn is not None and enc_rows is not None:
+            h = self.encoder_attn_layer_norm(x) if nb else x
+            x, attn = self.encoder_attn.forward_rows(h, B, T, kv=enc_rows, S=S, key_padding_mask=enc_padding_mask, residual=x,
+                                                     out_dropout=p, need_weights=need_attn or (not tr and self.need_attn))
+            if not nb:
+                x = self.encoder_attn_layer_norm(x)
+        with torch.no_grad() if not ft else contextlib.ExitStack():
+            h = self.final_layer_norm(x) if nb else x
+            x = Fn.ffn(h, x, self.fc1, self.fc2, self.act, pa, p)
+            if not nb:
+                x = self.final_layer_norm(x)
+        return x, attn
+
+    def forward(self, x, encoder_out=None, encoder_padding_mask=None, incremental_state=None, prev_self_attn_state=None,
+                prev_attn_state=None, self_attn_mask=None, self_attn_padding_mask=None, need_attn=False,
+                need_head_weights=False, pos_bias=None):
+        if need_head_weights:
+            need_attn = True
+        T, B, C = x.shape
+        rows = Fn.as_compute(x.transpose(0, 1).contiguous()).view(B * T, C)
+        enc_rows, S = None, None
+        if encoder_out is not None:
+            S = encoder_out.shape[0]
+            enc_rows = Fn.as_compute(encoder_out.transpose(0, 1).contiguous()).view(B * S, -1)
+        y, attn = self.forward_rows(rows, B, T, enc_rows, S, encoder_padding_mask, self_attn_padding_mask,
+                                    self_attn_mask is not None, need_attn)
+        if attn is not None:
+            attn = attn.transpose(0, 1)  # [H,B,T,S]
+            if not need_head_weights:
+                attn = attn.mean(dim=0)
+        return y.view(B, T, C).transpose(0, 1), attn, None
+
+    def make_generation_fast_(self, need_attn=False, **kwargs):
+        self.need_attn = need_attn
+
+    def set_num_updates(self, num_updates):
+        self.num_updates = num_updates
