@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""SpeechT5-Base pre-training step benchmark on MI355X (BASELINE.json metric: audio-sec/s forward+backward).
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One step = what one optimizer update of the reference recipe does with --update-freq 2 (SURVEY.md 3.1-3.2,
+8d cfg 2): forward+backward of ONE speech micro-batch (8 x 10 s synthetic 16 kHz clips, HuBERT-mask + NCE +
+mel decoder branch) and ONE text micro-batch (16 x 512 tokens, BART infilling), gradient all-reduce over the
+ranks (RCCL, overlapped with backward), global-norm clip and the fused Adam update.  bf16 compute, fp32
+master weights / statistics; dropout active as in t5_transformer_base (0.1, attention 0.1, pre-net 0.5,
+post-net 0.5); LayerDrop is set to 0 so that every step does the full work.  Inputs are resident in HBM.
+
+value = audio seconds of the speech micro-batches processed per wall second by the whole job.
+Extra objects: `roofline` for the dominant kernel (bf16 NT MFMA GEMM; algorithmic FLOPs of its launches /
+their HIP-event time inside the timed region) and `cpu_baseline` (the CPU oracle, fp32, host cores, one
+10 s clip forward+backward)."""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+
+
+def build(device, compute_dtype):
+    from speecht5_amd import functional as Fn
+    from speecht5_amd.criterions import SpeechT5Criterion
+    from speecht5_amd.speecht5 import t5_transformer_base
+    from speecht5_amd.task import SpeechT5Task
+    Fn.set_compute_dtype(compute_dtype)
+    args = Namespace(label_rates=50, sample_rate=16000, speech_odim=80, bert_init=True, use_codebook=True,
+                     share_input_output_embed=True, encoder_layerdrop=0.0, decoder_layerdrop=0.0)
+    t5_transformer_base(args)
+    task = SpeechT5Task.synthetic(args)
+    torch.manual_seed(1337)
+    model = task.build_model(args).to(device)
+    crit = SpeechT5Criterion(task, loss_weights=[10, 0.1], sync_logging=False)
+    return args, task, model, crit
+
+
+def cpu_baseline(model, args, seconds=10.0):
+    """The CPU oracle (oracle/speecht5_oracle.py: fp32 restatement of the reference path) on the host cores:
+    one 10 s clip, speech_pretrain forward + loss + backward, timed once after a short warm-up clip."""
+    from oracle import speecht5_oracle as O
+    from speecht5_amd.synthetic import speech_pretrain_sample
+    from types import SimpleNamespace
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cfg = SimpleNamespace(**vars(args))
+
+    def run(secs):
+        s = speech_pretrain_sample(B=1, seconds=secs, device="cpu", seed=7)
+        T = int(secs * 50) - 1
+        mask = torch.zeros(1, T, dtype=torch.bool)
+        mask[:, : int(0.6 * T)] = True
+        t0 = time.perf_counter()
+        out = O.forward_speech_pretrain(sd, cfg, s, mask_indices=mask, mix_idx=torch.arange(0, T, 2), gumbel_noise=None)
+        loss, ss, _ = O.speech_pretrain_loss(out, s, cfg, loss_weights=(10, 0.1))
+        (loss / ss).backward()
+        return time.perf_counter() - t0
+
+    run(1.0)
+    t = run(seconds)
+    return {"value": round(seconds / t, 4), "unit": "audio-sec/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 x {seconds:g} s clip, speech_pretrain fwd+bwd (fp32 CPU oracle), {t:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=8, help="speech clips (10 s) per GPU per step")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    device = torch.device(f"cuda:{local}")
+
+    from speecht5_amd import functional as Fn, hip
+    from speecht5_amd.ddp import FlatGradDataParallel, FusedAdam
+    from speecht5_amd.synthetic import speech_pretrain_sample, text_pretrain_sample
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    args, task, model, crit = build(device, dtype)
+    ddp = FlatGradDataParallel(model)
+    opt = FusedAdam(ddp, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0)
+    Fn.manual_seed(1337 + rank)
+    import numpy as np
+    np.random.seed(1337 + rank)
+    torch.manual_seed(1337 + rank)
+    vocab = len(task.dicts["text"])
+    speech = speech_pretrain_sample(B=a.batch, seconds=10.0, device=device, seed=1337 + rank)
+    text = text_pretrain_sample(B=16, T=512, vocab=vocab, mask_idx=task.dicts["text"].index("<mask>"), device=device, seed=2337 + rank)
+    micro = [speech, text]
+
+    def step(i):
+        ddp.zero_grad()
+        for s in micro:
+            task.train_step(s, model, crit, None, i, sync=False)
+        ddp.finish()
+        opt.step(grad_scale=1.0 / len(micro))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    hip.profiler.reset()
+    hip.profiler.enabled = True
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    hip.profiler.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    audio_seconds = a.batch * 10.0 * world * a.steps
+    prof = hip.profiler.summary()
+    key = "bf16_NT" if a.dtype == "bf16" else "f32_NT"
+    n, flops, secs = prof.get(key, (0, 0.0, 0.0))
+    peak = BF16_DENSE_PEAK_TFLOPS if a.dtype == "bf16" else 157.3
+    roof = {"bound": "mfma", "kernel": f"gemm_kernel<{a.dtype}, NT> (Linear / conv / QK^T forward form)",
+            "achieved": round(flops / secs / 1e12, 2) if secs > 0 else None, "peak": peak, "unit": "TFLOP/s",
+            "frac": round(flops / secs / 1e12 / peak, 4) if secs > 0 else None, "traffic": None,
+            "launches_per_step": n // max(a.steps, 1), "avg_launch_us": round(secs / max(n, 1) * 1e6, 2),
+            "all_variants": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None,
+                                 "ms_per_step": round(v[2] / a.steps * 1e3, 3)} for k, v in sorted(prof.items())}}
+    if rank == 0:
+        out = {"metric": "audio-sec/s fwd+bwd SpeechT5-Base", "value": round(audio_seconds / dt, 2), "unit": "audio-sec/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": "SpeechT5-Base pretrain step (speech 8x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
+                                      "fwd+bwd+allreduce+clip+Adam, per GPU", "arch": "t5_transformer_base (12 enc + 6 dec, d=768)",
+                          "global_speech_batch": a.batch * world, "clip_seconds": 10, "parallelism": f"dp{world}",
+                          "dropout": 0.1, "layerdrop": 0.0},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,6 +157,12 @@ int st5_cross_entropy(const void* logits, const int32_t* target, float* loss_sum
                       int64_t rows, int32_t V, int64_t ld, float label_smoothing, int32_t ignore_index,
                       float grad_scale, int dtype, void* stream);
 
+/* ---- optimizer (fairseq `adam`: decoupled weight decay; README.md:107-115 flags) ----
+ * One fused pass over the flat fp32 buffers: g' = g * grad_scale * min(1, max_norm / (sqrt(*gnorm_sq) * grad_scale));
+ * m,v update; p = p*(1 - lr*wd) - lr/bc1 * m / (sqrt(v/bc2) + eps).  gnorm_sq is a DEVICE scalar (may be NULL). */
+int st5_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale, void* stream);
+
 const char* st5_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,15 @@
+"""speecht5_amd: the SpeechT5 forward/backward hot path as hand-written gfx950 (MI355X) HIP kernels behind the
+reference's fairseq plug-in surface.  `--user-dir speecht5_amd` registers task `speecht5`, model `t5_transformer`
+(+ archs `t5_transformer_base/_large/_base_asr`) and criterion `speecht5` like SpeechT5/speecht5/__init__.py:1."""
+from . import fairseq_compat  # noqa: F401
+
+
+def _register():
+    from . import criterions, speecht5, task  # noqa: F401
+
+
+try:
+    _register()
+except Exception as e:  # pragma: no cover  (torch missing etc.)
+    import warnings
+    warnings.warn(f"speecht5_amd registration failed: {e}")

@@ -1,0 +1,345 @@
+"""Criterion mirrors of SpeechT5/speecht5/criterions/*.py: same class names, constructor arguments,
+`forward(model, sample) -> (loss, sample_size, logging_output)` contract and loss definitions.
+
+The model forward/backward underneath runs on the HIP kernels.  The scalar loss arithmetic on the model
+outputs (masked L1/MSE/BCE, guided attention, NCE/label-smoothed CE, CTC) is evaluated with fp32 torch
+device ops in this round -- SURVEY.md 8(f) ranks fusing it as the next row after the model path.
+`sync_logging=False` keeps the logged scalars as device tensors (no `.item()` host syncs inside a timed
+step); the default mirrors the reference and returns Python floats."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .fairseq_compat import register_criterion
+from .modules.speech_encoder_prenet import SpeechEncoderPrenet
+
+
+def _item(x, sync):
+    if not torch.is_tensor(x):
+        return x
+    return x.detach().item() if sync else x.detach()
+
+
+def make_non_pad_mask(lengths, maxlen=None, device=None):
+    lengths = torch.as_tensor(lengths, device=device)
+    maxlen = int(lengths.max()) if maxlen is None else maxlen
+    return torch.arange(maxlen, device=lengths.device)[None, :] < lengths[:, None]
+
+
+class Tacotron2Loss(nn.Module):
+    """text_to_speech_loss.py:263-345 (use_masking; weighted masking is unused by the recipes)."""
+
+    def __init__(self, use_masking=True, use_weighted_masking=False, bce_pos_weight=20.0):
+        super().__init__()
+        assert use_masking and not use_weighted_masking
+        self.register_buffer("pos_weight", torch.tensor(bce_pos_weight), persistent=False)
+
+    def forward(self, after_outs, before_outs, logits, ys, labels, olens):
+        masks = make_non_pad_mask(olens, ys.shape[1], ys.device).unsqueeze(-1)
+        ys_m = ys.masked_select(masks)
+        after_m = after_outs.masked_select(masks)
+        before_m = before_outs.masked_select(masks)
+        labels_m = labels.masked_select(masks[:, :, 0])
+        logits_m = logits.masked_select(masks[:, :, 0])
+        l1 = F.l1_loss(after_m, ys_m) + F.l1_loss(before_m, ys_m)
+        mse = F.mse_loss(after_m, ys_m) + F.mse_loss(before_m, ys_m)
+        bce = F.binary_cross_entropy_with_logits(logits_m, labels_m, pos_weight=self.pos_weight.to(ys.device))
+        return l1, mse, bce
+
+
+class GuidedMultiHeadAttentionLoss(nn.Module):
+    """text_to_speech_loss.py:370-427."""
+
+    def __init__(self, sigma=0.4, alpha=1.0, reset_always=True):
+        super().__init__()
+        self.sigma, self.alpha = sigma, alpha
+
+    def forward(self, att_ws, ilens, olens):
+        B, _, To, Ti = att_ws.shape
+        dev = att_ws.device
+        ilens = torch.as_tensor(ilens, device=dev).float()
+        olens = torch.as_tensor(olens, device=dev).float()
+        gx = torch.arange(To, device=dev).float()[None, :, None] / olens[:, None, None]
+        gy = torch.arange(Ti, device=dev).float()[None, None, :] / ilens[:, None, None]
+        w = 1.0 - torch.exp(-((gy - gx) ** 2) / (2 * self.sigma ** 2))
+        mask = (torch.arange(To, device=dev)[None, :, None] < olens[:, None, None]) & \
+               (torch.arange(Ti, device=dev)[None, None, :] < ilens[:, None, None])
+        losses = w.unsqueeze(1) * att_ws
+        return self.alpha * torch.mean(losses.masked_select(mask.unsqueeze(1)))
+
+
+class TexttoSpeechLoss(nn.Module):
+    """text_to_speech_loss.py:53-257."""
+
+    def __init__(self, task, sentence_avg=False, use_masking=True, use_weighted_masking=False, loss_type="L1",
+                 bce_pos_weight=5.0, bce_loss_lambda=1.0, use_guided_attn_loss=False, guided_attn_loss_sigma=0.4,
+                 guided_attn_loss_lambda=1.0, num_layers_applied_guided_attn=2, num_heads_applied_guided_attn=2,
+                 modules_applied_guided_attn=("encoder-decoder",), sync_logging=True):
+        super().__init__()
+        self.task = task
+        self.loss_type = loss_type
+        self.bce_loss_lambda = bce_loss_lambda
+        self.use_guided_attn_loss = use_guided_attn_loss
+        self.criterion = Tacotron2Loss(use_masking, use_weighted_masking, bce_pos_weight)
+        self.num_heads_applied_guided_attn = num_heads_applied_guided_attn
+        self.modules_applied_guided_attn = modules_applied_guided_attn
+        if use_guided_attn_loss:
+            self.attn_criterion = GuidedMultiHeadAttentionLoss(sigma=guided_attn_loss_sigma, alpha=guided_attn_loss_lambda)
+        self.sync_logging = sync_logging
+
+    def forward(self, model, sample):
+        net_output = model(**sample["net_input"])
+        loss, l1, l2, bce, ga = self.compute_loss(model, net_output, sample)
+        s = self.sync_logging
+        log = {"loss": _item(loss, s), "l1_loss": _item(l1, s), "l2_loss": _item(l2, s), "bce_loss": _item(bce, s),
+               "sample_size": 1, "ntokens": sample["ntokens"], "nsentences": sample["target"].size(0)}
+        if ga is not None:
+            log["enc_dec_attn_loss"] = _item(ga, s)
+        return loss, 1, log
+
+    def compute_loss(self, model, net_output, sample):
+        before_outs, after_outs, logits, attn = net_output
+        labels, ys = sample["labels"], sample["dec_target"]
+        olens, ilens = sample["dec_target_lengths"], sample["src_lengths"]
+        r = model.reduction_factor
+        if r > 1:
+            olens_in = torch.div(torch.as_tensor(olens), r, rounding_mode="floor")
+            olens = torch.as_tensor(olens) - torch.as_tensor(olens) % r
+            max_olen = int(olens.max())
+            ys = ys[:, :max_olen]
+            labels = labels[:, :max_olen]
+            labels = torch.scatter(labels, 1, (olens.to(labels.device) - 1).unsqueeze(1), 1.0)
+        else:
+            olens_in = olens
+        l1, l2, bce = self.criterion(after_outs, before_outs, logits, ys, labels, olens)
+        if self.loss_type == "L1":
+            loss = l1 + self.bce_loss_lambda * bce if self.bce_loss_lambda > 0.0 else l1
+        elif self.loss_type == "L2":
+            loss = l2 + self.bce_loss_lambda * bce if self.bce_loss_lambda > 0.0 else l2
+        elif self.loss_type == "L1+L2":
+            loss = l1 + l2 + self.bce_loss_lambda * bce if self.bce_loss_lambda > 0.0 else l1 + l2
+        else:
+            raise ValueError("unknown --loss-type " + self.loss_type)
+        ga = None
+        if self.use_guided_attn_loss:
+            ilens_in = ilens
+            if sample.get("task_name") == "s2s" and isinstance(getattr(model, "speech_encoder_prenet", None), SpeechEncoderPrenet):
+                ilens_in = model.speech_encoder_prenet.get_src_lengths(torch.as_tensor(ilens_in))
+            if "encoder-decoder" in self.modules_applied_guided_attn:
+                att = [a[:, : self.num_heads_applied_guided_attn] for a in attn]
+                ga = self.attn_criterion(torch.cat(att, dim=1), ilens_in, olens_in)
+                loss = loss + ga
+        return loss, l1, l2, bce, ga
+
+
+class SpeechPretrainCriterion(nn.Module):
+    """speech_pretrain_criterion.py:49-198."""
+
+    def __init__(self, task, sentence_avg=False, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_weights=None, log_keys=None,
+                 use_masking=True, use_weighted_masking=False, loss_type="L1", bce_pos_weight=5.0, hubert_weight=1.0,
+                 dec_weight=1.0, sync_logging=True):
+        super().__init__()
+        self.pred_masked_weight = pred_masked_weight
+        self.pred_nomask_weight = pred_nomask_weight
+        self.loss_weights = loss_weights
+        self.log_keys = [] if log_keys is None else log_keys
+        self.hubert_weight = hubert_weight
+        self.dec_weight = dec_weight
+        self.speech_criterion = TexttoSpeechLoss(task, sentence_avg, use_masking, use_weighted_masking, loss_type, bce_pos_weight,
+                                                 sync_logging=sync_logging)
+        self.sync_logging = sync_logging
+
+    def forward(self, model, sample, reduce=True, log_pred=False):
+        s = self.sync_logging
+        if self.dec_weight == 0:
+            sample["net_input"]["only_hubert"] = True
+        net_output, net_output_dec = model(target_list=sample["target_list"], **sample["net_input"])
+        loss, sample_size, log = 0.0, 0, {}
+        reduction = "sum" if reduce else "none"
+        logp_m_list = model.get_logits(net_output, True)
+        targ_m_list = model.get_targets(None, net_output, True)
+        loss_m_list = []
+        for i, (lm, tm) in enumerate(zip(logp_m_list, targ_m_list)):
+            l = F.cross_entropy(lm, tm, reduction=reduction)
+            loss_m_list.append(l)
+            log[f"loss_m_{i}"] = _item(l, s)
+        if self.pred_masked_weight > 0:
+            loss = loss + self.pred_masked_weight * sum(loss_m_list)
+            sample_size += targ_m_list[0].numel()
+        logp_u_list = model.get_logits(net_output, False)
+        targ_u_list = model.get_targets(None, net_output, False)
+        loss_u_list = []
+        for i, (lu, tu) in enumerate(zip(logp_u_list, targ_u_list)):
+            l = F.cross_entropy(lu, tu, reduction=reduction)
+            loss_u_list.append(l)
+            log[f"loss_u_{i}"] = _item(l, s)
+        if self.pred_nomask_weight > 0:
+            loss = loss + self.pred_nomask_weight * sum(loss_u_list)
+            sample_size += targ_u_list[0].numel()
+        if self.loss_weights is not None:
+            extra_losses, names = model.get_extra_losses(net_output)
+            lw = self.loss_weights
+            if len(lw) == 1 and len(extra_losses) != 1:
+                lw = [lw[0]] * len(extra_losses)
+            lw = lw[:len(extra_losses)] if len(lw) > len(extra_losses) else lw
+            for p, n, coef in zip(extra_losses, names, lw):
+                if coef != 0 and p is not None:
+                    p = coef * p.float() * sample_size
+                    loss = loss + p
+                    log[f"loss_{n}"] = _item(p, s)
+        log = {"ntokens": sample_size, "nsentences": sample["id"].numel(), "sample_size": sample_size, "ngpu": 1, **log}
+        if "loss_prob_perplexity" in log:
+            log["code_perplexity"] = _item(net_output["code_perplexity"], s)
+        if self.dec_weight == 0.0:
+            log["loss"] = _item(loss, s)
+            return loss, sample_size, log
+        dec_loss, l1, l2, bce, ga = self.speech_criterion.compute_loss(model, net_output_dec, sample)
+        log.update(dec_loss=_item(dec_loss, s), l1_loss=_item(l1, s), l2_loss=_item(l2, s), bce_loss=_item(bce, s))
+        loss = self.hubert_weight * loss + self.dec_weight * sample_size * dec_loss
+        log["loss"] = _item(loss, s)
+        return loss, sample_size, log
+
+
+class TextPretrainCriterion(nn.Module):
+    """text_pretrain_criterion.py:35-101."""
+
+    def __init__(self, task, sentence_avg=False, bart_weight=1.0, loss_weights=None, sync_logging=True):
+        super().__init__()
+        self.task = task
+        self.padding_idx = task.target_dictionary.pad()
+        self.sentence_avg = sentence_avg
+        self.loss_weights = loss_weights
+        self.bart_weight = bart_weight
+        self.sync_logging = sync_logging
+
+    def forward(self, model, sample, reduce=True):
+        s = self.sync_logging
+        net_output, codebook_out, encoder_output = model(**sample["net_input"])
+        lprobs = model.get_normalized_probs(net_output, log_probs=True)
+        bart_loss = F.nll_loss(lprobs.view(-1, lprobs.size(-1)), sample["target"].view(-1), ignore_index=self.padding_idx,
+                               reduction="sum" if reduce else "none")
+        sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
+        loss = self.bart_weight * bart_loss
+        log = {"loss": _item(loss, s), "ntokens": sample["ntokens"], "nsentences": sample["target"].size(0),
+               "bart_loss": _item(bart_loss, s), "sample_size": sample_size}
+        if "prob_perplexity" in codebook_out:
+            extra_losses, names = model.get_extra_losses(codebook_out)
+            lw = self.loss_weights
+            if len(lw) == 1 and len(extra_losses) != 1:
+                lw = [lw[0]] * len(extra_losses)
+            lw = lw[len(extra_losses):] if len(lw) > len(extra_losses) else lw  # (sic) text_pretrain_criterion.py:73-76
+            for p, n, coef in zip(extra_losses, names, lw):
+                if coef != 0 and p is not None:
+                    p = coef * p.float() * sample_size
+                    loss = loss + p
+                    log[f"loss_{n}"] = _item(p, s)
+        if "loss_prob_perplexity" in log:
+            log["code_perplexity"] = _item(codebook_out["code_perplexity"], s)
+        return loss, sample_size, log
+
+
+def label_smoothed_nll_loss(lprobs, target, epsilon, ignore_index=None, reduce=True):
+    """speech_to_text_loss.py:93-110."""
+    if target.dim() == lprobs.dim() - 1:
+        target = target.unsqueeze(-1)
+    nll_loss = -lprobs.gather(dim=-1, index=target)
+    smooth_loss = -lprobs.sum(dim=-1, keepdim=True)
+    if ignore_index is not None:
+        pad_mask = target.eq(ignore_index)
+        nll_loss = nll_loss.masked_fill(pad_mask, 0.0)
+        smooth_loss = smooth_loss.masked_fill(pad_mask, 0.0)
+    if reduce:
+        nll_loss, smooth_loss = nll_loss.sum(), smooth_loss.sum()
+    eps_i = epsilon / (lprobs.size(-1) - 1)
+    return (1.0 - epsilon - eps_i) * nll_loss + eps_i * smooth_loss, nll_loss
+
+
+class SpeechtoTextLoss(nn.Module):
+    """speech_to_text_loss.py:113-337 (CE + CTC; the WER/KenLM validation extras are not part of the hot path)."""
+
+    def __init__(self, cfg, task, sentence_avg=True, label_smoothing=0.1, ignore_prefix_size=0, report_accuracy=False,
+                 ce_weight=1.0, ctc_weight=0.0, sync_logging=True):
+        super().__init__()
+        self.task = task
+        self.blank_idx = task.target_dictionary.index(getattr(task, "blank_symbol", "<ctc_blank>"))
+        self.pad_idx = task.target_dictionary.pad()
+        self.eos_idx = task.target_dictionary.eos()
+        self.padding_idx = self.pad_idx
+        self.ce_weight, self.ctc_weight = ce_weight, ctc_weight
+        self.sentence_avg = sentence_avg
+        self.eps = label_smoothing
+        self.zero_infinity = getattr(cfg, "zero_infinity", True)
+        self.sync_logging = sync_logging
+
+    def forward(self, model, sample, reduce=True):
+        s = self.sync_logging
+        if self.ce_weight == 0 and self.ctc_weight > 0:
+            sample["only_ctc"] = True
+        net_output_decoder, net_output = model(**sample["net_input"])
+        loss_ce = nll = loss_ctc = None
+        if self.ce_weight > 0:
+            lprobs = model.get_normalized_probs(net_output_decoder, log_probs=True)
+            loss_ce, nll = label_smoothed_nll_loss(lprobs.view(-1, lprobs.size(-1)), sample["target"].view(-1), self.eps,
+                                                   ignore_index=self.padding_idx, reduce=reduce)
+        if self.ctc_weight > 0:
+            loss_ctc = self.compute_loss_ctc(model, net_output, sample)
+        if self.ce_weight > 0 and self.ctc_weight > 0:
+            loss = self.ce_weight * loss_ce + self.ctc_weight * loss_ctc
+        else:
+            loss = loss_ce if self.ce_weight > 0 else loss_ctc
+        ntokens = sample["ntokens"] if "ntokens" in sample else sample["target_lengths"].sum().item()
+        sample_size = sample["target"].size(0) if self.sentence_avg else ntokens
+        log = {"loss": _item(loss, s), "ce_loss": _item(loss_ce, s) if loss_ce is not None else 0,
+               "ctc_loss": _item(loss_ctc, s) if loss_ctc is not None else 0, "nll_loss": _item(nll, s) if nll is not None else 0,
+               "ntokens": ntokens, "nsentences": sample["target"].size(0), "sample_size": sample_size}
+        return loss, sample_size, log
+
+    def compute_loss_ctc(self, model, net_output, sample):
+        lprobs = model.get_normalized_probs_for_ctc(net_output, log_probs=True).contiguous()
+        if net_output["encoder_padding_mask"] is not None:
+            input_lengths = (~net_output["encoder_padding_mask"][0]).long().sum(-1)
+        else:
+            input_lengths = lprobs.new_full((lprobs.size(1),), lprobs.size(0), dtype=torch.long)
+        pad_mask = (sample["target"] != self.pad_idx) & (sample["target"] != self.eos_idx)
+        targets_flat = sample["target"].masked_select(pad_mask)
+        target_lengths = sample["target_lengths"] if "target_lengths" in sample else pad_mask.sum(-1)
+        target_lengths = target_lengths - 1
+        return F.ctc_loss(lprobs, targets_flat, input_lengths, target_lengths, blank=self.blank_idx, reduction="sum",
+                          zero_infinity=self.zero_infinity)
+
+
+@register_criterion("speecht5")
+class SpeechT5Criterion(nn.Module):
+    """speecht5_criterion.py:32-120: dispatches on sample['task_name']."""
+
+    def __init__(self, task, sentence_avg=False, label_smoothing=0.1, ignore_prefix_size=0, report_accuracy=False,
+                 use_masking=True, use_weighted_masking=False, loss_type="L1", bce_pos_weight=5.0, bce_loss_lambda=1.0,
+                 use_guided_attn_loss=False, num_heads_applied_guided_attn=2, ce_weight=1.0, ctc_weight=0.0, hubert_weight=1.0,
+                 dec_weight=1.0, bart_weight=1.0, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_weights=None, cfg=None,
+                 sync_logging=True, guided_attn_loss_lambda=1.0, guided_attn_loss_sigma=0.4):
+        super().__init__()
+        self.speech_criterion = TexttoSpeechLoss(task, sentence_avg, use_masking, use_weighted_masking, loss_type, bce_pos_weight,
+                                                 bce_loss_lambda, use_guided_attn_loss, guided_attn_loss_sigma, guided_attn_loss_lambda,
+                                                 2, num_heads_applied_guided_attn, sync_logging=sync_logging)
+        self.text_criterion = SpeechtoTextLoss(cfg, task, sentence_avg, label_smoothing, ignore_prefix_size, report_accuracy,
+                                               ce_weight, ctc_weight, sync_logging=sync_logging)
+        self.text_pretrain_criterion = TextPretrainCriterion(task, sentence_avg, bart_weight, loss_weights, sync_logging=sync_logging)
+        self.speech_pretrain_criterion = SpeechPretrainCriterion(task, sentence_avg, pred_masked_weight, pred_nomask_weight,
+                                                                 loss_weights, None, use_masking, use_weighted_masking, loss_type,
+                                                                 bce_pos_weight, hubert_weight, dec_weight, sync_logging=sync_logging)
+
+    def forward(self, model, sample, reduce=True):
+        task_name = sample["task_name"]
+        if task_name in ("s2t", "s2c"):
+            return self.text_criterion(model, sample, reduce)
+        if task_name in ("t2s", "s2s"):
+            return self.speech_criterion(model, sample)
+        if task_name == "text_pretrain":
+            return self.text_pretrain_criterion(model, sample, reduce)
+        if task_name == "speech_pretrain":
+            return self.speech_pretrain_criterion(model, sample, reduce)
+        raise ValueError(task_name)
+
+    @staticmethod
+    def logging_outputs_can_be_summed():
+        return False

@@ -1,0 +1,65 @@
+// Fused optimizer step over the flat fp32 parameter / gradient buffers:
+// Adam(beta1, beta2, eps) with decoupled weight decay as fairseq's `adam` (p -= lr*wd*p), global-norm
+// gradient clipping and the 1/(W*U) gradient scale folded into one pass.  The squared gradient norm is
+// read from device memory so that the step needs no host synchronisation.
+// HBM-bound: reads p, g, m, v and writes p, m, v once (28 B per parameter).
+#include "common.h"
+#include "../../include/speecht5_hip.h"
+
+namespace {
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                   float bc2, const float* __restrict__ gnorm_sq, float max_norm,
+                                                   float gscale) {
+  float coef = gscale;
+  if (gnorm_sq && max_norm > 0.f) {
+    const float norm = sqrtf(gnorm_sq[0]) * gscale;
+    const float c = max_norm / (norm + 1e-6f);
+    coef *= c < 1.f ? c : 1.f;
+  }
+  const float step = lr / bc1;
+  const float inv_bc2 = 1.f / sqrtf(bc2);
+  const long long nv = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gg[e] * coef;
+      mm[e] = b1 * mm[e] + (1.f - b1) * ge;
+      vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+      const float denom = sqrtf(vv[e]) * inv_bc2 + eps;
+      pp[e] = pp[e] * (1.f - lr * wd) - step * mm[e] / denom;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  for (long long i = nv * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float ge = g[i] * coef;
+    const float mi = b1 * m[i] + (1.f - b1) * ge;
+    const float vi = b2 * v[i] + (1.f - b2) * ge * ge;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] * (1.f - lr * wd) - step * mi / (sqrtf(vi) * inv_bc2 + eps);
+  }
+}
+}  // namespace
+
+extern "C" int st5_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int32_t step, const float* gnorm_sq,
+                             float max_norm, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || n < 0 || step < 1) return ST5_ERR_ARG;
+  if (n == 0) return ST5_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
+                     lr, beta1, beta2, eps, weight_decay, bc1, bc2, gnorm_sq, max_norm, grad_scale);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}

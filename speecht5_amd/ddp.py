@@ -1,0 +1,164 @@
+"""Data parallelism for the SpeechT5 hot path: one process per GPU, RCCL (torch.distributed `nccl`) over xGMI.
+
+The reference trains with fairseq's legacy_ddp (README.md:86-88): after backward, ONE all-reduce of a flat
+buffer holding every parameter's gradient (zeros for parameters the micro-batch did not touch, which is why
+the recipe needs --find-unused-parameters).  Same semantics here, re-designed for overlap:
+
+* all gradients live in one flat fp32 buffer; `param.grad` are views into it, and the wgrad GEMM epilogues
+  accumulate into those views directly (speecht5_amd/functional.py), so there is no copy-in/copy-out;
+* the buffer is cut into buckets along module boundaries in backward order (post-nets, decoder layers 5..0,
+  encoder layers 11..0, pre-nets).  `functional.layer_boundary()` plants an identity autograd node at each
+  layer input; its backward fires when that layer's gradients are complete and launches the bucket's
+  all-reduce (async, on the process group's RCCL stream) while backward continues on the compute stream;
+* `finish()` launches whatever was not triggered (unused or boundary-less parameters are still reduced: every
+  parameter takes part in every step), waits, and leaves the MEAN over ranks in the buffer.
+
+xGMI note: the 8-GPU node is a full mesh of point-to-point links, so a ring all-reduce is bound
+by one link (~153 GB/s).  Buckets default to 64 MB so that several collectives are in flight during backward.
+"""
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+
+
+class _Trigger(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, owner, bucket_id):
+        ctx.owner, ctx.bucket_id = owner, bucket_id
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.owner._bucket_ready(ctx.bucket_id)
+        return g, None, None
+
+
+class FlatGradDataParallel:
+    def __init__(self, model, process_group=None, bucket_groups=None):
+        """bucket_groups: list of lists of modules, in the order their backward completes; parameters not covered by
+        any group form a final bucket.  Default: derived from a T5TransformerModel (see `default_buckets`)."""
+        self.model = model
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        params, seen = [], set()
+        groups = bucket_groups if bucket_groups is not None else default_buckets(model)
+        self.module_bucket = {}
+        order = []
+        for bi, mods in enumerate(groups):
+            for m in mods:
+                self.module_bucket[id(m)] = bi
+                for p in m.parameters():
+                    if id(p) not in seen and p.requires_grad:
+                        seen.add(id(p))
+                        order.append((bi, p))
+        nb = len(groups)
+        for p in model.parameters():
+            if id(p) not in seen and p.requires_grad:
+                seen.add(id(p))
+                order.append((nb, p))
+        order.sort(key=lambda t: t[0])
+        total = sum(p.numel() for _, p in order)
+        dev = order[0][1].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.buckets = []  # (start, end)
+        off, cur, start = 0, order[0][0], 0
+        for bi, p in order:
+            if bi != cur:
+                self.buckets.append((start, off))
+                start, cur = off, bi
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.buckets.append((start, off))
+        self.params = [p for _, p in order]
+        self._launched = [None] * len(self.buckets)
+        Fn.set_layer_boundary_hook(self._boundary)
+
+    # -- hooks -------------------------------------------------------------------------------------
+    def _boundary(self, x, module):
+        bi = self.module_bucket.get(id(module))
+        if bi is None or self.world == 1 or not x.requires_grad:
+            return x
+        return _Trigger.apply(x, self, bi)
+
+    def _bucket_ready(self, bi):
+        if self._launched[bi] is None and self.world > 1:
+            s, e = self.buckets[bi]
+            self._launched[bi] = dist.all_reduce(self.flat[s:e], group=self.pg, async_op=True)
+
+    # -- step API ----------------------------------------------------------------------------------
+    def zero_grad(self):
+        self.flat.zero_()
+        self._launched = [None] * len(self.buckets)
+
+    def finish(self):
+        """Call after backward: reduce the remaining buckets, wait for all, average over ranks."""
+        if self.world > 1:
+            for bi in range(len(self.buckets)):
+                self._bucket_ready(bi)
+            for w in self._launched:
+                w.wait()
+            self.flat.mul_(1.0 / self.world)
+        self._launched = [None] * len(self.buckets)
+
+
+def default_buckets(model):
+    """Backward-completion order of a T5TransformerModel: post-nets + NCE head + quantizer, decoder layers (last
+    first), decoder pre-nets, encoder layers (last first), encoder pre-nets.  The remaining parameters (layer-less
+    encoder/decoder members, tied embeddings, ...) fall into a final bucket reduced by finish()."""
+    groups = []
+    head = [m for m in (getattr(model, n, None) for n in ("speech_decoder_postnet", "text_decoder_postnet", "hubert_layer",
+                                                            "quantizer")) if m is not None]
+    if head:
+        groups.append(head)
+    dec = getattr(model, "decoder", None)
+    if dec is not None and hasattr(dec, "layers"):
+        groups += [[l] for l in reversed(list(dec.layers))]
+    pre = [m for m in (getattr(model, n, None) for n in ("speech_decoder_prenet", "text_decoder_prenet")) if m is not None]
+    if pre:
+        groups.append(pre)
+    enc = getattr(model, "encoder", None)
+    if enc is not None and hasattr(enc, "layers"):
+        groups += [[l] for l in reversed(list(enc.layers))]
+    return groups
+
+
+class FusedAdam:
+    """fairseq `adam` (decoupled weight decay) + global-norm clipping on the flat buffers, one HIP kernel per step.
+    Parameters are re-pointed at views of one flat fp32 buffer so that the update is a single launch."""
+
+    def __init__(self, ddp: FlatGradDataParallel, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0):
+        self.ddp = ddp
+        self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip_norm
+        total = ddp.flat.numel()
+        dev = ddp.flat.device
+        self.pflat = torch.empty(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in ddp.params:
+            n = p.numel()
+            self.pflat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.pflat[off:off + n].view_as(p)
+            off += n
+        self.m = torch.zeros_like(self.pflat)
+        self.v = torch.zeros_like(self.pflat)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.t = 0
+
+    def backward(self, loss):
+        loss.backward()
+
+    def step(self, grad_scale=1.0):
+        from . import hip
+        self.t += 1
+        L = hip.lib()
+        g = self.ddp.flat
+        if self.clip > 0:
+            hip.check(L.st5_sumsq(g.data_ptr(), self.gnorm_sq.data_ptr(), g.numel(), 1.0, 0, hip.F32, hip.stream()), "st5_sumsq")
+        hip.check(L.st5_adam_step(self.pflat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), g.numel(), self.lr,
+                                  self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                  self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale, hip.stream()),
+                  "st5_adam_step")
+        # parameters changed in place through the flat view: invalidate the compute-dtype weight cache
+        for p in self.ddp.params:
+            p.data = p.data  # noqa  (keeps views)
+        Fn.weight_cache.clear()

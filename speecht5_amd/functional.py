@@ -17,7 +17,7 @@ import torch
 from . import hip
 from .hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH  # noqa: F401
 
-_S = SimpleNamespace(dtype=torch.float32, seed=0x5EED, counter=0, grad_hook=None)
+_S = SimpleNamespace(dtype=torch.float32, seed=0x5EED, counter=0, grad_hook=None, boundary_hook=None)
 
 
 def set_compute_dtype(dtype):
@@ -44,6 +44,15 @@ def set_grad_ready_hook(fn):
     """fn(param) is called when a parameter's .grad has received its last contribution of this backward
     from this library (used to launch bucketed all-reduces while backward is still running)."""
     _S.grad_hook = fn
+
+
+def set_layer_boundary_hook(fn):
+    """fn(x, module) -> x, called by the layer mirrors at their input (see speecht5_amd/ddp.py)."""
+    _S.boundary_hook = fn
+
+
+def layer_boundary(x, module):
+    return x if _S.boundary_hook is None else _S.boundary_hook(x, module)
 
 
 def _ceil8(n):

@@ -75,6 +75,8 @@ _SIGS = {
     "st5_pad_time": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "st5_cross_entropy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,
                                   c_float, c_int32, c_float, c_int, c_void_p]),
+    "st5_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                              c_int32, c_void_p, c_float, c_float, c_void_p]),
     "st5_version": (c_char_p, []),
 }
 
@@ -137,6 +139,29 @@ def operand(t, ld, off=0, rpb=0, bstride=0, seg=0, seg_stride=0, zs0=0, zs1=0):
 _NULL_OP = Operand()
 
 
+class GemmProfiler:
+    """Optional per-launch HIP-event timing of st5_gemm (bench.py's roofline leg).  Events are recorded on the
+    stream the kernel is launched on, around every launch, while the timed region runs."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []  # (variant, flops, start_event, end_event)
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        """{variant: (launches, total_flops, total_seconds)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for variant, flops, e0, e1 in self.records:
+            n, f, t = out.get(variant, (0, 0.0, 0.0))
+            out[variant] = (n + 1, f + flops, t + e0.elapsed_time(e1) * 1e-3)
+        return out
+
+
+profiler = GemmProfiler()
+
+
 def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_zs=0, batch=1, zdiv=1, act=ACT_NONE,
          flags=0, alpha=1.0, beta=0.0, dropout_p=0.0, seed=0):
     p = GemmParams()
@@ -149,6 +174,14 @@ def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_
     p.M, p.N, p.K, p.batch, p.zdiv = M, N, K, batch, zdiv
     p.act, p.flags = act, flags
     p.alpha, p.beta, p.dropout_p, p.seed = alpha, beta, dropout_p, seed
+    if profiler.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().st5_gemm(byref(p), dtype, stream()), "st5_gemm")
+        e1.record()
+        variant = ("bf16" if dtype == BF16 else "f32") + "_" + ("T" if flags & A_KSTRIDED else "N") + ("N" if flags & B_KSTRIDED else "T")
+        profiler.records.append((variant, 2.0 * M * N * K * batch, e0, e1))
+        return
     check(lib().st5_gemm(byref(p), dtype, stream()), "st5_gemm")
 
 

@@ -34,6 +34,7 @@ class TransformerSentenceEncoderLayer(nn.Module):
         """x rows [B*T, C] -> rows.  Post-LN (:112-132) or pre-LN (:90-111)."""
         tr = self.training
         p, pa = (self.dropout if tr else 0.0), (self.activation_dropout if tr else 0.0)
+        x = Fn.layer_boundary(x, self)
         if self.layer_norm_first:
             h = self.self_attn_layer_norm(x)
             pb = pos_bias
@@ -96,6 +97,7 @@ class TransformerDecoderLayer(nn.Module):
         tr = self.training
         p, pa = (self.dropout if tr else 0.0), (self.activation_dropout if tr else 0.0)
         nb = self.normalize_before
+        x = Fn.layer_boundary(x, self)
         with torch.no_grad() if not ft else contextlib.ExitStack():
             h = self.self_attn_layer_norm(x) if nb else x
             x, _ = self.self_attn.forward_rows(h, B, T, key_padding_mask=self_padding_mask, causal=causal, residual=x,
