@@ -207,7 +207,7 @@ __device__ __forceinline__ void store_vec(U* p, bool full, int ne, const float (
 struct EpiArgs {  // everything the epilogue needs, by value
   void* C; const void* R; const void* P; void* Cpre; const float* bias;
   long long c_ld, c_bs, r_ld, r_bs, p_ld, p_bs, q_ld, q_bs;
-  int rpb, M, N, act, out_f32, dact, c_vec_ok;
+  int rpb, M, N, act, out_f32, dact, c_vec_ok, atomic;
   float alpha, beta, dropout_p;
   unsigned long long seed, ctr_base;
 };
@@ -324,8 +324,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const st5_gemm_params p,
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
-  const int nk = (p.K + BK - 1) / BK;
-  la.load(0); lb.load(0);
+  // split-K: blockIdx.y owns k-tiles [kt0, kt0 + nk)
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int per = (nk_all + gridDim.y - 1) / gridDim.y;
+  const int kt0 = blockIdx.y * per;
+  const int nk = (nk_all - kt0) < per ? (nk_all - kt0) : per;
+  if (nk <= 0) return;
+  la.load(kt0 * BK); lb.load(kt0 * BK);
   la.store(smem); lb.store(smem + TILE_BYTES);
   __syncthreads();
 
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const st5_gemm_params p,
   for (int kt = 0; kt < nk; ++kt) {
     const char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
     char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-    if (kt + 1 < nk) { la.load((kt + 1) * BK); lb.load((kt + 1) * BK); }
+    if (kt + 1 < nk) { la.load((kt0 + kt + 1) * BK); lb.load((kt0 + kt + 1) * BK); }
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       const frag_t a0 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0, kg * 2 + fhalf));
@@ -355,6 +360,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const st5_gemm_params p,
   ea.p_ld = p.P.ld; ea.p_bs = p.P.bstride; ea.q_ld = p.Cpre.ld; ea.q_bs = p.Cpre.bstride;
   ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
   ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
+  ea.atomic = 0;
+  if (gridDim.y > 1) {  // split-K: each split writes its own fp32 slab (p.C describes slab 0, slabs are M*N apart)
+    ea.C = reinterpret_cast<float*>(ea.C) + (long long)blockIdx.y * p.M * p.N;
+  }
   ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
   ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
   // fold the batch offsets into the base pointers
@@ -379,10 +388,49 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const st5_gemm_params p,
   }
 }
 
+// C[m, n] = beta * C[m, n] + sum_s slab[s][m][n]   (slabs dense [M, N] fp32; C fp32 with row mapping)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C,
+                                                            int nsplit, int M, int N, long long ldc, int rpb,
+                                                            long long bstride, float beta) {
+  const long long nv = (long long)M * N / 4;  // N % 4 == 0 guaranteed by the host
+  const long long slab = (long long)M * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    const long long e0 = i * 4;
+    const int m = (int)(e0 / N), n = (int)(e0 % N);
+    f32x4 acc = *reinterpret_cast<const f32x4*>(slabs + e0);
+    for (int s2 = 1; s2 < nsplit; ++s2) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + s2 * slab + e0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    const long long co = (rpb ? (long long)(m / rpb) * bstride + (long long)(m % rpb) * ldc : (long long)m * ldc) + n;
+    f32x4* dst = reinterpret_cast<f32x4*>(C + co);
+    if (beta != 0.f) {
+      const f32x4 o = *dst;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += beta * o[e];
+    }
+    *dst = acc;
+  }
+}
+
+float* g_slab = nullptr;
+size_t g_slab_bytes = 0;
+float* slab_workspace(size_t bytes) {
+  if (bytes > g_slab_bytes) {
+    if (g_slab) (void)hipFree(g_slab);  // synchronises with in-flight users
+    g_slab = nullptr;
+    const size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
+    if (hipMalloc(&g_slab, want) != hipSuccess) { g_slab_bytes = 0; return nullptr; }
+    g_slab_bytes = want;
+  }
+  return g_slab;
+}
+
 template <typename T>
-int launch(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
+int launch(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  dim3 grid(tiles, 1, p.batch), block(NTHREADS);
+  dim3 grid(tiles, nsplit, p.batch), block(NTHREADS);
   const bool aks = p.flags & ST5_GEMM_A_KSTRIDED, bks = p.flags & ST5_GEMM_B_KSTRIDED;
   if (!aks && !bks) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, p, c_vec_ok);
   else if (!aks && bks) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, p, c_vec_ok);
@@ -423,6 +471,39 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   };
   const int c_vec_ok = c_ok(p.C) && c_ok(p.R) && c_ok(p.P) && c_ok(p.Cpre);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, s);
-  return launch<float>(p, c_vec_ok, s);
+  // split-K for fp32 outputs (weight gradients: small M x N, very long K): raise the block count towards ~1.5 per
+  // CU; every split writes its own dense fp32 slab (plain 16-byte stores), a second kernel sums the slabs into C.
+  // (fp32 atomics into C were measured 1.6x slower than no split at all: device-scope atomics bypass the XCD L2.)
+  int nsplit = 1;
+  const bool plain = !p.bias && !p.R.ptr && !p.P.ptr && !p.Cpre.ptr && p.act == ST5_ACT_NONE && p.dropout_p == 0.f;
+  if ((p.flags & ST5_GEMM_OUT_F32) && plain && p.batch == 1 && p.N % 8 == 0 && p.C.ld % 4 == 0) {
+    const long long tiles = (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int bk = 128 / es;
+    const int nk = (p.K + bk - 1) / bk;
+    if (tiles < 200 && nk >= 16) {
+      long long want = (384 + tiles - 1) / tiles;
+      long long maxs = nk / 8;  // at least 8 k-tiles per split
+      nsplit = (int)(want < maxs ? want : maxs);
+      if (nsplit < 1) nsplit = 1;
+      const int per = (nk + nsplit - 1) / nsplit;
+      nsplit = (nk + per - 1) / per;
+    }
+  }
+  if (nsplit > 1) {
+    float* slabs = slab_workspace((size_t)nsplit * p.M * p.N * sizeof(float));
+    if (!slabs) return ST5_ERR_LAUNCH;
+    st5_gemm_params q = p;
+    q.C.ptr = slabs; q.C.ld = p.N; q.C.rpb = 0; q.C.bstride = 0; q.C.zs0 = q.C.zs1 = 0; q.beta = 0.f;
+    const int rc = dtype == ST5_BF16 ? launch<bf16_t>(q, 1, nsplit, s) : launch<float>(q, 1, nsplit, s);
+    if (rc) return rc;
+    long long blocks = ((long long)p.M * p.N / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs,
+                       reinterpret_cast<float*>(const_cast<void*>(p.C.ptr)), nsplit, p.M, p.N, (long long)p.C.ld, p.C.rpb,
+                       (long long)p.C.bstride, p.beta);
+    HIP_CHECK_LAUNCH();
+    return ST5_OK;
+  }
+  if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, nsplit, s);
+  return launch<float>(p, c_vec_ok, nsplit, s);
 }

@@ -9,12 +9,12 @@
 
 namespace {
 
-constexpr int MAXCH = 8;  // 8 chunks x 512 columns per wave pass => cols <= 4096 held in registers
+constexpr int MAXCH = 8;  // up to 8 chunks x 512 columns per wave pass => cols <= 4096 held in registers
 
-template <typename T>
-__device__ __forceinline__ void load_row(const T* row, int cols, int lane, bool vec, float (&v)[MAXCH][8]) {
+template <typename T, int NCH>
+__device__ __forceinline__ void load_row(const T* row, int cols, int lane, bool vec, float (&v)[NCH][8]) {
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = i * 512 + lane * 8;
     if (c < cols) {
       if (vec) load8f<T>(row + c, v[i]);
@@ -28,10 +28,10 @@ __device__ __forceinline__ void load_row(const T* row, int cols, int lane, bool 
     }
   }
 }
-template <typename T>
-__device__ __forceinline__ void store_row(T* row, int cols, int lane, bool vec, const float (&v)[MAXCH][8]) {
+template <typename T, int NCH>
+__device__ __forceinline__ void store_row(T* row, int cols, int lane, bool vec, const float (&v)[NCH][8]) {
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = i * 512 + lane * 8;
     if (c < cols) {
       if (vec) store8f<T>(row + c, v[i]);
@@ -43,7 +43,7 @@ __device__ __forceinline__ void store_row(T* row, int cols, int lane, bool vec, 
   }
 }
 
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
@@ -52,17 +52,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const bool vec = (cols % 8) == 0;
-  float v[MAXCH][8];
-  load_row<T>(x + row * cols, cols, lane, vec, v);
+  float v[NCH][8];
+  load_row<T, NCH>(x + row * cols, cols, lane, vec, v);
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i)
+  for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) s += v[i][e];
   const float mu = wave_sum(s) / (float)cols;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i)
+  for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = i * 512 + lane * 8 + e;
@@ -71,17 +71,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
   const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i)
+  for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = i * 512 + lane * 8 + e;
       if (c < cols) v[i][e] = (v[i][e] - mu) * rs * gamma[c] + beta[c];
     }
-  store_row<T>(y + row * cols, cols, lane, vec, v);
+  store_row<T, NCH>(y + row * cols, cols, lane, vec, v);
   if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
 }
 
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ mean,
@@ -91,13 +91,13 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const bool vec = (cols % 8) == 0;
-  float xv[MAXCH][8], gv[MAXCH][8];
-  load_row<T>(x + row * cols, cols, lane, vec, xv);
-  load_row<T>(dy + row * cols, cols, lane, vec, gv);
+  float xv[NCH][8], gv[NCH][8];
+  load_row<T, NCH>(x + row * cols, cols, lane, vec, xv);
+  load_row<T, NCH>(dy + row * cols, cols, lane, vec, gv);
   const float mu = mean[row], rs = rstd[row];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i)
+  for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = i * 512 + lane * 8 + e;
@@ -111,10 +111,10 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
   s1 = wave_sum(s1) / (float)cols;
   s2 = wave_sum(s2) / (float)cols;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i)
+  for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) gv[i][e] = rs * (gv[i][e] - s1 - xv[i][e] * s2);
-  store_row<T>(dx + row * cols, cols, lane, vec, gv);
+  store_row<T, NCH>(dx + row * cols, cols, lane, vec, gv);
 }
 
 // ---- column reductions: out[c] (+)= scale * sum_r f(r, c) --------------------------------------
@@ -166,6 +166,53 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
     part[(long long)blockIdx.y * cols + blockIdx.x * 256 + c] = s;
   }
 }
+// single-launch variant: block partials go straight into out[] with fp32 atomics (cols x nsplit atomics in total)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colreduce_atomic_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ out,
+                                                               long long rows, int cols, long long ld, float scale) {
+  __shared__ float red[8][256 + 8];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + tx * 8;
+  const bool vec = (ld % 8) == 0 && c0 + 8 <= cols;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (c0 < cols) {
+    for (long long r = (long long)blockIdx.y * 8 + ty; r < rows; r += (long long)gridDim.y * 8) {
+      float a[8], b[8];
+      if (vec) load8f<T>(x + r * ld + c0, a);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (c0 + e < cols) ? Elem<T>::to_f(x[r * ld + c0 + e]) : 0.f;
+      }
+      if (MODE == 1) {
+        if (vec) load8f<T>(dy + r * ld + c0, b);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) b[e] = (c0 + e < cols) ? Elem<T>::to_f(dy[r * ld + c0 + e]) : 0.f;
+        }
+        const float mu = mean[r], rs = rstd[r];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += b[e] * (a[e] - mu) * rs;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += a[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = acc[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (blockIdx.x * 256 + c < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += red[j][c];
+    unsafeAtomicAdd(out + blockIdx.x * 256 + c, s * scale);
+  }
+}
 __global__ void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nsplit, int cols,
                                        float scale, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,10 +235,15 @@ int colreduce(const void* x, const void* dy, const float* mean, const float* rst
               long long rows, int cols, long long ld, float scale, int accumulate, hipStream_t s) {
   const int ns = nsplit_for(rows);
   dim3 grid((cols + 255) / 256, ns);
-  hipLaunchKernelGGL((colreduce_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, mean, rstd, ws,
-                     rows, cols, ld);
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, ws, out, ns, cols, scale,
-                     accumulate);
+  if (accumulate) {  // += : one launch, block partials combined with fp32 atomics
+    hipLaunchKernelGGL((colreduce_atomic_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, mean, rstd,
+                       out, rows, cols, ld, scale);
+  } else {
+    hipLaunchKernelGGL((colreduce_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, mean, rstd, ws,
+                       rows, cols, ld);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, ws, out, ns, cols, scale,
+                       accumulate);
+  }
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -204,13 +256,17 @@ extern "C" int st5_layernorm_fwd(const void* x, const float* gamma, const float*
   if (rows == 0) return ST5_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((rows + 3) / 4));
-  if (dtype == ST5_BF16)
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean,
-                       rstd, (long long)rows, cols, eps);
-  else if (dtype == ST5_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean,
-                       rstd, (long long)rows, cols, eps);
-  else return ST5_ERR_ARG;
+  if (dtype != ST5_BF16 && dtype != ST5_F32) return ST5_ERR_ARG;
+#define LNF(TT, NCH)                                                                                              \
+  hipLaunchKernelGGL((ln_fwd_kernel<TT, NCH>), grid, dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, \
+                     (long long)rows, cols, eps)
+#define LNF_T(TT)                                                                                \
+  do {                                                                                           \
+    if (cols <= 512) LNF(TT, 1); else if (cols <= 1024) LNF(TT, 2); else if (cols <= 2048) LNF(TT, 4); else LNF(TT, 8); \
+  } while (0)
+  if (dtype == ST5_BF16) LNF_T(bf16_t); else LNF_T(float);
+#undef LNF_T
+#undef LNF
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -238,12 +294,16 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
   if (rc) return rc;
   if (dx) {
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (dtype == ST5_BF16)
-      hipLaunchKernelGGL(ln_bwd_dx_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma,
-                         mean, rstd, (bf16_t*)dx, (long long)rows, cols);
-    else
-      hipLaunchKernelGGL(ln_bwd_dx_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma,
-                         mean, rstd, (float*)dx, (long long)rows, cols);
+#define LNB(TT, NCH)                                                                                         \
+  hipLaunchKernelGGL((ln_bwd_dx_kernel<TT, NCH>), grid, dim3(256), 0, s, (const TT*)dy, (const TT*)x, gamma, mean, \
+                     rstd, (TT*)dx, (long long)rows, cols)
+#define LNB_T(TT)                                                                                \
+  do {                                                                                           \
+    if (cols <= 512) LNB(TT, 1); else if (cols <= 1024) LNB(TT, 2); else if (cols <= 2048) LNB(TT, 4); else LNB(TT, 8); \
+  } while (0)
+    if (dtype == ST5_BF16) LNB_T(bf16_t); else LNB_T(float);
+#undef LNB_T
+#undef LNB
     HIP_CHECK_LAUNCH();
   }
   return ST5_OK;

@@ -18,7 +18,7 @@ __device__ __forceinline__ int bucket(int i, int j, int maxrel) {
   return d + maxrel;
 }
 
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ scores, const T* __restrict__ qp,
                                                           const uint8_t* __restrict__ kpm, T* __restrict__ probs,
                                                           T* __restrict__ probs_drop, int BH, int H, int Tq, int S,
@@ -34,10 +34,10 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
   const uint8_t* mrow = kpm ? kpm + (long long)b * S : nullptr;
   // causal offset: query i may attend keys j <= i + (S - Tq) (incremental decoding has S >= Tq)
   const int jmax = causal ? i + (S - Tq) : S - 1;
-  float v[MAXCH][8];
+  float v[NCH][8];
   float mx = -INFINITY;
 #pragma unroll
-  for (int c = 0; c < MAXCH; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     const int j0 = c * 512 + lane * 8;
     if (j0 < lds) {
       load8f<T>(srow + j0, v[c]);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
   mx = wave_max(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int c = 0; c < MAXCH; ++c)
+  for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float p = (mx == -INFINITY) ? 0.f : __expf(v[c][e] - mx);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
   const unsigned int thresh = dropout_p > 0.f ? (unsigned int)((double)dropout_p * 4294967296.0) : 0u;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
 #pragma unroll
-  for (int c = 0; c < MAXCH; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     const int j0 = c * 512 + lane * 8;
     if (j0 < lds) {
 #pragma unroll
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
   }
 }
 
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(T* __restrict__ dP, const T* __restrict__ probs,
                                                           const float* __restrict__ dP_extra, T* __restrict__ dqp,
                                                           int BH, int Tq, int S, int lds, int nb, int maxrel,
@@ -105,10 +105,10 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(T* __restrict__ dP, co
     const int i = (int)(rowid % Tq);
     const unsigned int thresh = dropout_p > 0.f ? (unsigned int)((double)dropout_p * 4294967296.0) : 0u;
     const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
-    float g[MAXCH][8], p[MAXCH][8];
+    float g[NCH][8], p[NCH][8];
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int j0 = c * 512 + lane * 8;
       if (j0 < lds) {
         load8f<T>(dP + rowid * lds + j0, g[c]);
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(T* __restrict__ dP, co
     }
     dot = wave_sum(dot);
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int j0 = c * 512 + lane * 8;
       if (j0 < lds) {
 #pragma unroll
@@ -160,15 +160,17 @@ extern "C" int st5_softmax_fwd(const void* scores, const void* qp, const uint8_t
   hipStream_t s = (hipStream_t)stream;
   const long long rows = (long long)BH * T;
   dim3 grid((unsigned)((rows + 3) / 4));
-  if (dtype == ST5_BF16)
-    hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)scores, (const bf16_t*)qp, kpm,
-                       (bf16_t*)probs, (bf16_t*)probs_drop, BH, H, T, S, lds, nb, maxrel, causal, dropout_p,
-                       (unsigned long long)seed);
-  else if (dtype == ST5_F32)
-    hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)scores, (const float*)qp, kpm,
-                       (float*)probs, (float*)probs_drop, BH, H, T, S, lds, nb, maxrel, causal, dropout_p,
-                       (unsigned long long)seed);
-  else return ST5_ERR_ARG;
+  if (dtype != ST5_BF16 && dtype != ST5_F32) return ST5_ERR_ARG;
+#define SMF(TT, NCH)                                                                                                  \
+  hipLaunchKernelGGL((softmax_fwd_kernel<TT, NCH>), grid, dim3(256), 0, s, (const TT*)scores, (const TT*)qp, kpm,     \
+                     (TT*)probs, (TT*)probs_drop, BH, H, T, S, lds, nb, maxrel, causal, dropout_p, (unsigned long long)seed)
+#define SMF_T(TT)                                                                                                     \
+  do {                                                                                                                \
+    if (lds <= 512) SMF(TT, 1); else if (lds <= 1024) SMF(TT, 2); else if (lds <= 2048) SMF(TT, 4); else SMF(TT, 8);  \
+  } while (0)
+  if (dtype == ST5_BF16) SMF_T(bf16_t); else SMF_T(float);
+#undef SMF_T
+#undef SMF
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -182,13 +184,17 @@ extern "C" int st5_softmax_bwd(void* dP_inout, const void* probs, const float* d
   const long long rows = (long long)BH * T;
   dim3 grid((unsigned)((rows + 3) / 4));
   const size_t shm = dqp ? (size_t)4 * nb * sizeof(float) : 16;
-  if (dtype == ST5_BF16)
-    hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, dim3(256), shm, s, (bf16_t*)dP_inout, (const bf16_t*)probs,
-                       dP_extra, (bf16_t*)dqp, BH, T, S, lds, nb, maxrel, dropout_p, (unsigned long long)seed);
-  else if (dtype == ST5_F32)
-    hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, dim3(256), shm, s, (float*)dP_inout, (const float*)probs,
-                       dP_extra, (float*)dqp, BH, T, S, lds, nb, maxrel, dropout_p, (unsigned long long)seed);
-  else return ST5_ERR_ARG;
+  if (dtype != ST5_BF16 && dtype != ST5_F32) return ST5_ERR_ARG;
+#define SMB(TT, NCH)                                                                                               \
+  hipLaunchKernelGGL((softmax_bwd_kernel<TT, NCH>), grid, dim3(256), shm, s, (TT*)dP_inout, (const TT*)probs, dP_extra, \
+                     (TT*)dqp, BH, T, S, lds, nb, maxrel, dropout_p, (unsigned long long)seed)
+#define SMB_T(TT)                                                                                                  \
+  do {                                                                                                             \
+    if (lds <= 512) SMB(TT, 1); else if (lds <= 1024) SMB(TT, 2); else if (lds <= 2048) SMB(TT, 4); else SMB(TT, 8); \
+  } while (0)
+  if (dtype == ST5_BF16) SMB_T(bf16_t); else SMB_T(float);
+#undef SMB_T
+#undef SMB
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

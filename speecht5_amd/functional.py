@@ -514,16 +514,17 @@ def _attn_bwd(dctx, q, k, v, dq, dk, dv, probs, pdrop, dP_extra, B, H, T, S, hd,
              hip.operand(dkt, dkld, off=dkoff, zs0=S * dkld, zs1=hd), S, hd, T, _dt(dtype), batch=BH, zdiv=H,
              flags=hip.A_KSTRIDED | hip.B_KSTRIDED, alpha=alpha)
     if pe is not None and want_dpe:
-        # dPE[h] = alpha * sum_b dQP[b,h]^T . Q[b,h]; then reduce over heads (fp32)
-        part = torch.empty(H, nb, hd, dtype=torch.float32, device=dev)
-        hip.gemm(hip.operand(dqp, nb, rpb=T, bstride=H * T * nb, zs0=T * nb),
-                 hip.operand(qt, qld, off=qoff, rpb=T, bstride=T * qld, zs0=hd),
-                 hip.operand(part, hd, zs0=nb * hd), nb, hd, B * T, _dt(dtype), batch=H, zdiv=1,
+        # dPE = alpha * sum_{b,h} dQP[b,h]^T . Q[b,h]: one [nb x hd] product per (b,h) (K = T), then a column
+        # reduction over the B*H partials (fp32)
+        part = torch.empty(BH, nb, hd, dtype=torch.float32, device=dev)
+        hip.gemm(hip.operand(dqp, nb, zs0=H * T * nb, zs1=T * nb),
+                 hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd),
+                 hip.operand(part, hd, zs0=H * nb * hd, zs1=nb * hd), nb, hd, T, _dt(dtype), batch=BH, zdiv=H,
                  flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, alpha=alpha)
-        g = torch.empty(nb, hd, dtype=torch.float32, device=dev)
+        g = torch.zeros(nb, hd, dtype=torch.float32, device=dev)
         L = hip.lib()
-        ws = hip.workspace(L.st5_colsum_ws_bytes(H, nb * hd), dev)
-        hip.check(L.st5_colsum_ws(part.data_ptr(), g.data_ptr(), ws.data_ptr(), H, nb * hd, nb * hd, 1.0, 0, hip.F32,
+        ws = hip.workspace(L.st5_colsum_ws_bytes(BH, nb * hd), dev)
+        hip.check(L.st5_colsum_ws(part.data_ptr(), g.data_ptr(), ws.data_ptr(), BH, nb * hd, nb * hd, 1.0, 1, hip.F32,
                                   hip.stream()), "st5_colsum_ws")
         return g
     return None

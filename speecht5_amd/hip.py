@@ -153,9 +153,18 @@ class GemmProfiler:
     def summary(self):
         """{variant: (launches, total_flops, total_seconds)} -- call after torch.cuda.synchronize()."""
         out = {}
-        for variant, flops, e0, e1 in self.records:
+        for variant, flops, e0, e1, _shape in self.records:
             n, f, t = out.get(variant, (0, 0.0, 0.0))
             out[variant] = (n + 1, f + flops, t + e0.elapsed_time(e1) * 1e-3)
+        return out
+
+
+    def by_shape(self):
+        out = {}
+        for variant, flops, e0, e1, shape in self.records:
+            k = (variant,) + shape
+            n, f, t = out.get(k, (0, 0.0, 0.0))
+            out[k] = (n + 1, f + flops, t + e0.elapsed_time(e1) * 1e-3)
         return out
 
 
@@ -180,7 +189,7 @@ def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_
         check(lib().st5_gemm(byref(p), dtype, stream()), "st5_gemm")
         e1.record()
         variant = ("bf16" if dtype == BF16 else "f32") + "_" + ("T" if flags & A_KSTRIDED else "N") + ("N" if flags & B_KSTRIDED else "T")
-        profiler.records.append((variant, 2.0 * M * N * K * batch, e0, e1))
+        profiler.records.append((variant, 2.0 * M * N * K * batch, e0, e1, (M, N, K, batch)))
         return
     check(lib().st5_gemm(byref(p), dtype, stream()), "st5_gemm")
 
