@@ -25,6 +25,8 @@ extern "C" {
 #define ST5_ACT_GELU 1
 #define ST5_ACT_RELU 2
 #define ST5_ACT_TANH 3
+#define ST5_ACT_LRELU_01 4  /* LeakyReLU(0.1), HiFi-GAN */
+#define ST5_ACT_LRELU_001 5 /* LeakyReLU(0.01) */
 
 /* gemm flags */
 #define ST5_GEMM_A_KSTRIDED 1  /* A(i,k) stored k-outer (i contiguous): "transposed" operand      */
@@ -128,6 +130,9 @@ int st5_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, vo
 /* y = act(x) ; dx = dy * act'(x) */
 int st5_act_fwd(const void* x, void* y, int64_t n, int32_t act, int dtype, void* stream);
 int st5_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int32_t act, int dtype, void* stream);
+/* y[r,c] = act(x[r,c] * a[c] + b[c])   (per-channel affine: spectrogram normalisation, BatchNorm apply) */
+int st5_channel_affine(const void* x, const float* a, const float* b, void* y, int64_t rows, int32_t cols, int32_t act,
+                       int dtype, void* stream);
 /* y = dropout(x) with the library's counter RNG (same generator as the GEMM epilogue) */
 int st5_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
 /* x[r,:] = v (fp32 [cols]) where mask[r] != 0  (apply_hubert_mask, speech_encoder_prenet.py:249) */

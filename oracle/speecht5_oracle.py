@@ -647,3 +647,33 @@ def base_config(**over):
     )
     c.update(over)
     return SimpleNamespace(**c)
+
+
+# --------------------------------------------------------------------------------------------
+# HiFi-GAN generator (not in the reference tree; spec = HF SpeechT5HifiGan.forward,
+# transformers/models/speecht5/modeling_speecht5.py:3029-3066).  Pinned by tests/golden/tiny_hifigan.pt.
+# --------------------------------------------------------------------------------------------
+def hifigan(sd, cfg, spectrogram):
+    """cfg: dict with upsample_rates, upsample_kernel_sizes, resblock_kernel_sizes, resblock_dilation_sizes,
+    normalize_before.  spectrogram [B, L, 80] -> waveform [B, prod(rates) * L]."""
+    x = spectrogram
+    if cfg.get("normalize_before", True):
+        x = (x - sd["mean"]) / sd["scale"]
+    h = F.conv1d(x.transpose(2, 1), sd["conv_pre.weight"], sd["conv_pre.bias"], padding=3)
+    nk = len(cfg["resblock_kernel_sizes"])
+    for i, (u, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+        h = F.leaky_relu(h, 0.1)
+        h = F.conv_transpose1d(h, sd[f"upsampler.{i}.weight"], sd[f"upsampler.{i}.bias"], stride=u, padding=(k - u) // 2)
+        acc = None
+        for j, (rk, dil) in enumerate(zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"])):
+            p = f"resblocks.{i * nk + j}."
+            r = h
+            for q, d in enumerate(dil):
+                t = F.conv1d(F.leaky_relu(r, 0.1), sd[p + f"convs1.{q}.weight"], sd[p + f"convs1.{q}.bias"], dilation=d,
+                             padding=(rk * d - d) // 2)
+                t = F.conv1d(F.leaky_relu(t, 0.1), sd[p + f"convs2.{q}.weight"], sd[p + f"convs2.{q}.bias"], padding=(rk - 1) // 2)
+                r = t + r
+            acc = r if acc is None else acc + r
+        h = acc / nk
+    h = F.leaky_relu(h)
+    return torch.tanh(F.conv1d(h, sd["conv_post.weight"], sd["conv_post.bias"], padding=3)).squeeze(1)

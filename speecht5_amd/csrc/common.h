@@ -95,12 +95,16 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 #define ACT_GELU 1
 #define ACT_RELU 2
 #define ACT_TANH 3
+#define ACT_LRELU_01 4   // LeakyReLU(0.1)  (HiFi-GAN)
+#define ACT_LRELU_001 5  // LeakyReLU(0.01) (F.leaky_relu default)
 
 __device__ __forceinline__ float act_f(int act, float x) {
   switch (act) {
     case ACT_GELU: return gelu_f(x);
     case ACT_RELU: return x > 0.f ? x : 0.f;
     case ACT_TANH: return tanhf(x);
+    case ACT_LRELU_01: return x > 0.f ? x : 0.1f * x;
+    case ACT_LRELU_001: return x > 0.f ? x : 0.01f * x;
     default: return x;
   }
 }
@@ -110,6 +114,8 @@ __device__ __forceinline__ float act_grad_f(int act, float x) {
     case ACT_GELU: return gelu_grad_f(x);
     case ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case ACT_TANH: { float t = tanhf(x); return 1.f - t * t; }
+    case ACT_LRELU_01: return x > 0.f ? 1.f : 0.1f;
+    case ACT_LRELU_001: return x > 0.f ? 1.f : 0.01f;
     default: return 1.f;
   }
 }

@@ -212,6 +212,16 @@ __global__ void pad_time_kernel(const T* __restrict__ src, T* __restrict__ dst, 
   for (int c = threadIdx.x & 63; c < C; c += 64) d[c] = in ? s[c] : zero;
 }
 
+template <typename T>
+__global__ void channel_affine_kernel(const T* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
+                                      T* __restrict__ y, long long rows, int cols, int act) {
+  const long long n = rows * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cols);
+    y[i] = Elem<T>::from_f(act_f(act, fmaf(Elem<T>::to_f(x[i]), a[c], b[c])));
+  }
+}
+
 // ---- cross entropy: one wave per row ----
 template <typename T>
 __global__ void cross_entropy_kernel(const T* __restrict__ logits, const int32_t* __restrict__ target,
@@ -342,6 +352,16 @@ extern "C" int st5_act_bwd(const void* dy, const void* x, void* dx, int64_t n, i
   ActB f{act};
   DISPATCH(dtype, hipLaunchKernelGGL((map2_kernel<bf16_t, ActB>), grid_for(n / 8 + 1), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, (long long)n, f),
            hipLaunchKernelGGL((map2_kernel<float, ActB>), grid_for(n / 8 + 1), dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, (long long)n, f));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_channel_affine(const void* x, const float* a, const float* b, void* y, int64_t rows, int32_t cols,
+                                  int32_t act, int dtype, void* stream) {
+  if (!x || !a || !b || !y || rows < 0 || cols <= 0) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH(dtype, hipLaunchKernelGGL(channel_affine_kernel<bf16_t>, grid_for(rows * cols), dim3(256), 0, s, (const bf16_t*)x, a, b, (bf16_t*)y, (long long)rows, cols, act),
+           hipLaunchKernelGGL(channel_affine_kernel<float>, grid_for(rows * cols), dim3(256), 0, s, (const float*)x, a, b, (float*)y, (long long)rows, cols, act));
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

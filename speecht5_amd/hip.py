@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32,
 import torch
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_LRELU_01, ACT_LRELU_001 = 0, 1, 2, 3, 4, 5
 A_KSTRIDED, B_KSTRIDED, OUT_F32, DACT = 1, 2, 4, 8
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libspeecht5_hip.so")
@@ -64,6 +64,7 @@ _SIGS = {
     "st5_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
     "st5_act_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "st5_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
+    "st5_channel_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),
     "st5_dropout": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_uint64, c_int, c_void_p]),
     "st5_masked_fill_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "st5_masked_fill_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
