@@ -76,6 +76,8 @@ typedef struct st5_gemm_params {
  * speech_encoder_prenet.py:177; F.conv1d at speech_encoder_prenet.py:300 (layers 1..6) and :107
  * (pos_conv); torch.bmm at multihead_attention.py:340,389; and their autograd backward passes. */
 int st5_gemm(const st5_gemm_params* p, int dtype, void* stream);
+/* 1 (default): plain NT GEMMs use the LDS-DMA pipelined kernel; 0: always the register-staged kernel (A/B testing). */
+int st5_gemm_set_glds(int enabled);
 
 /* ---- row-wise normalisation (encoder.py:226, transformer_layer.py:124,132, speech_encoder_prenet.py:174) */
 /* y = LN(x) * gamma + beta over the last dim (cols); saves mean/rstd (fp32 [rows]). */
@@ -100,6 +102,27 @@ int st5_softmax_fwd(const void* scores, const void* qp, const uint8_t* kpm, void
 int st5_softmax_bwd(void* dP_inout, const void* probs, const float* dP_extra, void* dqp, int32_t BH, int32_t T,
                     int32_t S, int32_t lds, int32_t nb, int32_t maxrel, float dropout_p, uint64_t seed, int dtype,
                     void* stream);
+
+/* ---- fused attention (bf16, head_dim 64): O = dropout(softmax(scale*Q.K^T + relpos-bias + masks)) . V without
+ *      materialising scores (multihead_attention.py:340-389).  q/k/v/o are row-major projections with leading dimensions
+ *      *_ld: row (b*T + t) (queries) / (b*S + s) (keys), column h*64 + d.  lse fp32 [B*H, T] (saved for backward).
+ *      pe: relative key table [nb = 2*maxrel, 64] (dtype) or NULL.  lds: row length used by the dropout counter
+ *      (same generator/counters as the unfused st5_softmax path).  Other dtypes / head sizes: use the unfused path. */
+int st5_flash_attn_fwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld, void* o,
+                       int64_t o_ld, float* lse, const void* pe, const uint8_t* kpm, int32_t B, int32_t H, int32_t T,
+                       int32_t S, int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal, int32_t lds, float scale,
+                       float dropout_p, uint64_t seed, int dtype, void* stream);
+
+/* Backward of st5_flash_attn_fwd: recomputes P from (q, k, bias, lse).  Writes dq/dk/dv (dtype, same row layouts as
+ * q/k/v with their own leading dimensions); dvec fp32 [B*H*T] scratch (D = rowsum(dO*O)).  With pe: qp = scale*q.pe^T
+ * [B*H, T, nb] (dtype, caller computes it with st5_gemm) and dqp [B*H, T, nb] receives the bucket gradients
+ * (the caller folds dqp into dq and d(pe) with st5_gemm, exactly as for the unfused path). */
+int st5_flash_attn_bwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld, const void* o,
+                       int64_t o_ld, const void* dout, int64_t do_ld, void* dq, int64_t dq_ld, void* dk, int64_t dk_ld, void* dv,
+                       int64_t dv_ld, const float* lse, float* dvec, const void* pe, const void* qp, void* dqp,
+                       const uint8_t* kpm, int32_t B, int32_t H, int32_t T, int32_t S, int32_t head_dim, int32_t nb,
+                       int32_t maxrel, int32_t causal, int32_t lds, float scale, float dropout_p, uint64_t seed, int dtype,
+                       void* stream);
 
 /* ---- speech pre-net layer 0: Conv1d(1->C,k,stride,no bias) + GroupNorm(C groups) + GELU
  *      (speech_encoder_prenet.py:300,323-324).  wav fp32 [B,S]; out channels-last [B,L,C] (dtype);

@@ -440,6 +440,151 @@ int launch(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream_t s) {
   return ST5_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// NT fast path: both operands K-major, K a multiple of the k-tile, no K segmentation.  Same tiling, MFMA
+// fragments, swizzled LDS image and epilogue as gemm_kernel, but the operand tiles go HBM -> LDS directly
+// (global_load_lds_dwordx4, 16 B per lane, no staging registers) through a 3-deep ring of LDS buffers with
+// counted vmcnt waits and raw s_barrier, so two k-tiles of loads stay in flight across the barrier while the
+// MFMAs of the current tile run (cdna_hip_programming.md section 5, "Pipelining across barriers").
+// The LDS destination of an LDS-DMA is lane-linear (wave base + lane*16), so the XOR swizzle is applied to
+// the per-lane SOURCE address instead: lane l of a wave-instruction covering rows r0..r0+7 loads logical chunk
+// (l&7) ^ swz(r0 + l>>3) of its row, which is exactly what lands in physical chunk l&7.
+// ------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+constexpr int GLDS_NBUF = 2;  // 64 KB LDS => two blocks per CU; 3- and 4-deep rings at one block per CU measured 10-25 % slower
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int BK = 128 / (int)sizeof(T);
+  typedef typename Frag<T>::type frag_t;
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int z = blockIdx.z;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
+    bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
+  const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
+  const OpAddr aa = make_addr(p.A.ld, p.A.bstride, 0, p.A.rpb, 0);
+  const OpAddr ab = make_addr(p.B.ld, p.B.bstride, 0, p.B.rpb, 0);
+
+  const T* asrc[4];
+  const T* bsrc[4];
+  const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wave) * 8 + rsub;
+    const int c = pc ^ ((row >> 1) & 7);
+    int gr = m0 + row; gr = gr < p.M ? gr : p.M - 1;
+    asrc[i] = Ap + aa.outer(gr) + c * VEC;
+    int gc = n0 + row; gc = gc < p.N ? gc : p.N - 1;
+    bsrc[i] = Bp + ab.outer(gc) + c * VEC;
+  }
+  const int dst0 = wave * 1024;  // byte offset of this wave's 8-row slab inside a 4-slab group
+
+  auto issue = [&](int kt, int buf) {
+    char* base = dsm + buf * 2 * TILE_BYTES + dst0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[i] + (long long)kt * BK), (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int t = 0; t < GLDS_NBUF - 1; ++t)
+    if (t < nk) issue(t, t);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int arow0 = wr * 64 + frow, brow0 = wc * 64 + frow;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed when at most the 8 loads of tile kt+1 are still outstanding
+    {
+      int ahead = nk - 1 - kt;
+      ahead = ahead < GLDS_NBUF - 2 ? ahead : GLDS_NBUF - 2;  // tiles allowed to stay in flight
+      if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + GLDS_NBUF - 1 < nk) issue(kt + GLDS_NBUF - 1, (kt + GLDS_NBUF - 1) % GLDS_NBUF);
+    const char* cur = dsm + (kt % GLDS_NBUF) * 2 * TILE_BYTES;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const frag_t a0 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0, kg * 2 + fhalf));
+      const frag_t a1 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0 + 32, kg * 2 + fhalf));
+      const frag_t b0 = *reinterpret_cast<const frag_t*>(cur + TILE_BYTES + lds_off(brow0, kg * 2 + fhalf));
+      const frag_t b1 = *reinterpret_cast<const frag_t*>(cur + TILE_BYTES + lds_off(brow0 + 32, kg * 2 + fhalf));
+      mma<T>(a0, b0, acc00); mma<T>(a0, b1, acc01); mma<T>(a1, b0, acc10); mma<T>(a1, b1, acc11);
+    }
+  }
+  __syncthreads();
+
+  EpiArgs ea;
+  ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
+  ea.bias = p.bias ? p.bias + (long long)z * p.bias_zs : nullptr;
+  ea.c_ld = p.C.ld; ea.c_bs = p.C.bstride; ea.r_ld = p.R.ld; ea.r_bs = p.R.bstride;
+  ea.p_ld = p.P.ld; ea.p_bs = p.P.bstride; ea.q_ld = p.Cpre.ld; ea.q_bs = p.Cpre.bstride;
+  ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
+  ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
+  ea.atomic = 0;
+  ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
+  ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
+  {
+    const long long zc = z_off(p.C.zs0, p.C.zs1, z, p.zdiv);
+    if (ea.out_f32) ea.C = reinterpret_cast<float*>(ea.C) + zc; else ea.C = reinterpret_cast<T*>(ea.C) + zc;
+    if (ea.R) {
+      const long long zr = z_off(p.R.zs0, p.R.zs1, z, p.zdiv);
+      if (ea.out_f32) ea.R = reinterpret_cast<const float*>(ea.R) + zr; else ea.R = reinterpret_cast<const T*>(ea.R) + zr;
+    }
+    if (ea.P) ea.P = reinterpret_cast<const T*>(ea.P) + z_off(p.P.zs0, p.P.zs1, z, p.zdiv);
+    if (ea.Cpre) ea.Cpre = reinterpret_cast<T*>(ea.Cpre) + z_off(p.Cpre.zs0, p.Cpre.zs1, z, p.zdiv);
+  }
+  float* stage = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (h == 0) stage_write(stage, acc00, acc01, lane);
+    else stage_write(stage, acc10, acc11, lane);
+    __syncthreads();
+    epilogue_rows<T>(ea, stage, m0 + wr * 64 + h * 32, n0 + wc * 64, lane);
+    __syncthreads();
+  }
+}
+
+template <typename T>
+int launch_glds(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  dim3 grid(tiles, 1, p.batch), block(NTHREADS);
+  const size_t shm = (size_t)GLDS_NBUF * 2 * TILE_BYTES;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return ST5_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_glds_kernel<T>), grid, block, shm, s, p, c_vec_ok);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+bool g_use_glds = true;
+
 bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -504,6 +649,14 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
     HIP_CHECK_LAUNCH();
     return ST5_OK;
   }
+  // LDS-DMA pipelined fast path for the plain NT form (Linear / conv forward and, with cached transposed weights,
+  // the data-gradient GEMMs)
+  const int bk = 128 / es;
+  if (g_use_glds && !(p.flags & (ST5_GEMM_A_KSTRIDED | ST5_GEMM_B_KSTRIDED)) && p.K % bk == 0 && p.K >= 2 * bk && !p.A.seg && !p.B.seg)
+    return dtype == ST5_BF16 ? launch_glds<bf16_t>(p, c_vec_ok, s) : launch_glds<float>(p, c_vec_ok, s);
   if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, nsplit, s);
   return launch<float>(p, c_vec_ok, nsplit, s);
 }
+
+/* A/B switch for the LDS-DMA NT kernel (tools/bench_kernels.py uses it for within-process comparisons). */
+extern "C" int st5_gemm_set_glds(int enabled) { g_use_glds = enabled != 0; return ST5_OK; }

@@ -530,6 +530,82 @@ def _attn_bwd(dctx, q, k, v, dq, dk, dv, probs, pdrop, dP_extra, B, H, T, S, hd,
     return None
 
 
+
+# -------------------------------------------------------------------------------------------------
+# fused (flash) attention path: bf16, head_dim 64, no probability output
+# -------------------------------------------------------------------------------------------------
+_FLASH = SimpleNamespace(enabled=True)
+
+
+def set_flash_attention(enabled):
+    """Switch between the fused attention kernels and the unfused GEMM+softmax path (bf16 only; fp32 is always unfused)."""
+    _FLASH.enabled = bool(enabled)
+
+
+def _can_flash(dtype, hd, want_probs):
+    return _FLASH.enabled and dtype == torch.bfloat16 and hd == 64 and not want_probs
+
+
+def _eptr(t3):
+    t, _ld, off = t3
+    return t.data_ptr() + off * t.element_size()
+
+
+def _flash_fwd(q, k, v, B, H, T, S, hd, pe, maxrel, kpm, causal, p_drop, seed):
+    dev = q[0].device
+    d = H * hd
+    ctx = torch.empty(B * T, d, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B * H, T, dtype=torch.float32, device=dev)
+    nb = pe.shape[0] if pe is not None else 0
+    hip.check(hip.lib().st5_flash_attn_fwd(_eptr(q), q[1], _eptr(k), k[1], _eptr(v), v[1], ctx.data_ptr(), d, lse.data_ptr(),
+                                           hip.ptr(pe), hip.ptr(kpm), B, H, T, S, hd, nb, maxrel, 1 if causal else 0, _ceil8(S),
+                                           hd ** -0.5, p_drop, seed, hip.BF16, hip.stream()), "st5_flash_attn_fwd")
+    return ctx, lse
+
+
+def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe, maxrel, kpm, causal, p_drop, seed):
+    """Writes dq/dk/dv slices; returns dPE (fp32) or None."""
+    dev = dctx.device
+    dtype = torch.bfloat16
+    d = H * hd
+    BH = B * H
+    alpha = hd ** -0.5
+    dvec = torch.empty(BH * T, dtype=torch.float32, device=dev)
+    qp = dqp = None
+    nb = 0
+    qt, qld, qoff = q
+    if pe is not None:
+        nb = pe.shape[0]
+        qp = torch.empty(BH, T, nb, dtype=dtype, device=dev)
+        hip.gemm(hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd), hip.operand(pe, hd),
+                 hip.operand(qp, nb, zs0=H * T * nb, zs1=T * nb), T, nb, hd, hip.BF16, batch=BH, zdiv=H, alpha=alpha)
+        dqp = torch.empty(BH, T, nb, dtype=dtype, device=dev)
+    hip.check(hip.lib().st5_flash_attn_bwd(_eptr(q), q[1], _eptr(k), k[1], _eptr(v), v[1], ctx.data_ptr(), d, dctx.data_ptr(), d,
+                                           _eptr(dq), dq[1], _eptr(dk), dk[1], _eptr(dv), dv[1], lse.data_ptr(), dvec.data_ptr(),
+                                           hip.ptr(pe), hip.ptr(qp), hip.ptr(dqp), hip.ptr(kpm), B, H, T, S, hd, nb, maxrel,
+                                           1 if causal else 0, _ceil8(S), alpha, p_drop, seed, hip.BF16, hip.stream()),
+              "st5_flash_attn_bwd")
+    if pe is None:
+        return None
+    dqt, dqld, dqoff = dq
+    # dQ += alpha * dQP . PE
+    hip.gemm(hip.operand(dqp, nb, zs0=H * T * nb, zs1=T * nb), hip.operand(pe, hd),
+             hip.operand(dqt, dqld, off=dqoff, zs0=T * dqld, zs1=hd), T, hd, nb, hip.BF16, batch=BH, zdiv=H,
+             flags=hip.B_KSTRIDED, alpha=alpha, beta=1.0)
+    if not want_dpe:
+        return None
+    part = torch.empty(BH, nb, hd, dtype=torch.float32, device=dev)
+    hip.gemm(hip.operand(dqp, nb, zs0=H * T * nb, zs1=T * nb), hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd),
+             hip.operand(part, hd, zs0=H * nb * hd, zs1=nb * hd), nb, hd, T, hip.BF16, batch=BH, zdiv=H,
+             flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, alpha=alpha)
+    g = torch.zeros(nb, hd, dtype=torch.float32, device=dev)
+    L = hip.lib()
+    ws = hip.workspace(L.st5_colsum_ws_bytes(BH, nb * hd), dev)
+    hip.check(L.st5_colsum_ws(part.data_ptr(), g.data_ptr(), ws.data_ptr(), BH, nb * hd, nb * hd, 1.0, 1, hip.F32, hip.stream()),
+              "st5_colsum_ws")
+    return g
+
+
 class SelfAttentionFunction(torch.autograd.Function):
     """Fused-QKV self-attention core.  qkv [B*T, 3d] -> ctx [B*T, d].  `pe` is the relative-position key
     table [2*maxrel, hd] in the compute dtype (a differentiable cast / norm_k of the parameter) or None."""
@@ -539,17 +615,32 @@ class SelfAttentionFunction(torch.autograd.Function):
         B, H, T, hd, maxrel, causal, p_drop = cfg
         d = H * hd
         seed = next_seed() if p_drop > 0 else 0
+        if _can_flash(qkv.dtype, hd, False):
+            ctx, lse = _flash_fwd((qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), B, H, T, T, hd, pe, maxrel, kpm, causal,
+                                  p_drop, seed)
+            ctx_.save_for_backward(qkv, ctx, lse, pe, kpm)
+            ctx_.meta = (cfg, seed, True)
+            return ctx
         ctx, probs, pdrop = _attn_fwd((qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), B, H, T, T, hd, pe, maxrel,
                                       kpm, causal, p_drop, seed)
         ctx_.save_for_backward(qkv, probs, pdrop, pe)
-        ctx_.meta = (cfg, seed)
+        ctx_.meta = (cfg, seed, False)
         return ctx
 
     @staticmethod
     def backward(ctx_, dctx):
-        qkv, probs, pdrop, pe = ctx_.saved_tensors
-        (B, H, T, hd, maxrel, causal, p_drop), seed = ctx_.meta
+        (B, H, T, hd, maxrel, causal, p_drop), seed, flash = ctx_.meta
         d = H * hd
+        if flash:
+            qkv, ctx, lse, pe, kpm = ctx_.saved_tensors
+            dqkv = torch.empty_like(qkv)
+            dpe = _flash_bwd(dctx.contiguous(), ctx, lse, (qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), (dqkv, 3 * d, 0),
+                             (dqkv, 3 * d, d), (dqkv, 3 * d, 2 * d), B, H, T, T, hd, pe, pe is not None and ctx_.needs_input_grad[1],
+                             maxrel, kpm, causal, p_drop, seed)
+            if dpe is not None and pe.dtype != torch.float32:
+                dpe = to_compute(dpe)
+            return dqkv, dpe, None, None
+        qkv, probs, pdrop, pe = ctx_.saved_tensors
         dqkv = torch.empty_like(qkv)
         dpe = _attn_bwd(dctx.contiguous(), (qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), (dqkv, 3 * d, 0),
                         (dqkv, 3 * d, d), (dqkv, 3 * d, 2 * d), probs, pdrop, None, B, H, T, T, hd, pe,
@@ -568,9 +659,14 @@ class CrossAttentionFunction(torch.autograd.Function):
         B, H, T, S, hd, p_drop, want_probs = cfg
         d = H * hd
         seed = next_seed() if p_drop > 0 else 0
+        if _can_flash(q.dtype, hd, want_probs):
+            ctx, lse = _flash_fwd((q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), B, H, T, S, hd, None, 0, kpm, False, p_drop, seed)
+            ctx_.save_for_backward(q, kv, ctx, lse, kpm)
+            ctx_.meta = (cfg, seed, True)
+            return ctx, None
         ctx, probs, pdrop = _attn_fwd((q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), B, H, T, S, hd, None, 0, kpm, False, p_drop, seed)
         ctx_.save_for_backward(q, kv, probs, pdrop)
-        ctx_.meta = (cfg, seed)
+        ctx_.meta = (cfg, seed, False)
         if want_probs:
             pf = to_float(probs)[:, :, :S] if probs.shape[2] != S or probs.dtype != torch.float32 else probs
             return ctx, pf.reshape(B, H, T, S)
@@ -578,9 +674,16 @@ class CrossAttentionFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx_, dctx, dprobs):
-        q, kv, probs, pdrop = ctx_.saved_tensors
-        (B, H, T, S, hd, p_drop, _), seed = ctx_.meta
+        (B, H, T, S, hd, p_drop, _), seed, flash = ctx_.meta
         d = H * hd
+        if flash:
+            q, kv, ctx, lse, kpm = ctx_.saved_tensors
+            dq = torch.empty_like(q)
+            dkv = torch.empty_like(kv)
+            _flash_bwd(dctx.contiguous(), ctx, lse, (q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), (dq, d, 0), (dkv, 2 * d, 0),
+                       (dkv, 2 * d, d), B, H, T, S, hd, None, False, 0, kpm, False, p_drop, seed)
+            return dq, dkv, None, None
+        q, kv, probs, pdrop = ctx_.saved_tensors
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         extra = None

@@ -40,6 +40,7 @@ class GemmParams(Structure):
 
 _SIGS = {
     "st5_gemm": (c_int, [POINTER(GemmParams), c_int, c_void_p]),
+    "st5_gemm_set_glds": (c_int, [c_int]),
     "st5_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                   c_float, c_int, c_void_p]),
     "st5_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -49,6 +50,13 @@ _SIGS = {
                                 c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_int, c_void_p]),
     "st5_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                 c_int32, c_float, c_uint64, c_int, c_void_p]),
+    "st5_flash_attn_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                   c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                   c_float, c_float, c_uint64, c_int, c_void_p]),
+    "st5_flash_attn_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                   c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                   c_int32, c_float, c_float, c_uint64, c_int, c_void_p]),
     "st5_conv0_gn_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                       c_int32, c_int32, c_int32, c_int32, c_float, c_int, c_void_p]),
     "st5_conv0_gn_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

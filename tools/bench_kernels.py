@@ -36,6 +36,16 @@ def gemm_case(name, M, N, K, dtype, aks=False, bks=False, out_f32=False, act=0, 
 
 
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "glds":
+        for use in (0, 1):
+            hip.lib().st5_gemm_set_glds(use)
+            print("---- glds", use)
+            for dtype in (torch.bfloat16, torch.float32):
+                for (M, N, K) in ((3992, 2304, 768), (3992, 768, 768), (3992, 3072, 768), (3992, 768, 3072), (8192, 3072, 768), (8192, 768, 3072),
+                                  (127992, 512, 1536), (8192, 8192, 8192)):
+                    gemm_case("NT", M, N, K, dtype, act=1)
+        sys.exit(0)
     M = 8 * 499
     for dtype in (torch.bfloat16, torch.float32):
         gemm_case("qkv proj (NT)", M, 2304, 768, dtype)
