@@ -167,6 +167,9 @@ int st5_masked_fill_rows_bwd(void* dx, const uint8_t* mask, float* dv, int64_t r
 /* y[r,:] = x[r,:] + scale * table[idx[r], :]   (table fp32 [n, cols]); idx int32 [rows] */
 int st5_add_table_rows(const void* x, const float* table, const int32_t* idx, void* y, int64_t rows, int32_t cols,
                        float scale, int dtype, void* stream);
+/* same with the scale read from device memory (learnable alpha of ScaledPositionalEncoding; no host sync) */
+int st5_add_table_rows_dev(const void* x, const float* table, const int32_t* idx, void* y, int64_t rows, int32_t cols,
+                           const float* scale_dev, int dtype, void* stream);
 /* y[r,:] = emb_scale * table[tok[r],:] + pos_scale * pos[pidx[r],:]   (embedding + positions) */
 int st5_embed_rows(const float* table, const int32_t* tok, const float* pos, const int32_t* pidx, void* y,
                    int64_t rows, int32_t cols, float emb_scale, float pos_scale, int dtype, void* stream);

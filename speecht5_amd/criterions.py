@@ -32,18 +32,24 @@ class Tacotron2Loss(nn.Module):
     def __init__(self, use_masking=True, use_weighted_masking=False, bce_pos_weight=20.0):
         super().__init__()
         assert use_masking and not use_weighted_masking
-        self.register_buffer("pos_weight", torch.tensor(bce_pos_weight), persistent=False)
+        self.bce_pos_weight = float(bce_pos_weight)
+        self._pw = {}
 
     def forward(self, after_outs, before_outs, logits, ys, labels, olens):
+        # mean over the non-padded elements, written as mask-weighted sums: the reference's masked_select has a
+        # data-dependent output size (= a host sync); the values are identical
         masks = make_non_pad_mask(olens, ys.shape[1], ys.device).unsqueeze(-1)
-        ys_m = ys.masked_select(masks)
-        after_m = after_outs.masked_select(masks)
-        before_m = before_outs.masked_select(masks)
-        labels_m = labels.masked_select(masks[:, :, 0])
-        logits_m = logits.masked_select(masks[:, :, 0])
-        l1 = F.l1_loss(after_m, ys_m) + F.l1_loss(before_m, ys_m)
-        mse = F.mse_loss(after_m, ys_m) + F.mse_loss(before_m, ys_m)
-        bce = F.binary_cross_entropy_with_logits(logits_m, labels_m, pos_weight=self.pos_weight.to(ys.device))
+        m = masks.to(ys.dtype)
+        n_frames = m.sum()
+        n_elem = n_frames * ys.shape[2]
+        da, db = (after_outs - ys) * m, (before_outs - ys) * m
+        l1 = (da.abs().sum() + db.abs().sum()) / n_elem
+        mse = (da.pow(2).sum() + db.pow(2).sum()) / n_elem
+        pw = self._pw.get(ys.device)
+        if pw is None:
+            pw = self._pw[ys.device] = torch.tensor(self.bce_pos_weight, device=ys.device)
+        bce_all = F.binary_cross_entropy_with_logits(logits, labels, pos_weight=pw, reduction="none")
+        bce = (bce_all * m[:, :, 0]).sum() / n_frames
         return l1, mse, bce
 
 
@@ -105,7 +111,8 @@ class TexttoSpeechLoss(nn.Module):
         if r > 1:
             olens_in = torch.div(torch.as_tensor(olens), r, rounding_mode="floor")
             olens = torch.as_tensor(olens) - torch.as_tensor(olens) % r
-            max_olen = int(olens.max())
+            # the collater pads to the longest utterance, so max(olens) = padded length rounded down to r (no host sync)
+            max_olen = ys.shape[1] - ys.shape[1] % r
             ys = ys[:, :max_olen]
             labels = labels[:, :max_olen]
             labels = torch.scatter(labels, 1, (olens.to(labels.device) - 1).unsqueeze(1), 1.0)

@@ -138,27 +138,29 @@ __global__ void masked_fill_rows_kernel(T* __restrict__ x, const uint8_t* __rest
   if (row >= rows || !mask[row]) return;
   for (int c = threadIdx.x & 63; c < cols; c += 64) x[row * cols + c] = Elem<T>::from_f(v[c]);
 }
-// dv[c] += sum_{masked rows} dx[r,c]; dx[r,:] = 0 for masked rows.  Grid over column blocks.
+// dv[c] += sum_{masked rows} dx[r,c]; dx[r,:] = 0 for masked rows.  grid (column blocks of 256, row splits):
+// each thread owns one column and strides over rows; block partials go to dv with fp32 atomics.
 template <typename T>
 __global__ void masked_fill_rows_bwd_kernel(T* __restrict__ dx, const uint8_t* __restrict__ mask,
                                             float* __restrict__ dv, long long rows, int cols) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   float s = 0.f;
-  for (long long r = 0; r < rows; ++r) {
+  for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
     if (mask[r]) {
       s += Elem<T>::to_f(dx[r * cols + c]);
       dx[r * cols + c] = Elem<T>::from_f(0.f);
     }
   }
-  if (dv) dv[c] += s;
+  if (dv && s != 0.f) unsafeAtomicAdd(dv + c, s);
 }
 template <typename T>
 __global__ void add_table_rows_kernel(const T* __restrict__ x, const float* __restrict__ table,
                                       const int32_t* __restrict__ idx, T* __restrict__ y, long long rows, int cols,
-                                      float scale) {
+                                      float scale, const float* __restrict__ scale_dev) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (scale_dev) scale *= scale_dev[0];
   const float* trow = table + (long long)idx[row] * cols;
   for (int c = (threadIdx.x & 63) * 8; c < cols; c += 512) {
     if (c + 8 <= cols) {
@@ -391,9 +393,10 @@ extern "C" int st5_masked_fill_rows_bwd(void* dx, const uint8_t* mask, float* dv
   if (!dx || !mask || rows < 0 || cols <= 0) return ST5_ERR_ARG;
   if (rows == 0) return ST5_OK;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)((cols + 63) / 64));
-  DISPATCH(dtype, hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<bf16_t>, grid, dim3(64), 0, s, (bf16_t*)dx, mask, dv, (long long)rows, cols),
-           hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<float>, grid, dim3(64), 0, s, (float*)dx, mask, dv, (long long)rows, cols));
+  const unsigned ny = (unsigned)(rows < 256 ? rows : 256);
+  dim3 grid((unsigned)((cols + 255) / 256), ny);
+  DISPATCH(dtype, hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)dx, mask, dv, (long long)rows, cols),
+           hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<float>, grid, dim3(256), 0, s, (float*)dx, mask, dv, (long long)rows, cols));
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -403,8 +406,19 @@ extern "C" int st5_add_table_rows(const void* x, const float* table, const int32
   if (rows == 0) return ST5_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((rows + 3) / 4));
-  DISPATCH(dtype, hipLaunchKernelGGL(add_table_rows_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, table, idx, (bf16_t*)y, (long long)rows, cols, scale),
-           hipLaunchKernelGGL(add_table_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)x, table, idx, (float*)y, (long long)rows, cols, scale));
+  DISPATCH(dtype, hipLaunchKernelGGL(add_table_rows_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, table, idx, (bf16_t*)y, (long long)rows, cols, scale, (const float*)nullptr),
+           hipLaunchKernelGGL(add_table_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)x, table, idx, (float*)y, (long long)rows, cols, scale, (const float*)nullptr));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_add_table_rows_dev(const void* x, const float* table, const int32_t* idx, void* y, int64_t rows,
+                                      int32_t cols, const float* scale_dev, int dtype, void* stream) {
+  if (!x || !table || !idx || !y || !scale_dev || rows < 0 || cols <= 0 || cols % 8) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  DISPATCH(dtype, hipLaunchKernelGGL(add_table_rows_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, table, idx, (bf16_t*)y, (long long)rows, cols, 1.f, scale_dev),
+           hipLaunchKernelGGL(add_table_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)x, table, idx, (float*)y, (long long)rows, cols, 1.f, scale_dev));
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

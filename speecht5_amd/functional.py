@@ -810,6 +810,15 @@ class AddTableRowsFunction(torch.autograd.Function):
         return dy, None, None, None
 
 
+def add_table_rows_dev(x, table, idx, scale_dev):
+    """y[r] = x[r] + scale_dev[0] * table[idx[r]] with the scale read from device memory (no autograd)."""
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    hip.check(hip.lib().st5_add_table_rows_dev(x.data_ptr(), table.data_ptr(), idx.data_ptr(), y.data_ptr(), rows, x.shape[-1],
+                                               scale_dev.data_ptr(), _dt(x), hip.stream()), "st5_add_table_rows_dev")
+    return y
+
+
 def add_table_rows(x, table, idx, scale=1.0):
     return AddTableRowsFunction.apply(x.contiguous(), table, idx.to(torch.int32).contiguous(), float(scale))
 

@@ -78,6 +78,7 @@ _SIGS = {
     "st5_masked_fill_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "st5_add_table_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_int,
                                    c_void_p]),
+    "st5_add_table_rows_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int, c_void_p]),
     "st5_embed_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
                                c_int, c_void_p]),
     "st5_embed_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_int, c_void_p]),

@@ -97,7 +97,7 @@ class ScaledPEAdd(torch.autograd.Function):
     def forward(ctx, x, alpha, pe):
         B, T, d = x.shape
         idx = torch.arange(T, device=x.device, dtype=torch.int32).repeat(B)
-        y = Fn.AddTableRowsFunction.apply(x, pe, idx, float(alpha.detach()))
+        y = Fn.add_table_rows_dev(x, pe, idx, alpha.detach())  # alpha stays on the device (no host sync)
         ctx.save_for_backward(pe)
         ctx.alpha = alpha
         ctx.T = T

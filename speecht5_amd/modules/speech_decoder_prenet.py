@@ -62,7 +62,8 @@ class SpeechDecoderPrenet(nn.Module):
             tgt_frames_mask = None
             if tgt_lengths_in is not None:
                 lens = torch.as_tensor(tgt_lengths_in, device=x.device)
-                tgt_frames_mask = torch.arange(int(lens.max()), device=x.device)[None, :] >= lens[:, None]
+                # the batch is padded to its longest target, so max(lens) == T: no host read needed
+                tgt_frames_mask = torch.arange(x.size(1), device=x.device)[None, :] >= lens[:, None]
             return x, tgt_frames_mask
 
     def set_num_updates(self, num_updates):

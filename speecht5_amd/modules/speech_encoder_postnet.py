@@ -39,23 +39,33 @@ class SpeechEncoderPostnet(nn.Module):
         """x [B,T,C] (compute dtype).  Boolean-index gathers are torch glue, the projection is the HIP GEMM."""
         label_embs_list = self.label_embs_concat.split(self.num_classes, 0)
 
-        def branch(sel):
-            rows = x[sel]  # [S, C]
+        host = getattr(mask_indices, "_st5_host", None)
+
+        def branch(sel, sel_host):
+            if sel_host is not None:  # gather indices known on the host: no nonzero() sync on the device
+                idx = torch.nonzero(sel_host.reshape(-1)).squeeze(1).to(x.device, non_blocking=True)
+                rows = x.reshape(-1, x.shape[-1]).index_select(0, idx)
+                sel = idx
+            else:
+                rows = x[sel]  # [S, C]
             proj = Fn.linear(rows.contiguous(), self.final_proj.weight, self.final_proj.bias)
             projs = proj.chunk(len(target_list), dim=-1) if self.untie_final_proj else [proj] * len(target_list)
             outs = []
             for i, (p, t) in enumerate(zip(projs, target_list)):
-                tg = t[sel]
+                tg = t.reshape(-1).index_select(0, sel) if sel_host is not None else t[sel]
                 emb = label_embs_list[i]
                 outs.append(self.compute_nce(Fn.as_float(p.contiguous()), emb[tg.long()], emb, tg))
             return outs
 
+        mh = ph = None
+        if host is not None:
+            mh, ph = host
         if not self.skip_masked:
-            logit_m_list = branch(torch.logical_and(~padding_mask, mask_indices))
+            logit_m_list = branch(torch.logical_and(~padding_mask, mask_indices), (~ph & mh) if host is not None else None)
         else:
             logit_m_list = [None for _ in target_list]
         if not self.skip_nomask:
-            logit_u_list = branch(torch.logical_and(~padding_mask, ~mask_indices))
+            logit_u_list = branch(torch.logical_and(~padding_mask, ~mask_indices), (~ph & ~mh) if host is not None else None)
         else:
             logit_u_list = [None for _ in target_list]
         return {"logit_m_list": logit_m_list, "logit_u_list": logit_u_list, "padding_mask": padding_mask}

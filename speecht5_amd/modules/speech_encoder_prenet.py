@@ -103,7 +103,28 @@ class SpeechEncoderPrenet(nn.Module):
         with torch.no_grad() if not ft else contextlib.ExitStack():
             return self._forward(src_tokens, require_feat_pen, target_list, padding_mask, mask)
 
+    def _frames(self, n_samples):
+        n = n_samples
+        for _, k, s in self.feature_extractor.conv_layers_infos:
+            n = (n - k) // s + 1
+        return n
+
     def _forward(self, src_tokens, require_feat_pen=False, target_list=None, padding_mask=None, mask=True):
+        # Everything that needs host data (frame padding mask, HuBERT span mask from the numpy RNG) depends only on the
+        # INPUTS, so it is computed first, while the GPU is still idle / busy with the previous step: the single
+        # device->host read of `padding_mask` happens here instead of in the middle of the forward pass.
+        T = self._frames(src_tokens.size(1))
+        if target_list is not None:
+            targ_tsz = min([t.size(1) for t in target_list])
+            if self.feat2tar_ratio * T > targ_tsz:
+                T = int(targ_tsz / self.feat2tar_ratio)
+        pm_host = padding_mask.cpu()
+        extra = pm_host.size(1) % T
+        pmh = pm_host[:, :-extra] if extra > 0 else pm_host
+        frame_pad_host = pmh.view(pmh.size(0), T, -1).all(-1)  # == forward_padding_mask() on the host
+        pre_mask = None
+        if mask and self.mask_prob > 0 and frame_pad_host is not None:
+            pre_mask = self._sample_mask(src_tokens.size(0), T, frame_pad_host, src_tokens.device)
         if self.feature_grad_mult > 0:
             x = self.feature_extractor(src_tokens, grad_scale=self.feature_grad_mult)  # [B, T, C]
         else:
@@ -118,7 +139,11 @@ class SpeechEncoderPrenet(nn.Module):
             x = Fn.linear(x, self.post_extract_proj.weight, self.post_extract_proj.bias)
         x = Fn.dropout(x, self.dropout, self.training)
         if mask:
-            x, mask_indices = self.apply_hubert_mask(x, encoder_padding_mask)
+            if pre_mask is None and self.mask_prob > 0:
+                # (target-trimmed path: the frame padding mask depends on the trimmed feature length)
+                fp_host = encoder_padding_mask.cpu()
+                pre_mask = self._sample_mask(x.size(0), x.size(1), fp_host, x.device)
+            x, mask_indices = self.apply_hubert_mask(x, encoder_padding_mask, pre_mask)
         else:
             mask_indices = None
         if self.use_conv_pos:
@@ -140,8 +165,8 @@ class SpeechEncoderPrenet(nn.Module):
         if self.feat2tar_ratio * feat_tsz > targ_tsz:
             feat_tsz = int(targ_tsz / self.feat2tar_ratio)
             features = features[:, :feat_tsz].contiguous()
-        target_inds = torch.arange(feat_tsz).float() * self.feat2tar_ratio
-        target_list = [t[:, target_inds.long()] for t in target_list]
+        target_inds = (torch.arange(feat_tsz).float() * self.feat2tar_ratio).long().to(features.device, non_blocking=True)
+        target_list = [t.index_select(1, target_inds) for t in target_list]
         return features, target_list
 
     def forward_padding_mask(self, features, padding_mask):
@@ -154,14 +179,20 @@ class SpeechEncoderPrenet(nn.Module):
     def get_src_lengths(self, src_lengths):
         return self.feature_extractor.get_out_seq_lens_tensor(src_lengths)
 
-    def apply_hubert_mask(self, x, padding_mask):
+    def _sample_mask(self, B, T, frame_pad_host, device):
+        """HuBERT span mask from the numpy RNG (speech_encoder_prenet.py:237-247) -> (device bool [B,T], host copies)."""
+        m = compute_mask_indices((B, T), frame_pad_host, self.mask_prob, self.hubert_mask_length, self.mask_selection,
+                                 self.mask_other, min_masks=2, no_overlap=self.no_mask_overlap, min_space=self.mask_min_space)
+        mt = torch.from_numpy(m)
+        dev = mt.to(device, non_blocking=True)
+        dev._st5_host = (mt, frame_pad_host)  # host copies: the NCE head derives its gather indices without a device sync
+        return dev
+
+    def apply_hubert_mask(self, x, padding_mask, pre_mask=None):
         B, T, C = x.shape
         mask_indices = None
         if self.mask_prob > 0:
-            m = compute_mask_indices((B, T), padding_mask.cpu() if padding_mask is not None else None, self.mask_prob,
-                                     self.hubert_mask_length, self.mask_selection, self.mask_other, min_masks=2,
-                                     no_overlap=self.no_mask_overlap, min_space=self.mask_min_space)
-            mask_indices = torch.from_numpy(m).to(x.device)
+            mask_indices = pre_mask if pre_mask is not None else self._sample_mask(B, T, padding_mask.cpu(), x.device)
             x = Fn.masked_fill_rows(x, mask_indices.reshape(-1), self.mask_emb)
         if self.mask_channel_prob > 0:
             raise NotImplementedError("channel masking (ASR fine-tuning regulariser) has no HIP kernel yet")

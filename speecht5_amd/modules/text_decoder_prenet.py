@@ -35,7 +35,7 @@ class TextDecoderPrenet(nn.Module):
         """With an incremental state the reference embeds only the last token (:102-105); this mirror always
         embeds the whole prefix and the decoder recomputes it (identical outputs for the last position)."""
         pad = prev_output_tokens.eq(self.padding_idx)
-        x_mask = pad if bool(pad.any()) else None
+        x_mask = pad  # the reference returns None when nothing is padded (a host sync); an all-False mask is equivalent
         positions = self.embed_positions.positions(~pad)
         table = self.embed_positions.table(prev_output_tokens.shape[1] + self.padding_idx + 2, prev_output_tokens.device)
         x = Fn.embed_rows(self.embed_tokens.weight, prev_output_tokens, pos=table, pidx=positions, emb_scale=self.embed_scale)

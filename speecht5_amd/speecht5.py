@@ -227,8 +227,9 @@ class T5TransformerModel(FairseqEncoderDecoderModel):
             q = self.quantizer(enc_btc)
             tlen = q["x"].size(1)
             random_idx = torch.randperm(tlen)[:int(tlen * self.codebook_prob)]
-            q_w = q["x"].new_zeros(tlen)
-            q_w[random_idx.to(q_w.device)] = 1.0
+            q_w_host = torch.zeros(tlen)
+            q_w_host[random_idx] = 1.0
+            q_w = q_w_host.to(q["x"].device, non_blocking=True)  # built on the host: no device-side index_put / sync
             # time-wise mix of quantised codes and encoder states (:870-877); fp32 torch arithmetic on [B,T,d]
             mixed = q_w.view(-1, 1) * q["x"] + (-q_w + 1).view(-1, 1) * Fn.as_float(enc_btc.contiguous())
             encoder_output["encoder_out"][0] = mixed.transpose(0, 1)
