@@ -114,8 +114,8 @@ int st5_flash_attn_fwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld,
                        float dropout_p, uint64_t seed, int dtype, void* stream);
 
 /* Backward of st5_flash_attn_fwd: recomputes P from (q, k, bias, lse).  Writes dq/dk/dv (dtype, same row layouts as
- * q/k/v with their own leading dimensions); dvec fp32 [B*H*T] scratch (D = rowsum(dO*O)).  With pe: qp = scale*q.pe^T
- * [B*H, T, nb] (dtype, caller computes it with st5_gemm) and dqp [B*H, T, nb] receives the bucket gradients
+ * q/k/v with their own leading dimensions); dvec fp32 [B*H*T] scratch (D = rowsum(dO*O)).  With pe: qp = scale*log2(e)*q.pe^T
+ * [B*H, T, nb] (dtype, caller computes it with st5_gemm; the kernels evaluate exp2 in the log2 domain) and dqp [B*H, T, nb] receives the bucket gradients
  * (the caller folds dqp into dq and d(pe) with st5_gemm, exactly as for the unfused path). */
 int st5_flash_attn_bwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld, const void* o,
                        int64_t o_ld, const void* dout, int64_t do_ld, void* dq, int64_t dq_ld, void* dk, int64_t dk_ld, void* dv,

@@ -120,20 +120,61 @@ __device__ __forceinline__ float act_grad_f(int act, float x) {
   }
 }
 
-// Counter-based RNG for dropout: one 32-bit hash per element index (murmur3 finalizer over a
-// 64-bit counter mixed with the seed).  keep = u >= p * 2^32.  The same (seed, index) is
-// re-evaluated in the backward pass, so no mask is stored.
-__device__ __forceinline__ unsigned int rng_hash(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+// Counter-based RNG for dropout, two levels so that the per-element cost is a few VALU instructions:
+//   * every aligned block of 64 consecutive element indices gets a 32-bit key = fold(splitmix64(seed, idx >> 6));
+//   * every aligned PAIR of elements inside the block gets 32 bits = mix(key ^ pair * golden), 16 bits per
+//     element (two xorshift-multiply rounds with 24-bit multiplies); keep <=> u16 >= p * 65536.
+// The same (seed, idx) is re-evaluated by every kernel that needs the mask (GEMM epilogue, softmax, fused attention,
+// backward passes), so no mask is ever stored.  Attention probabilities use idx = row * round_up(row_len, 64) + key so a
+// 64-key tile of the fused kernels is exactly one block.
+__device__ __forceinline__ unsigned long long rng_hash64(unsigned long long seed, unsigned long long group) {
+  unsigned long long z = group + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (unsigned int)(z >> 16);
+  return z ^ (z >> 31);
 }
-__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned long long idx,
-                                               unsigned int thresh, float inv_keep) {
-  return rng_hash(seed, idx) >= thresh ? inv_keep : 0.f;
+__device__ __forceinline__ unsigned int dropout_thresh(float p) { return (unsigned int)(p * 65536.0f); }
+__device__ __forceinline__ unsigned int drop_block_key(unsigned long long seed, unsigned long long block) {
+  const unsigned long long h = rng_hash64(seed, block);
+  return (unsigned int)h ^ (unsigned int)(h >> 32);
 }
+// 2 x 16 random bits for elements (2*pair, 2*pair+1) of a block; pair in [0, 32)
+// pc = pair * 0x9E3779B1 (callers with a compile-time pair pass the product)
+__device__ __forceinline__ unsigned int drop_pair_bits_pc(unsigned int key, unsigned int pc) {
+  unsigned int x = key ^ pc;
+  x ^= x >> 16; x = __umul24(x, 0xCA6B85u);  // v_mul_u32_u24 is full rate (v_mul_lo_u32 is quarter rate)
+  x ^= x >> 13; x = __umul24(x, 0xB2AE35u);
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned int drop_pair_bits(unsigned int key, unsigned int pair) {
+  return drop_pair_bits_pc(key, pair * 0x9E3779B1u);
+}
+__device__ __forceinline__ bool drop_keep(unsigned int bits, int odd, unsigned int thresh16) {
+  return (odd ? bits >> 16 : bits & 0xffffu) >= thresh16;
+}
+__device__ __forceinline__ float drop_pick(unsigned int bits, int odd, unsigned int thresh16, float inv_keep) {
+  return ((odd ? bits >> 16 : bits & 0xffffu) >= thresh16) ? inv_keep : 0.f;
+}
+// scale factor (0 or inv_keep) of a single element
+__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned long long idx, unsigned int thresh16,
+                                               float inv_keep) {
+  const unsigned int key = drop_block_key(seed, idx >> 6);
+  return drop_pick(drop_pair_bits(key, ((unsigned int)idx & 63u) >> 1), (int)(idx & 1), thresh16, inv_keep);
+}
+// scale factors of the 8 elements idx8 .. idx8+7 (idx8 % 8 == 0): one block key, four pair hashes
+__device__ __forceinline__ void dropout_scale8(unsigned long long seed, unsigned long long idx8, unsigned int thresh16,
+                                               float inv_keep, float (&out)[8]) {
+  const unsigned int key = drop_block_key(seed, idx8 >> 6);
+  const unsigned int p0 = ((unsigned int)idx8 & 63u) >> 1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned int bits = drop_pair_bits(key, p0 + e);
+    out[2 * e] = drop_pick(bits, 0, thresh16, inv_keep);
+    out[2 * e + 1] = drop_pick(bits, 1, thresh16, inv_keep);
+  }
+}
+__device__ __forceinline__ long long drop_row_stride(int row_len) { return ((long long)row_len + 63) & ~63ll; }
 
 #define HIP_CHECK_LAUNCH()                                   \
   do {                                                       \

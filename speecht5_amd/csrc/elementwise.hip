@@ -371,7 +371,7 @@ extern "C" int st5_dropout(const void* x, void* y, int64_t n, float p, uint64_t 
   if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return ST5_ERR_ARG;
   if (n == 0) return ST5_OK;
   hipStream_t s = (hipStream_t)stream;
-  Drop f{(unsigned long long)seed, (unsigned int)((double)p * 4294967296.0), 1.f / (1.f - p)};
+  Drop f{(unsigned long long)seed, (unsigned int)(p * 65536.0f), 1.f / (1.f - p)};
   DISPATCH(dtype, hipLaunchKernelGGL((map1_kernel<bf16_t, Drop>), grid_for(n / 8 + 1), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long long)n, f),
            hipLaunchKernelGGL((map1_kernel<float, Drop>), grid_for(n / 8 + 1), dim3(256), 0, s, (const float*)x, (float*)y, (long long)n, f));
   HIP_CHECK_LAUNCH();

@@ -227,7 +227,7 @@ __device__ __forceinline__ void stage_write(float* stage, const f32x16& acc0, co
 template <typename T>
 __device__ __forceinline__ void epilogue_rows(const EpiArgs& ea, const float* stage, const int mbase, const int nbase,
                                               const int lane) {
-  const unsigned int thresh = ea.dropout_p > 0.f ? (unsigned int)((double)ea.dropout_p * 4294967296.0) : 0u;
+  const unsigned int thresh = ea.dropout_p > 0.f ? dropout_thresh(ea.dropout_p) : 0u;
   const float inv_keep = ea.dropout_p > 0.f ? 1.f / (1.f - ea.dropout_p) : 1.f;
 #pragma unroll 1
   for (int pass = 0; pass < 4; ++pass) {
@@ -271,8 +271,10 @@ __device__ __forceinline__ void epilogue_rows(const EpiArgs& ea, const float* st
       }
       if (ea.dropout_p > 0.f) {
         const unsigned long long ctr = ea.ctr_base + (unsigned long long)gm * (unsigned long long)ea.N + gn;
+        float dsc[8];  // ctr is a multiple of 8 (N % 8 == 0, gn % 8 == 0)
+        dropout_scale8(ea.seed, ctr, thresh, inv_keep, dsc);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= dropout_scale(ea.seed, ctr + e, thresh, inv_keep);
+        for (int e = 0; e < 8; ++e) v[e] *= dsc[e];
       }
       if (ea.R) {
 #pragma unroll

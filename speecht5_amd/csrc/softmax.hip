@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
     }
   sum = wave_sum(sum);
   const float inv = sum > 0.f ? 1.f / sum : 0.f;  // fully-masked row -> zeros (reference would give NaN)
-  const unsigned int thresh = dropout_p > 0.f ? (unsigned int)((double)dropout_p * 4294967296.0) : 0u;
+  const unsigned int thresh = dropout_p > 0.f ? dropout_thresh(dropout_p) : 0u;
   const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -78,9 +78,9 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
       store8f<T>(probs + rowid * lds + j0, v[c]);
       if (probs_drop) {
         float d[8];
+        dropout_scale8(seed, (unsigned long long)(rowid * drop_row_stride(lds) + j0), thresh, inv_keep, d);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          d[e] = v[c][e] * dropout_scale(seed, (unsigned long long)rowid * lds + j0 + e, thresh, inv_keep);
+        for (int e = 0; e < 8; ++e) d[e] *= v[c][e];
         store8f<T>(probs_drop + rowid * lds + j0, d);
       }
     }
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(T* __restrict__ dP, co
   __syncthreads();
   if (active) {
     const int i = (int)(rowid % Tq);
-    const unsigned int thresh = dropout_p > 0.f ? (unsigned int)((double)dropout_p * 4294967296.0) : 0u;
+    const unsigned int thresh = dropout_p > 0.f ? dropout_thresh(dropout_p) : 0u;
     const float inv_keep = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     float g[NCH][8], p[NCH][8];
     float dot = 0.f;
@@ -113,10 +113,12 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(T* __restrict__ dP, co
       if (j0 < lds) {
         load8f<T>(dP + rowid * lds + j0, g[c]);
         load8f<T>(probs + rowid * lds + j0, p[c]);
+        float dsc[8];
+        if (dropout_p > 0.f) dropout_scale8(seed, (unsigned long long)(rowid * drop_row_stride(lds) + j0), thresh, inv_keep, dsc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float x = g[c][e];
-          if (dropout_p > 0.f) x *= dropout_scale(seed, (unsigned long long)rowid * lds + j0 + e, thresh, inv_keep);
+          if (dropout_p > 0.f) x *= dsc[e];
           if (dP_extra && j0 + e < S) x += dP_extra[rowid * S + j0 + e];
           if (j0 + e >= S) x = 0.f;
           g[c][e] = x;

@@ -114,6 +114,19 @@ def fused_weight(weights, dtype):
     return weight_cache.get(("w", dtype) + tuple(id(w) for w in weights), weights, build)
 
 
+def fused_weight_t(weights, dtype):
+    """[K, sum N_i] compute-dtype TRANSPOSE of the stacked weights (cached): the B operand of the data-gradient GEMM
+    dX = G . W in K-major form, so that dgrad runs on the same LDS-DMA NT kernel as the forward."""
+    def build():
+        src = weights[0].detach() if len(weights) == 1 else torch.cat([w.detach() for w in weights], 0)
+        src = src.reshape(src.shape[0], -1).contiguous().float()
+        out = torch.empty(src.shape[1], src.shape[0], dtype=dtype, device=src.device)
+        _cast_into(src, out, transpose=True)
+        return out
+
+    return weight_cache.get(("wt", dtype) + tuple(id(w) for w in weights), weights, build)
+
+
 def fused_bias(biases):
     if all(b is None for b in biases):
         return None
@@ -293,9 +306,13 @@ class LinearFunction(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=dtype, device=x2.device)
-            # dX = G . W   (B operand k-strided: W is [N, K], reduction over N)
-            hip.gemm(hip.operand(g, ldn), hip.operand(Wc, Wc.shape[1]), hip.operand(dx, K), M, K, N, _dt(dtype),
-                     flags=hip.B_KSTRIDED)
+            if N % 8 == 0:
+                # dX = G . W as an NT GEMM against the cached transposed weights W^T [K, N]
+                Wt = fused_weight_t(weights, dtype)
+                hip.gemm(hip.operand(g, ldn), hip.operand(Wt, N), hip.operand(dx, K), M, K, N, _dt(dtype))
+            else:  # odd widths (vocabulary): B operand k-strided, W is [N, K], reduction over N
+                hip.gemm(hip.operand(g, ldn), hip.operand(Wc, Wc.shape[1]), hip.operand(dx, K), M, K, N, _dt(dtype),
+                         flags=hip.B_KSTRIDED)
             dx = dx.view(xshape)
         off = 0
         for i, w in enumerate(weights):
@@ -364,8 +381,9 @@ class FFNFunction(torch.autograd.Function):
             g = _dropout(g, p_out, s2)
         # dHpre = (G . W2) * act'(Hpre) [* activation-dropout mask]   (fused epilogue)
         dh = torch.empty(M, Fd, dtype=dtype, device=x2.device)
-        hip.gemm(hip.operand(g, dout), hip.operand(W2, Fd), hip.operand(dh, Fd), M, Fd, dout, _dt(dtype),
-                 P=hip.operand(hpre, Fd), act=act, flags=hip.B_KSTRIDED | hip.DACT, dropout_p=p_act, seed=s1)
+        W2t = fused_weight_t([w2], dtype)  # [Fd, dout]
+        hip.gemm(hip.operand(g, dout), hip.operand(W2t, dout), hip.operand(dh, Fd), M, Fd, dout, _dt(dtype),
+                 P=hip.operand(hpre, Fd), act=act, flags=hip.DACT, dropout_p=p_act, seed=s1)
         if w2.requires_grad:
             hip.gemm(hip.operand(g, dout), hip.operand(h, Fd), hip.operand(grad_buffer(w2), Fd), dout, Fd, M, _dt(dtype),
                      flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0)
@@ -376,7 +394,8 @@ class FFNFunction(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=dtype, device=x2.device)
-            hip.gemm(hip.operand(dh, Fd), hip.operand(W1, d), hip.operand(dx, d), M, d, Fd, _dt(dtype), flags=hip.B_KSTRIDED)
+            W1t = fused_weight_t([w1], dtype)  # [d, Fd]
+            hip.gemm(hip.operand(dh, Fd), hip.operand(W1t, Fd), hip.operand(dx, d), M, d, Fd, _dt(dtype))
             dx = dx.view(xshape)
         if w1.requires_grad:
             hip.gemm(hip.operand(dh, Fd), hip.operand(x2, d), hip.operand(grad_buffer(w1), d), Fd, d, M, _dt(dtype),
@@ -551,6 +570,9 @@ def _eptr(t3):
     return t.data_ptr() + off * t.element_size()
 
 
+_LOG2E = 1.4426950408889634
+
+
 def _flash_fwd(q, k, v, B, H, T, S, hd, pe, maxrel, kpm, causal, p_drop, seed):
     dev = q[0].device
     d = H * hd
@@ -577,8 +599,9 @@ def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe
     if pe is not None:
         nb = pe.shape[0]
         qp = torch.empty(BH, T, nb, dtype=dtype, device=dev)
+        # the kernels work in the log2 domain: qp = scale * log2(e) * q.pe^T
         hip.gemm(hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd), hip.operand(pe, hd),
-                 hip.operand(qp, nb, zs0=H * T * nb, zs1=T * nb), T, nb, hd, hip.BF16, batch=BH, zdiv=H, alpha=alpha)
+                 hip.operand(qp, nb, zs0=H * T * nb, zs1=T * nb), T, nb, hd, hip.BF16, batch=BH, zdiv=H, alpha=alpha * _LOG2E)
         dqp = torch.empty(BH, T, nb, dtype=dtype, device=dev)
     hip.check(hip.lib().st5_flash_attn_bwd(_eptr(q), q[1], _eptr(k), k[1], _eptr(v), v[1], ctx.data_ptr(), d, dctx.data_ptr(), d,
                                            _eptr(dq), dq[1], _eptr(dk), dk[1], _eptr(dv), dv[1], lse.data_ptr(), dvec.data_ptr(),
