@@ -91,6 +91,26 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// GELU for the bf16 compute mode: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution) on
+// v_rcp / v_exp instead of the branchy libm erff -- the GEMM epilogues of fc1 are VALU-bound on this function.
+// g = gelu(x); when GRAD, g = d gelu / dx (shares the exp(-x^2/2) term).
+template <bool GRAD>
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float a = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(-a * a * 1.4426950408889634f);   // exp(-x^2 / 2)
+  const float erf_abs = fmaf(-poly, e, 1.0f);
+  const float erf_x = copysignf(erf_abs, x);
+  const float cdf = fmaf(0.5f, erf_x, 0.5f);
+  if (GRAD) return fmaf(x * 0.3989422804014327f, e, cdf);
+  return x * cdf;
+}
+
 #define ACT_NONE 0
 #define ACT_GELU 1
 #define ACT_RELU 2
@@ -98,9 +118,10 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 #define ACT_LRELU_01 4   // LeakyReLU(0.1)  (HiFi-GAN)
 #define ACT_LRELU_001 5  // LeakyReLU(0.01) (F.leaky_relu default)
 
+template <bool FAST = false>
 __device__ __forceinline__ float act_f(int act, float x) {
   switch (act) {
-    case ACT_GELU: return gelu_f(x);
+    case ACT_GELU: return FAST ? gelu_fast<false>(x) : gelu_f(x);
     case ACT_RELU: return x > 0.f ? x : 0.f;
     case ACT_TANH: return tanhf(x);
     case ACT_LRELU_01: return x > 0.f ? x : 0.1f * x;
@@ -109,9 +130,10 @@ __device__ __forceinline__ float act_f(int act, float x) {
   }
 }
 // derivative given the PRE-activation value
+template <bool FAST = false>
 __device__ __forceinline__ float act_grad_f(int act, float x) {
   switch (act) {
-    case ACT_GELU: return gelu_grad_f(x);
+    case ACT_GELU: return FAST ? gelu_fast<true>(x) : gelu_grad_f(x);
     case ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case ACT_TANH: { float t = tanhf(x); return 1.f - t * t; }
     case ACT_LRELU_01: return x > 0.f ? 1.f : 0.1f;
@@ -121,7 +143,7 @@ __device__ __forceinline__ float act_grad_f(int act, float x) {
 }
 
 // Counter-based RNG for dropout, two levels so that the per-element cost is a few VALU instructions:
-//   * every aligned block of 64 consecutive element indices gets a 32-bit key = fold(splitmix64(seed, idx >> 6));
+//   * every aligned block of 64 consecutive element indices gets a 32-bit key = mix(fold(splitmix64(seed)) ^ (idx >> 6));
 //   * every aligned PAIR of elements inside the block gets 32 bits = mix(key ^ pair * golden), 16 bits per
 //     element (two xorshift-multiply rounds with 24-bit multiplies); keep <=> u16 >= p * 65536.
 // The same (seed, idx) is re-evaluated by every kernel that needs the mask (GEMM epilogue, softmax, fused attention,
@@ -134,9 +156,16 @@ __device__ __forceinline__ unsigned long long rng_hash64(unsigned long long seed
   return z ^ (z >> 31);
 }
 __device__ __forceinline__ unsigned int dropout_thresh(float p) { return (unsigned int)(p * 65536.0f); }
+// 32-bit key of a 64-element block.  The seed part (splitmix64 of the seed, folded) is wave-uniform and loop-invariant,
+// so it is computed once on the scalar unit; the per-block part is one xorshift-multiply mixer on full-rate 24-bit
+// multiplies (different constants from the per-pair mixer below).
 __device__ __forceinline__ unsigned int drop_block_key(unsigned long long seed, unsigned long long block) {
-  const unsigned long long h = rng_hash64(seed, block);
-  return (unsigned int)h ^ (unsigned int)(h >> 32);
+  const unsigned long long h = rng_hash64(seed, 0ull);
+  unsigned int x = (unsigned int)block ^ (unsigned int)h ^ (unsigned int)(h >> 32) ^ __umul24((unsigned int)(block >> 32), 0x9E3779u);
+  x ^= x >> 15; x = __umul24(x, 0x9E3779u);
+  x ^= x >> 12; x = __umul24(x, 0x85EBCBu);
+  x ^= x >> 15;
+  return x;
 }
 // 2 x 16 random bits for elements (2*pair, 2*pair+1) of a block; pair in [0, 32)
 // pc = pair * 0x9E3779B1 (callers with a compile-time pair pass the product)

@@ -207,7 +207,7 @@ __device__ __forceinline__ void store_vec(U* p, bool full, int ne, const float (
 struct EpiArgs {  // everything the epilogue needs, by value
   void* C; const void* R; const void* P; void* Cpre; const float* bias;
   long long c_ld, c_bs, r_ld, r_bs, p_ld, p_bs, q_ld, q_bs;
-  int rpb, M, N, act, out_f32, dact, c_vec_ok, atomic;
+  int rpb, M, N, act, out_f32, dact, c_vec_ok, atomic, fast;
   float alpha, beta, dropout_p;
   unsigned long long seed, ctr_base;
 };
@@ -294,8 +294,115 @@ __device__ __forceinline__ void epilogue_rows(const EpiArgs& ea, const float* st
   }
 }
 
+
+// Fast epilogue of a wave's 64x64 tile for the common layout (every C-class operand dense-row: rpb == 0, 16-byte
+// aligned, N % 8 == 0 so a lane's 8 columns are all valid or all out of range).  Both 32-row halves are staged through the
+// wave-private LDS slab; the per-lane constants (bias, column offsets) are loaded once, the uniform feature tests are
+// per 8-vector, and the four row passes of a half are unrolled so their LDS reads / global loads overlap.
+template <typename T, typename OUT>
+__device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, const f32x16& acc00, const f32x16& acc01,
+                                              const f32x16& acc10, const f32x16& acc11, const int mbase, const int nbase,
+                                              const int lane) {
+  constexpr bool FASTACT = sizeof(T) == 2;   // bf16 compute mode
+  const int cc = (lane & 7) * 8, rsub = lane >> 3;
+  const int gn = nbase + cc;
+  const bool col_ok = gn < ea.N;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  if (ea.bias && col_ok) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(ea.bias + gn);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(ea.bias + gn + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+  }
+  const bool drop = ea.dropout_p > 0.f;
+  const unsigned int thresh = drop ? dropout_thresh(ea.dropout_p) : 0u;
+  const float inv_keep = drop ? 1.f / (1.f - ea.dropout_p) : 1.f;
+  OUT* const Cb = reinterpret_cast<OUT*>(ea.C) + gn;
+  const OUT* const Rb = ea.R ? reinterpret_cast<const OUT*>(ea.R) + gn : nullptr;
+  const T* const Pb = ea.P ? reinterpret_cast<const T*>(ea.P) + gn : nullptr;
+  T* const Qb = ea.Cpre ? reinterpret_cast<T*>(ea.Cpre) + gn : nullptr;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 0) stage_write(stage, acc00, acc01, lane);
+    else stage_write(stage, acc10, acc11, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (int pp = 0; pp < 2; ++pp) {   // two row passes at a time (keeps the register footprint of the epilogue small)
+      float v[2][8];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int row = (pp * 2 + k) * 8 + rsub;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + cc);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + cc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[k][e] = x0[e]; v[k][4 + e] = x1[e]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int gm = mbase + h * 32 + (pp * 2 + k) * 8 + rsub;
+        if (gm < ea.M && col_ok) {
+          float rv[8], pv[8], ov[8];
+          if (Rb) load8f<OUT>(Rb + (long long)gm * ea.r_ld, rv);
+          if (ea.dact) load8f<T>(Pb + (long long)gm * ea.p_ld, pv);
+          if (ea.beta != 0.f) load8f<OUT>(Cb + (long long)gm * ea.c_ld, ov);
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fmaf(v[k][e], ea.alpha, bias8[e]);
+          if (Qb) store8f<T>(Qb + (long long)gm * ea.q_ld, x);
+          if (ea.dact) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= act_grad_f<FASTACT>(ea.act, pv[e]);
+          } else if (ea.act != ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = act_f<FASTACT>(ea.act, x[e]);
+          }
+          if (drop) {
+            float dsc[8];
+            dropout_scale8(ea.seed, ea.ctr_base + (unsigned long long)gm * (unsigned long long)ea.N + gn, thresh, inv_keep, dsc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= dsc[e];
+          }
+          if (Rb) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += rv[e];
+          }
+          if (ea.beta != 0.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fmaf(ea.beta, ov[e], x[e]);
+          }
+          store8f<OUT>(Cb + (long long)gm * ea.c_ld, x);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab is rewritten by the next half
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void run_epilogue(const EpiArgs& ea, float* stage, const f32x16& acc00, const f32x16& acc01,
+                                             const f32x16& acc10, const f32x16& acc11, const int mbase, const int nbase,
+                                             const int lane) {
+  if (ea.fast) {
+    if (ea.out_f32) epilogue_fast<T, float>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
+    else epilogue_fast<T, T>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
+    return;
+  }
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (h == 0) stage_write(stage, acc00, acc01, lane);
+    else stage_write(stage, acc10, acc11, lane);
+    // the stage slab is private to this wave: order its LDS writes/reads inside the wave only.  (A block barrier here
+    // would also drain vmcnt, i.e. wait for the previous half's global stores.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    epilogue_rows<T>(ea, stage, mbase + h * 32, nbase, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 template <typename T, bool AKS, bool BKS>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const st5_gemm_params p, const int c_vec_ok) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const st5_gemm_params p, const int c_vec_ok) {
   constexpr int BK = 128 / (int)sizeof(T);
   typedef typename Frag<T>::type frag_t;
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
@@ -363,6 +470,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const st5_gemm_params p,
   ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
   ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
   ea.atomic = 0;
+  ea.fast = c_vec_ok && (p.N % 8 == 0) && !p.C.rpb;
   if (gridDim.y > 1) {  // split-K: each split writes its own fp32 slab (p.C describes slab 0, slabs are M*N apart)
     ea.C = reinterpret_cast<float*>(ea.C) + (long long)blockIdx.y * p.M * p.N;
   }
@@ -380,14 +488,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const st5_gemm_params p,
     if (ea.Cpre) ea.Cpre = reinterpret_cast<T*>(ea.Cpre) + z_off(p.Cpre.zs0, p.Cpre.zs1, z, p.zdiv);
   }
   float* stage = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    if (h == 0) stage_write(stage, acc00, acc01, lane);
-    else stage_write(stage, acc10, acc11, lane);
-    __syncthreads();
-    epilogue_rows<T>(ea, stage, m0 + wr * 64 + h * 32, n0 + wc * 64, lane);
-    __syncthreads();
-  }
+  run_epilogue<T>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 // C[m, n] = beta * C[m, n] + sum_s slab[s][m][n]   (slabs dense [M, N] fp32; C fp32 with row mapping)
@@ -457,8 +558,22 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 constexpr int GLDS_NBUF = 2;  // 64 KB LDS => two blocks per CU; 3- and 4-deep rings at one block per CU measured 10-25 % slower
 
+#ifndef GEMM_ABL
+#define GEMM_ABL 0
+#endif
+#ifdef GEMM_TIMING
+__device__ unsigned long long g_gemm_timing[8];
+#define GPROBE(i) do { __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += (unsigned int)(t_ - tprev); tprev = t_; } while (0)
+#else
+#define GPROBE(i)
+#endif
+
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
+#ifdef GEMM_TIMING
+  unsigned int tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int VEC = Elem<T>::VEC;
   constexpr int BK = 128 / (int)sizeof(T);
   typedef typename Frag<T>::type frag_t;
@@ -513,6 +628,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_glds_kernel(const st5_gemm_p
     if (t < nk) issue(t, t);
   const int frow = lane & 31, fhalf = lane >> 5;
   const int arow0 = wr * 64 + frow, brow0 = wc * 64 + frow;
+  GPROBE(0);
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed when at most the 8 loads of tile kt+1 are still outstanding
     {
@@ -524,7 +640,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_glds_kernel(const st5_gemm_p
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    GPROBE(1);
+#if GEMM_ABL != 2
     if (kt + GLDS_NBUF - 1 < nk) issue(kt + GLDS_NBUF - 1, (kt + GLDS_NBUF - 1) % GLDS_NBUF);
+#endif
     const char* cur = dsm + (kt % GLDS_NBUF) * 2 * TILE_BYTES;
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
@@ -532,10 +651,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_glds_kernel(const st5_gemm_p
       const frag_t a1 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0 + 32, kg * 2 + fhalf));
       const frag_t b0 = *reinterpret_cast<const frag_t*>(cur + TILE_BYTES + lds_off(brow0, kg * 2 + fhalf));
       const frag_t b1 = *reinterpret_cast<const frag_t*>(cur + TILE_BYTES + lds_off(brow0 + 32, kg * 2 + fhalf));
+#if GEMM_ABL == 3
+      asm volatile("" :: "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+#else
       mma<T>(a0, b0, acc00); mma<T>(a0, b1, acc01); mma<T>(a1, b0, acc10); mma<T>(a1, b1, acc11);
+#endif
     }
+    GPROBE(2);
   }
   __syncthreads();
+  GPROBE(3);
 
   EpiArgs ea;
   ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
@@ -545,6 +670,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_glds_kernel(const st5_gemm_p
   ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
   ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
   ea.atomic = 0;
+  ea.fast = c_vec_ok && (p.N % 8 == 0) && !p.C.rpb;
   ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
   ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
   {
@@ -558,15 +684,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_glds_kernel(const st5_gemm_p
     if (ea.Cpre) ea.Cpre = reinterpret_cast<T*>(ea.Cpre) + z_off(p.Cpre.zs0, p.Cpre.zs1, z, p.zdiv);
   }
   float* stage = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    if (h == 0) stage_write(stage, acc00, acc01, lane);
-    else stage_write(stage, acc10, acc11, lane);
-    __syncthreads();
-    epilogue_rows<T>(ea, stage, m0 + wr * 64 + h * 32, n0 + wc * 64, lane);
-    __syncthreads();
-  }
+#if GEMM_ABL == 1
+  asm volatile("" :: "v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
+  if (ea.alpha == 123.f)
+#endif
+  run_epilogue<T>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
+#ifdef GEMM_TIMING
+  GPROBE(4);
+  if (lane == 0) { for (int i = 0; i < 5; ++i) atomicAdd(&g_gemm_timing[i], (unsigned long long)tacc[i]); atomicAdd(&g_gemm_timing[7], 1ull); }
+#endif
 }
+
+#ifdef GEMM_TIMING
+}  // namespace
+extern "C" int st5_gemm_timing(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_timing), sizeof(g_gemm_timing)) != hipSuccess) return ST5_ERR_LAUNCH;
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_timing), z, sizeof(z)) != hipSuccess) return ST5_ERR_LAUNCH; }
+  return ST5_OK;
+}
+namespace {
+#endif
 
 template <typename T>
 int launch_glds(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {

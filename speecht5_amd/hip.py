@@ -14,7 +14,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_LRELU_01, ACT_LRELU_001 = 0, 1, 2, 3, 4, 5
 A_KSTRIDED, B_KSTRIDED, OUT_F32, DACT = 1, 2, 4, 8
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libspeecht5_hip.so")
+_LIB_PATH = os.environ.get("ST5_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libspeecht5_hip.so")
 
 
 class HipLibraryMissing(RuntimeError):

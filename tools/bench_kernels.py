@@ -46,6 +46,22 @@ if __name__ == "__main__":
                                   (127992, 512, 1536), (8192, 8192, 8192)):
                     gemm_case("NT", M, N, K, dtype, act=1)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "blas":
+        # reference point only: the library GEMM (hipBLASLt through torch.matmul) on the same shapes
+        dtype = torch.bfloat16
+        for (M, N, K) in ((3992, 2304, 768), (3992, 768, 768), (3992, 3072, 768), (3992, 768, 3072), (8192, 2304, 768), (8192, 768, 768),
+                          (8192, 3072, 768), (8192, 768, 3072), (5008, 768, 768), (5008, 1536, 768), (127992, 512, 1536), (63992, 512, 1536)):
+            gemm_case("NT  mine", M, N, K, dtype)
+            A = torch.randn(M, K, device=dev).to(dtype); B = torch.randn(N, K, device=dev).to(dtype)
+            t = timeit(lambda: torch.matmul(A, B.t()))
+            print(f"{'NT  hipblaslt':34s} M={M:6d} N={N:5d} K={K:6d} {'bfloat16':9s} {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TFLOP/s")
+        for (M, N, K) in ((768, 768, 3992), (2304, 768, 3992), (3072, 768, 3992), (768, 3072, 3992), (768, 768, 8192), (2304, 768, 8192),
+                          (3072, 768, 8192), (768, 3072, 8192), (512, 1536, 127992)):
+            gemm_case("TN  mine (f32 out)", M, N, K, dtype, aks=True, bks=True, out_f32=True)
+            A = torch.randn(K, M, device=dev).to(dtype); B = torch.randn(K, N, device=dev).to(dtype)
+            t = timeit(lambda: torch.matmul(A.t(), B))
+            print(f"{'TN  hipblaslt (bf16 out)':34s} M={M:6d} N={N:5d} K={K:6d} {'bfloat16':9s} {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TFLOP/s")
+        sys.exit(0)
     M = 8 * 499
     for dtype in (torch.bfloat16, torch.float32):
         gemm_case("qkv proj (NT)", M, 2304, 768, dtype)
