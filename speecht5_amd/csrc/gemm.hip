@@ -556,7 +556,10 @@ int launch(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-constexpr int GLDS_NBUF = 2;  // 64 KB LDS => two blocks per CU; 3- and 4-deep rings at one block per CU measured 10-25 % slower
+#ifndef GLDS_NBUF_V
+#define GLDS_NBUF_V 2
+#endif
+constexpr int GLDS_NBUF = GLDS_NBUF_V;  // 64 KB LDS => two blocks per CU; 3- and 4-deep rings at one block per CU measured 10-25 % slower
 
 #ifndef GEMM_ABL
 #define GEMM_ABL 0

@@ -117,6 +117,209 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
   store_row<T, NCH>(dx + row * cols, cols, lane, vec, gv);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Vector (cols % 4 == 0) LayerNorm kernels.  Lane l owns the 4-element vectors l, l+64, ... of a row (NV per lane),
+// so 768 columns split evenly over the wave (3 x 8-byte bf16 loads per lane and row, 512 contiguous bytes per wave
+// instruction).  A wave works on RPW rows at a time with all their loads issued before the first reduction, and loads
+// gamma/beta once.  Backward is one pass: dx plus per-lane dgamma/dbeta partial sums kept in registers across the
+// wave's rows, reduced over the block through LDS into a [blocks][2][cols] workspace; a tiny second kernel folds the
+// workspace into dgamma/dbeta (+=).
+// ------------------------------------------------------------------------------------------------
+constexpr int RPW = 4;          // rows per wave per iteration
+constexpr int LN_MAX_BLOCKS = 256;
+
+template <typename T> __device__ __forceinline__ void load4f(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4f<float>(const float* p, float (&v)[4]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = a[i];
+}
+template <> __device__ __forceinline__ void load4f<bf16_t>(const bf16_t* p, float (&v)[4]) {
+  const u32x2 a = *reinterpret_cast<const u32x2*>(p);
+  v[0] = __uint_as_float(a[0] << 16); v[1] = __uint_as_float(a[0] & 0xffff0000u);
+  v[2] = __uint_as_float(a[1] << 16); v[3] = __uint_as_float(a[1] & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4f(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4f<float>(float* p, const float (&v)[4]) {
+  f32x4 a;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = v[i];
+  *reinterpret_cast<f32x4*>(p) = a;
+}
+template <> __device__ __forceinline__ void store4f<bf16_t>(bf16_t* p, const float (&v)[4]) {
+  bf16x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (bf16_t)v[i];
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                                         long long rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= rows) return;
+  float v[RPW][NV][4];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const long long row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < cols) load4f<T>(x + row * cols + c, v[r][i]);
+      else { v[r][i][0] = v[r][i][1] = v[r][i][2] = v[r][i][3] = 0.f; }
+    }
+  }
+  float g[NV][4], b[NV][4];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) { load4f<float>(gamma + c, g[i]); load4f<float>(beta + c, b[i]); }
+    else { g[i][0] = g[i][1] = g[i][2] = g[i][3] = 0.f; b[i][0] = b[i][1] = b[i][2] = b[i][3] = 0.f; }
+  }
+  const float inv_n = 1.f / (float)cols;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += v[r][i][e];
+    const float mu = wave_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bool in = (i * 64 + lane) * 4 < cols;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = in ? v[r][i][e] - mu : 0.f; v[r][i][e] = d; q += d * d; }
+    }
+    const float rs = rsqrtf(wave_sum(q) * inv_n + eps);
+    if (row0 + r < rows) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaf(v[r][i][e] * rs, g[i][e], b[i][e]);
+          store4f<T>(y + (row0 + r) * cols + c, o);
+        }
+      }
+      if (lane == 0) { if (mean) mean[row0 + r] = mu; if (rstd) rstd[row0 + r] = rs; }
+    }
+  }
+}
+
+// dx (+ block partials of dgamma/dbeta when PG).  part: [gridDim.x][2][cols]
+template <typename T, int NV, bool PG>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, T* __restrict__ dx,
+                                                         float* __restrict__ part, long long rows, int cols) {
+  extern __shared__ float red[];   // PG: [4 waves][2][cols]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float g[NV][4], dg[NV][4], db[NV][4];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) load4f<float>(gamma + c, g[i]);
+    else { g[i][0] = g[i][1] = g[i][2] = g[i][3] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+  }
+  const float inv_n = 1.f / (float)cols;
+  for (long long row0 = ((long long)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * 4 * RPW) {
+    float xv[RPW][NV][4], gv[RPW][NV][4], mu[RPW], rs[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const long long row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) { load4f<T>(x + row * cols + c, xv[r][i]); load4f<T>(dy + row * cols + c, gv[r][i]); }
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xv[r][i][e] = 0.f; gv[r][i][e] = 0.f; }
+        }
+      }
+      mu[r] = mean[row]; rs[r] = rstd[row];
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const bool live = row0 + r < rows;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const bool in = (i * 64 + lane) * 4 < cols;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = in ? (xv[r][i][e] - mu[r]) * rs[r] : 0.f;
+          const float d = gv[r][i][e];
+          if (PG && live) { dg[i][e] = fmaf(d, xh, dg[i][e]); db[i][e] += d; }
+          const float gg = d * g[i][e];
+          xv[r][i][e] = xh; gv[r][i][e] = gg;
+          s1 += gg; s2 = fmaf(gg, xh, s2);
+        }
+      }
+      s1 = wave_sum(s1) * inv_n;
+      s2 = wave_sum(s2) * inv_n;
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int c = (i * 64 + lane) * 4;
+          if (c < cols) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rs[r] * (gv[r][i][e] - s1 - xv[r][i][e] * s2);
+            store4f<T>(dx + (row0 + r) * cols + c, o);
+          }
+        }
+      }
+    }
+  }
+  if (PG) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < cols) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[(wave * 2 + 0) * cols + c + e] = dg[i][e]; red[(wave * 2 + 1) * cols + c + e] = db[i][e]; }
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * cols; c += 256)
+      part[(long long)blockIdx.x * 2 * cols + c] = red[c] + red[2 * cols + c] + red[4 * cols + c] + red[6 * cols + c];
+  }
+}
+
+// dgamma[c] += sum_b part[b][0][c];  dbeta[c] += sum_b part[b][1][c]   (block = 64 columns x 16 partial-row lanes)
+__global__ __launch_bounds__(1024) void ln_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int nblk, int cols) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;     // index into [2][cols]
+  float s = 0.f;
+  if (c < 2 * cols)
+    for (int b = j; b < nblk; b += 16) s += part[(long long)b * 2 * cols + c];
+  red[j][cl] = s;
+  __syncthreads();
+  if (j == 0 && c < 2 * cols) {
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][cl];
+    if (c < cols) { if (dgamma) dgamma[c] += s; }
+    else if (dbeta) dbeta[c - cols] += s;
+  }
+}
+
+int ln_blocks(long long rows) {
+  long long n = (rows + 4 * RPW - 1) / (4 * RPW);
+  return (int)(n < LN_MAX_BLOCKS ? (n < 1 ? 1 : n) : LN_MAX_BLOCKS);
+}
+
 // ---- column reductions: out[c] (+)= scale * sum_r f(r, c) --------------------------------------
 // MODE 0: f = x            MODE 1: f = dy * (x - mean[r]) * rstd[r]   (LayerNorm dgamma)
 // Stage 1: grid (ceil(cols/256), nsplit), 256 threads = 32 column-groups(8 cols) x 8 row lanes.
@@ -257,6 +460,22 @@ extern "C" int st5_layernorm_fwd(const void* x, const float* gamma, const float*
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((rows + 3) / 4));
   if (dtype != ST5_BF16 && dtype != ST5_F32) return ST5_ERR_ARG;
+  if (cols % 4 == 0 && cols <= 2048) {   // vector kernels (every width of the model)
+    dim3 vgrid((unsigned)((rows + 4 * RPW - 1) / (4 * RPW)));
+#define LNV(TT, NV_)                                                                                                 \
+  hipLaunchKernelGGL((ln_fwd_vec_kernel<TT, NV_>), vgrid, dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, \
+                     (long long)rows, cols, eps)
+#define LNV_T(TT)                                                                                                     \
+  do {                                                                                                                \
+    if (cols <= 256) LNV(TT, 1); else if (cols <= 512) LNV(TT, 2); else if (cols <= 768) LNV(TT, 3);                  \
+    else if (cols <= 1024) LNV(TT, 4); else if (cols <= 1536) LNV(TT, 6); else LNV(TT, 8);                            \
+  } while (0)
+    if (dtype == ST5_BF16) LNV_T(bf16_t); else LNV_T(float);
+#undef LNV_T
+#undef LNV
+    HIP_CHECK_LAUNCH();
+    return ST5_OK;
+  }
 #define LNF(TT, NCH)                                                                                              \
   hipLaunchKernelGGL((ln_fwd_kernel<TT, NCH>), grid, dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, \
                      (long long)rows, cols, eps)
@@ -272,7 +491,9 @@ extern "C" int st5_layernorm_fwd(const void* x, const float* gamma, const float*
 }
 
 extern "C" int64_t st5_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols) {
-  return (int64_t)nsplit_for(rows) * cols * sizeof(float);
+  const int64_t a = (int64_t)nsplit_for(rows) * cols * sizeof(float);
+  const int64_t b = (int64_t)ln_blocks(rows) * 2 * cols * sizeof(float);
+  return a > b ? a : b;
 }
 
 extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
@@ -282,6 +503,30 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
   if ((dgamma || dbeta) && !ws) return ST5_ERR_ARG;
   if (rows == 0) return ST5_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype != ST5_BF16 && dtype != ST5_F32) return ST5_ERR_ARG;
+  if (dx && cols % 4 == 0 && cols <= 2048) {   // single-pass vector path
+    const int nb = ln_blocks(rows);
+    const bool pg = dgamma || dbeta;
+    const size_t shm = pg ? (size_t)8 * cols * sizeof(float) : 0;
+#define LBV(TT, NV_)                                                                                                    \
+  do {                                                                                                                  \
+    if (pg) hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, true>), dim3(nb), dim3(256), shm, s, (const TT*)dy, (const TT*)x, gamma, \
+                               mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols);                                 \
+    else hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, false>), dim3(nb), dim3(256), 0, s, (const TT*)dy, (const TT*)x, gamma, \
+                            mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols);                                    \
+  } while (0)
+#define LBV_T(TT)                                                                                                     \
+  do {                                                                                                                \
+    if (cols <= 256) LBV(TT, 1); else if (cols <= 512) LBV(TT, 2); else if (cols <= 768) LBV(TT, 3);                  \
+    else if (cols <= 1024) LBV(TT, 4); else if (cols <= 1536) LBV(TT, 6); else LBV(TT, 8);                            \
+  } while (0)
+    if (dtype == ST5_BF16) LBV_T(bf16_t); else LBV_T(float);
+#undef LBV_T
+#undef LBV
+    if (pg) hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((2 * cols + 63) / 64), dim3(1024), 0, s, (const float*)ws, dgamma, dbeta, nb, cols);
+    HIP_CHECK_LAUNCH();
+    return ST5_OK;
+  }
   // parameter gradients first (dx may alias dy)
   int rc = ST5_OK;
   if (dtype == ST5_BF16) {

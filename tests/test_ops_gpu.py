@@ -179,7 +179,7 @@ def test_gemm_dact_and_dropout(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,cols", [(37, 768), (130, 512), (9, 64), (5, 1024)])
+@pytest.mark.parametrize("rows,cols", [(37, 768), (130, 512), (9, 64), (5, 1024), (2100, 768), (11, 30), (6, 1536)])
 def test_layernorm(cuda, dtype, rows, cols):
     torch.manual_seed(rows)
     x = torch.randn(rows, cols) * 2 + 0.5
