@@ -729,6 +729,152 @@ bool g_use_glds = true;
 
 bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// ------------------------------------------------------------------------------------------------------
+// TN fast path (weight gradients: C[M,N] = A^T B with A = dY [K, M], B = X [K, N], the reduction index is the slow
+// one in memory for BOTH operands).  bf16 only.  The operand tiles are copied HBM -> LDS untransposed with LDS-DMA
+// ([64 k][128 m] per operand and k-tile, 16-byte chunks, chunk position XOR 4*(k&3)) and the MFMA fragments are
+// produced by the gfx950 transpose read ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 m] block (lane i loads
+// 4 m-consecutive bf16 of row k0 + (i>>2) at column 4*(i&3)) and every lane receives the 4 k-consecutive values of
+// its column -- two reads make the 8-deep k fragment of v_mfma_f32_32x32x16_bf16.  No register staging, no
+// register transposes (the register-staged gemm_kernel<.., true, true> needs 4x the load instructions and a
+// 4x4 shuffle per fragment).  Rows past K and columns past M/N read from a zero page.  Split-K as gemm_kernel.
+// ------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) char g_zero_page[256];
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile_row, int off0, int off1) {
+  // tile_row + off: this lane's 8-byte source for the two 4-row halves of the fragment
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile_row + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile_row + off1));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  typedef bf16_t T;
+  constexpr int BK = 64;
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int z = blockIdx.z;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
+    bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
+  const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
+
+  // split-K range
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int per = (nk_all + gridDim.y - 1) / gridDim.y;
+  const int kt0 = blockIdx.y * per;
+  const int nk = (kt0 + per <= nk_all ? per : nk_all - kt0) > 0 ? (kt0 + per <= nk_all ? per : nk_all - kt0) : 0;
+
+  // LDS-DMA sources: wave-instruction i of this wave covers tile rows (i*4 + wave)*4 .. +3; lane l -> row + (l>>4),
+  // physical chunk l&15, logical chunk (l&15) ^ 4*(l>>4)
+  const int lrow = lane >> 4;
+  const int lchunk = (lane & 15) ^ (4 * lrow);
+  const bool a_col_ok = m0 + lchunk * 8 < p.M, b_col_ok = n0 + lchunk * 8 < p.N;
+  const T* const zero = reinterpret_cast<const T*>(g_zero_page) + (lane & 15) * 8;
+  const T* abase = Ap + m0 + lchunk * 8;
+  const T* bbase = Bp + n0 + lchunk * 8;
+  auto issue = [&](int kt, int buf) {
+    char* base = dsm + buf * 2 * TILE_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kt * BK + (i * 4 + wave) * 4 + lrow;
+      const bool kin = k < p.K;
+      const T* sa = (kin && a_col_ok) ? abase + (long long)k * p.A.ld : zero;
+      const T* sb = (kin && b_col_ok) ? bbase + (long long)k * p.B.ld : zero;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sa, (lds_ptr_t)(base + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sb, (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+  if (nk > 0) issue(kt0, 0);
+  // transpose-read addressing of this lane: group (g = m sub-block of 16, h = k half), i = l&15 -> j = i>>2 (k row), q = i&3
+  const int g = (lane >> 4) & 1, h = lane >> 5, j = (lane & 15) >> 2, q = lane & 3;
+  // byte offset inside a tile for (k = 8h + j [+4 for the second read] [+16 per k-step], m = mbase + 16g + 4q)
+  auto frag_off = [&](int mbase) {
+    const int m = mbase + 16 * g + 4 * q;
+    const int pos = (m >> 3) ^ (4 * j);
+    return (8 * h + j) * 256 + pos * 16 + ((m >> 2) & 1) * 8;
+  };
+  const int oa0 = frag_off(wr * 64), oa1 = frag_off(wr * 64 + 32);
+  const int ob0 = frag_off(wc * 64), ob1 = frag_off(wc * 64 + 32);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt0 + kt + 1, (kt + 1) & 1);
+    const char* cur = dsm + (kt & 1) * 2 * TILE_BYTES;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const char* ta = cur + kg * 16 * 256;
+      const char* tb = ta + TILE_BYTES;
+      const bf16x8 a0 = tr_frag(ta, oa0, oa0 + 4 * 256);
+      const bf16x8 a1 = tr_frag(ta, oa1, oa1 + 4 * 256);
+      const bf16x8 b0 = tr_frag(tb, ob0, ob0 + 4 * 256);
+      const bf16x8 b1 = tr_frag(tb, ob1, ob1 + 4 * 256);
+      mma<T>(a0, b0, acc00); mma<T>(a0, b1, acc01); mma<T>(a1, b0, acc10); mma<T>(a1, b1, acc11);
+    }
+  }
+  __syncthreads();
+
+  EpiArgs ea;
+  ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
+  ea.bias = p.bias ? p.bias + (long long)z * p.bias_zs : nullptr;
+  ea.c_ld = p.C.ld; ea.c_bs = p.C.bstride; ea.r_ld = p.R.ld; ea.r_bs = p.R.bstride;
+  ea.p_ld = p.P.ld; ea.p_bs = p.P.bstride; ea.q_ld = p.Cpre.ld; ea.q_bs = p.Cpre.bstride;
+  ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
+  ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
+  ea.atomic = 0;
+  ea.fast = c_vec_ok && (p.N % 8 == 0) && !p.C.rpb;
+  if (gridDim.y > 1) ea.C = reinterpret_cast<float*>(ea.C) + (long long)blockIdx.y * p.M * p.N;
+  ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
+  ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
+  {
+    const long long zc = z_off(p.C.zs0, p.C.zs1, z, p.zdiv);
+    if (ea.out_f32) ea.C = reinterpret_cast<float*>(ea.C) + zc; else ea.C = reinterpret_cast<T*>(ea.C) + zc;
+    if (ea.R) {
+      const long long zr = z_off(p.R.zs0, p.R.zs1, z, p.zdiv);
+      if (ea.out_f32) ea.R = reinterpret_cast<const float*>(ea.R) + zr; else ea.R = reinterpret_cast<const T*>(ea.R) + zr;
+    }
+    if (ea.P) ea.P = reinterpret_cast<const T*>(ea.P) + z_off(p.P.zs0, p.P.zs1, z, p.zdiv);
+    if (ea.Cpre) ea.Cpre = reinterpret_cast<T*>(ea.Cpre) + z_off(p.Cpre.zs0, p.Cpre.zs1, z, p.zdiv);
+  }
+  float* stage = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
+  run_epilogue<T>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
+}
+
+int launch_tn_glds(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream_t s) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  dim3 grid(tiles, nsplit, p.batch), block(NTHREADS);
+  hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, block, (size_t)4 * TILE_BYTES, s, p, c_vec_ok);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+// operands the TN LDS-DMA kernel can take: bf16, both k-strided and dense (no row split / k segments), 16-byte
+// chunks along the contiguous index fully inside or outside the matrix
+bool tn_glds_ok(const st5_gemm_params& p, int dtype) {
+  if (dtype != ST5_BF16) return false;
+  if (!(p.flags & ST5_GEMM_A_KSTRIDED) || !(p.flags & ST5_GEMM_B_KSTRIDED)) return false;
+  if (p.A.rpb || p.B.rpb || p.A.seg || p.B.seg) return false;
+  if (p.M % 8 || p.N % 8 || p.A.ld % 8 || p.B.ld % 8 || p.A.zs0 % 8 || p.A.zs1 % 8 || p.B.zs0 % 8 || p.B.zs1 % 8) return false;
+  return aligned(p.A.ptr, 16) && aligned(p.B.ptr, 16);
+}
+
 }  // namespace
 
 extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
@@ -781,7 +927,8 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
     if (!slabs) return ST5_ERR_LAUNCH;
     st5_gemm_params q = p;
     q.C.ptr = slabs; q.C.ld = p.N; q.C.rpb = 0; q.C.bstride = 0; q.C.zs0 = q.C.zs1 = 0; q.beta = 0.f;
-    const int rc = dtype == ST5_BF16 ? launch<bf16_t>(q, 1, nsplit, s) : launch<float>(q, 1, nsplit, s);
+    const int rc = (g_use_glds && tn_glds_ok(q, dtype)) ? launch_tn_glds(q, 1, nsplit, s)
+                   : dtype == ST5_BF16 ? launch<bf16_t>(q, 1, nsplit, s) : launch<float>(q, 1, nsplit, s);
     if (rc) return rc;
     long long blocks = ((long long)p.M * p.N / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -796,6 +943,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   const int bk = 128 / es;
   if (g_use_glds && !(p.flags & (ST5_GEMM_A_KSTRIDED | ST5_GEMM_B_KSTRIDED)) && p.K % bk == 0 && p.K >= 2 * bk && !p.A.seg && !p.B.seg)
     return dtype == ST5_BF16 ? launch_glds<bf16_t>(p, c_vec_ok, s) : launch_glds<float>(p, c_vec_ok, s);
+  if (g_use_glds && tn_glds_ok(p, dtype)) return launch_tn_glds(p, c_vec_ok, nsplit, s);
   if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, nsplit, s);
   return launch<float>(p, c_vec_ok, nsplit, s);
 }

@@ -82,6 +82,27 @@ def test_gemm_transposed_layouts(cuda, dtype, aks, bks):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(768, 256, 5000), (136, 72, 8192), (264, 776, 130)])
+def test_gemm_weight_gradient_form(cuda, dtype, M, N, K):
+    """dW[M, N] (+)= dY^T X with both operands k-strided, fp32 accumulate output: the split-K path and, for bf16 with
+    8-aligned M / N, the LDS-DMA + transpose-read kernel (K tails, M/N tile tails)."""
+    torch.manual_seed(M + K)
+    dy, x = torch.randn(K, M), torch.randn(K, N) / math.sqrt(K)
+    ref = rt(dy, dtype).t() @ rt(x, dtype)
+    DY, X = dev(dy, dtype, cuda), dev(x, dtype, cuda)
+    C = torch.full((M, N), 2.0, dtype=torch.float32, device=cuda)
+    hip.gemm(hip.operand(DY, M), hip.operand(X, N), hip.operand(C, N), M, N, K, hip.dt(dtype),
+             flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0)
+    close(C, ref + 2.0, dtype, what="wgrad form")
+    # same operands as a batched product out of a wider buffer (leading dimensions larger than the matrix)
+    C2 = torch.zeros(M, N, dtype=dtype, device=cuda)
+    wide = torch.zeros(K, M + 8, dtype=dtype, device=cuda); wide[:, :M] = DY
+    hip.gemm(hip.operand(wide, M + 8), hip.operand(X, N), hip.operand(C2, N), M, N, K, hip.dt(dtype),
+             flags=hip.A_KSTRIDED | hip.B_KSTRIDED, bias=torch.ones(N, device=cuda))
+    close(C2, ref + 1.0, dtype, what="wgrad form, bf16 output + bias")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_batched_heads(cuda, dtype):
     """q.k^T per (batch, head) straight out of a fused [B*T, 3d] projection buffer."""
     torch.manual_seed(5)
