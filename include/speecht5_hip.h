@@ -69,6 +69,9 @@ typedef struct st5_gemm_params {
   float beta;       /* C = result + beta * C_old (0 => C_old not read) */
   float dropout_p;  /* dropout applied last (after act, before residual); 0 => off */
   uint64_t seed;    /* dropout RNG seed; element counter = z*M*N + row*N + col */
+  float* asum;      /* optional fp32 [M] (batch == 1): asum[m] += sum_k A(m, k).  With A = dY^T this is the bias gradient,
+                     * computed by the weight-gradient GEMM itself (one extra MFMA column in the first column of tiles)
+                     * instead of a separate reduction over dY (autograd of F.linear: grad_bias = dY.sum(0)). */
 } st5_gemm_params;
 
 /* Generic MFMA GEMM: C = drop(act(alpha * A.B^T + bias)) [* act'(P)] + R + beta*C.

@@ -186,6 +186,28 @@ __device__ __forceinline__ void mma<float>(const f32x4& a, const f32x4& b, f32x1
   for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], c, 0, 0, 0);
 }
 
+
+template <typename T> __device__ __forceinline__ typename Frag<T>::type ones_frag();
+template <> __device__ __forceinline__ bf16x8 ones_frag<bf16_t>() {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16_t)1.0f;
+  return o;
+}
+template <> __device__ __forceinline__ f32x4 ones_frag<float>() { f32x4 o = {1.f, 1.f, 1.f, 1.f}; return o; }
+
+// asum[m] += row sums held in column 0 of the two 32x32 "A x ones" accumulators of a wave (rows mbase .. mbase+63)
+__device__ __forceinline__ void flush_asum(float* asum, const f32x16& s0, const f32x16& s1, int mbase, int M, int lane) {
+  if ((lane & 31) != 0) return;
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (mbase + row < M) unsafeAtomicAdd(asum + mbase + row, s0[r]);
+    if (mbase + 32 + row < M) unsafeAtomicAdd(asum + mbase + 32 + row, s1[r]);
+  }
+}
+
 // predicated (static-index) tail accessors: arrays stay in registers
 template <typename U>
 __device__ __forceinline__ void load_vec(const U* p, bool full, int ne, float (&v)[8]) {
@@ -445,6 +467,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const st5_gemm_params
 
   const int frow = lane & 31, fhalf = lane >> 5;
   const int arow0 = wr * 64 + frow, brow0 = wc * 64 + frow;
+  const bool do_asum = p.asum != nullptr && tn == 0 && wc == 0;   // bias-gradient column: first column of tiles only
+  f32x16 sum0, sum1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sum0[r] = 0.f; sum1[r] = 0.f; }
   for (int kt = 0; kt < nk; ++kt) {
     const char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
     char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
@@ -456,10 +482,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const st5_gemm_params
       const frag_t b0 = *reinterpret_cast<const frag_t*>(cur + TILE_BYTES + lds_off(brow0, kg * 2 + fhalf));
       const frag_t b1 = *reinterpret_cast<const frag_t*>(cur + TILE_BYTES + lds_off(brow0 + 32, kg * 2 + fhalf));
       mma<T>(a0, b0, acc00); mma<T>(a0, b1, acc01); mma<T>(a1, b0, acc10); mma<T>(a1, b1, acc11);
+      if (do_asum) { mma<T>(a0, ones_frag<T>(), sum0); mma<T>(a1, ones_frag<T>(), sum1); }
     }
     if (kt + 1 < nk) { la.store(nxt); lb.store(nxt + TILE_BYTES); }
     __syncthreads();
   }
+  if (do_asum) flush_asum(p.asum, sum0, sum1, m0 + wr * 64, p.M, lane);
 
   // ------------------------------ epilogue ------------------------------
   EpiArgs ea;
@@ -813,6 +841,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   const int oa0 = frag_off(wr * 64), oa1 = frag_off(wr * 64 + 32);
   const int ob0 = frag_off(wc * 64), ob1 = frag_off(wc * 64 + 32);
 
+  const bool do_asum = p.asum != nullptr && tn == 0 && wc == 0;   // bias-gradient column: first column of tiles only
+  f32x16 sum0, sum1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sum0[r] = 0.f; sum1[r] = 0.f; }
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -827,9 +859,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
       const bf16x8 b0 = tr_frag(tb, ob0, ob0 + 4 * 256);
       const bf16x8 b1 = tr_frag(tb, ob1, ob1 + 4 * 256);
       mma<T>(a0, b0, acc00); mma<T>(a0, b1, acc01); mma<T>(a1, b0, acc10); mma<T>(a1, b1, acc11);
+      if (do_asum) { mma<T>(a0, ones_frag<T>(), sum0); mma<T>(a1, ones_frag<T>(), sum1); }
     }
   }
   __syncthreads();
+  if (do_asum) flush_asum(p.asum, sum0, sum1, m0 + wr * 64, p.M, lane);
 
   EpiArgs ea;
   ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
@@ -885,6 +919,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   if (p.batch <= 0) p.batch = 1;
   if (p.zdiv <= 0) p.zdiv = 1;
   if ((p.flags & ST5_GEMM_DACT) && !p.P.ptr) return ST5_ERR_ARG;
+  if (p.asum && p.batch > 1) return ST5_ERR_ARG;
   if (dtype != ST5_BF16 && dtype != ST5_F32) return ST5_ERR_ARG;
   const int es = dtype == ST5_BF16 ? 2 : 4;
   const int vec = 16 / es;
@@ -941,7 +976,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   // LDS-DMA pipelined fast path for the plain NT form (Linear / conv forward and, with cached transposed weights,
   // the data-gradient GEMMs)
   const int bk = 128 / es;
-  if (g_use_glds && !(p.flags & (ST5_GEMM_A_KSTRIDED | ST5_GEMM_B_KSTRIDED)) && p.K % bk == 0 && p.K >= 2 * bk && !p.A.seg && !p.B.seg)
+  if (g_use_glds && !p.asum && !(p.flags & (ST5_GEMM_A_KSTRIDED | ST5_GEMM_B_KSTRIDED)) && p.K % bk == 0 && p.K >= 2 * bk && !p.A.seg && !p.B.seg)
     return dtype == ST5_BF16 ? launch_glds<bf16_t>(p, c_vec_ok, s) : launch_glds<float>(p, c_vec_ok, s);
   if (g_use_glds && tn_glds_ok(p, dtype)) return launch_tn_glds(p, c_vec_ok, nsplit, s);
   if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, nsplit, s);

@@ -317,15 +317,19 @@ class LinearFunction(torch.autograd.Function):
         off = 0
         for i, w in enumerate(weights):
             n_i = w.shape[0]
+            b = biases[i]
+            want_db = b is not None and b.requires_grad
             if w.requires_grad:
                 gw = grad_buffer(w)
-                # dW_i += G[:, off:off+n_i]^T . X   (both operands k-strided, fp32 accumulate in place)
+                # dW_i += G[:, off:off+n_i]^T . X   (both operands k-strided, fp32 accumulate in place); the bias
+                # gradient db_i += colsum(G_i) rides along as one extra MFMA column of the same kernel
                 hip.gemm(hip.operand(g, ldn, off=off), hip.operand(x2, K), hip.operand(gw, K), n_i, K, M, _dt(dtype),
-                         flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0)
+                         flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0,
+                         asum=grad_buffer(b) if want_db else None)
                 _grad_done(w)
-            b = biases[i]
-            if b is not None and b.requires_grad:
+            elif want_db:
                 _colsum_into(g, ldn, n_i, grad_buffer(b), col_off=off)
+            if want_db:
                 _grad_done(b)
             off += n_i
         return (dx, d_res, None, None, None) + (None,) * (2 * len(weights))
@@ -386,10 +390,12 @@ class FFNFunction(torch.autograd.Function):
                  P=hip.operand(hpre, Fd), act=act, flags=hip.DACT, dropout_p=p_act, seed=s1)
         if w2.requires_grad:
             hip.gemm(hip.operand(g, dout), hip.operand(h, Fd), hip.operand(grad_buffer(w2), Fd), dout, Fd, M, _dt(dtype),
-                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0)
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0,
+                     asum=grad_buffer(b2) if b2.requires_grad else None)
             _grad_done(w2)
-        if b2.requires_grad:
+        elif b2.requires_grad:
             _colsum_into(g, dout, dout, grad_buffer(b2))
+        if b2.requires_grad:
             _grad_done(b2)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -399,10 +405,12 @@ class FFNFunction(torch.autograd.Function):
             dx = dx.view(xshape)
         if w1.requires_grad:
             hip.gemm(hip.operand(dh, Fd), hip.operand(x2, d), hip.operand(grad_buffer(w1), d), Fd, d, M, _dt(dtype),
-                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0)
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0,
+                     asum=grad_buffer(b1) if b1.requires_grad else None)
             _grad_done(w1)
-        if b1.requires_grad:
+        elif b1.requires_grad:
             _colsum_into(dh, Fd, Fd, grad_buffer(b1))
+        if b1.requires_grad:
             _grad_done(b1)
         return dx, d_res, None, None, None, None, None, None, None
 

@@ -35,7 +35,7 @@ class GemmParams(Structure):
                 ("bias", c_void_p), ("bias_zs", c_int64),
                 ("M", c_int32), ("N", c_int32), ("K", c_int32), ("batch", c_int32), ("zdiv", c_int32),
                 ("act", c_int32), ("flags", c_int32),
-                ("alpha", c_float), ("beta", c_float), ("dropout_p", c_float), ("seed", c_uint64)]
+                ("alpha", c_float), ("beta", c_float), ("dropout_p", c_float), ("seed", c_uint64), ("asum", c_void_p)]
 
 
 _SIGS = {
@@ -182,7 +182,7 @@ profiler = GemmProfiler()
 
 
 def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_zs=0, batch=1, zdiv=1, act=ACT_NONE,
-         flags=0, alpha=1.0, beta=0.0, dropout_p=0.0, seed=0):
+         flags=0, alpha=1.0, beta=0.0, dropout_p=0.0, seed=0, asum=None):
     p = GemmParams()
     p.A, p.B, p.C = A, B, C
     p.R = R if R is not None else _NULL_OP
@@ -193,6 +193,7 @@ def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_
     p.M, p.N, p.K, p.batch, p.zdiv = M, N, K, batch, zdiv
     p.act, p.flags = act, flags
     p.alpha, p.beta, p.dropout_p, p.seed = alpha, beta, dropout_p, seed
+    p.asum = ptr(asum)
     if profiler.enabled:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -94,6 +94,13 @@ def test_gemm_weight_gradient_form(cuda, dtype, M, N, K):
     hip.gemm(hip.operand(DY, M), hip.operand(X, N), hip.operand(C, N), M, N, K, hip.dt(dtype),
              flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0)
     close(C, ref + 2.0, dtype, what="wgrad form")
+    # bias gradient riding on the same kernel: asum[m] += sum_k dY[k, m]
+    C3 = torch.zeros(M, N, dtype=torch.float32, device=cuda)
+    db = torch.full((M,), 3.0, device=cuda)
+    hip.gemm(hip.operand(DY, M), hip.operand(X, N), hip.operand(C3, N), M, N, K, hip.dt(dtype),
+             flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, asum=db)
+    close(C3, ref, dtype, what="wgrad form with asum")
+    close(db - 3.0, rt(dy, dtype).sum(0), dtype, scale=math.sqrt(K), what="bias gradient (asum)")
     # same operands as a batched product out of a wider buffer (leading dimensions larger than the matrix)
     C2 = torch.zeros(M, N, dtype=dtype, device=cuda)
     wide = torch.zeros(K, M + 8, dtype=dtype, device=cuda); wide[:, :M] = DY
