@@ -143,9 +143,23 @@ def main():
     key = "bf16_NT" if a.dtype == "bf16" else "f32_NT"
     n, flops, secs = prof.get(key, (0, 0.0, 0.0))
     peak = BF16_DENSE_PEAK_TFLOPS if a.dtype == "bf16" else 157.3
-    roof = {"bound": "mfma", "kernel": f"gemm_kernel<{a.dtype}, NT> (Linear / conv / QK^T forward form)",
+    # measured HBM bytes per launch of the same kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
+    # (tools/pmc_traffic.sh), summary committed under profiles/ (the counters cannot be read from inside the process)
+    traffic = None
+    try:
+        import json as _json
+        pm = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")))
+        for kname, v in pm["kernels"].items():
+            if "gemm_nt_glds_kernel" in kname and a.dtype == "bf16":
+                traffic = v["hbm_corrected_bytes_per_launch"]
+    except Exception:
+        traffic = None
+    alg_bytes = hip.profiler.nt_bytes_per_launch() if hasattr(hip.profiler, "nt_bytes_per_launch") else None
+    roof = {"bound": "mfma", "kernel": f"gemm_nt_glds_kernel<{a.dtype}> (Linear / conv / attention-projection forward + data-gradient form)",
             "achieved": round(flops / secs / 1e12, 2) if secs > 0 else None, "peak": peak, "unit": "TFLOP/s",
-            "frac": round(flops / secs / 1e12 / peak, 4) if secs > 0 else None, "traffic": None,
+            "frac": round(flops / secs / 1e12 / peak, 4) if secs > 0 else None, "traffic": traffic,
+            "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)" if traffic else None,
+            "algorithmic_bytes_per_launch": alg_bytes,
             "launches_per_step": n, "sampled_steps": 1, "avg_launch_us": round(secs / max(n, 1) * 1e6, 2),
             "all_variants": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None,
                                  "ms_per_step": round(v[2] * 1e3, 3)} for k, v in sorted(prof.items())}}

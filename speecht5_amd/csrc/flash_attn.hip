@@ -238,7 +238,7 @@ __device__ __forceinline__ void build_qp_table(bf16_t* qp, int qp_ld, const bf16
 }
 
 template <bool BIAS>
-__global__ __launch_bounds__(256) void flash_fwd_kernel(const Args a) {
+__global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_fwd_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kbuf = smem;                 // 2 x 8 KB
   char* vbuf = smem + 2 * TILE_B;    // 2 x 8 KB
@@ -842,7 +842,7 @@ __device__ __forceinline__ void dkv_sub(f32x16& s, const f32x16& dp, f32x16& pd,
 }
 
 template <bool BIAS>
-__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_bwd_dkv_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kl = lane & 31, hi = lane >> 5;

@@ -169,6 +169,16 @@ class GemmProfiler:
         return out
 
 
+    def nt_bytes_per_launch(self, variant="bf16_NT"):
+        """Mean algorithmic HBM bytes (A + B read once, C written once) of the recorded launches of one variant."""
+        tot, n = 0, 0
+        es = 2 if variant.startswith("bf16") else 4
+        for v, _f, _e0, _e1, shape in self.records:
+            if v == variant:
+                M, N, K, b = shape
+                tot += b * (M * K + N * K + M * N) * es; n += 1
+        return int(tot / n) if n else None
+
     def by_shape(self):
         out = {}
         for variant, flops, e0, e1, shape in self.records:

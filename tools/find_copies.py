@@ -24,18 +24,15 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
 import collections
 agg = collections.defaultdict(lambda: [0, 0.0])
 for ev in prof.events():
-    if not ev.name.startswith("aten::"):
+    n = ev.name
+    if not (n.startswith("Memcpy") or n.startswith("Memset") or "hipMemcpy" in n or "hipMemset" in n):
         continue
-    dt = getattr(ev, "self_device_time_total", 0)
-    if dt <= 0:
-        continue
-    site = "?"
-    for fr in ev.stack or []:
-        if ("speecht5_amd" in fr or "bench.py" in fr) and "hip.py" not in fr:
-            site = fr.split("/root/repo/")[-1][:110]
-            break
-    agg[(ev.name, site)][0] += 1; agg[(ev.name, site)][1] += dt
-rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-print("total torch-op device time (us):", sum(v[1] for _, v in rows))
-for (name, site), (n, t) in rows[:60]:
-    print(f"{t:8.0f} us x{n:4d} {name:22s} {site}")
+    chain = []
+    par = ev.cpu_parent
+    while par is not None and len(chain) < 5:
+        chain.append(par.name[:50]); par = par.cpu_parent
+    key = (n[:40], " <- ".join(chain))
+    agg[key][0] += 1; agg[key][1] += getattr(ev, "self_device_time_total", 0) or ev.cpu_time_total
+rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
+for (name, chain), (n, t) in rows[:40]:
+    print(f"x{n:4d} {t:8.0f} us {name:40s} {chain}")
