@@ -85,8 +85,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("ST5_DDP_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
@@ -175,7 +176,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -41,6 +41,10 @@ class FlatGradDataParallel:
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # ST5_DDP_FORCE_COLLECTIVES=1 runs the bucketed async all-reduce path even in a 1-rank group (used to exercise the
+        # RCCL stream / event plumbing on a single-GPU box; a 1-rank all-reduce leaves the data unchanged)
+        import os
+        self.collectives = self.world > 1 or (os.environ.get("ST5_DDP_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
         params, seen = [], set()
         groups = bucket_groups if bucket_groups is not None else default_buckets(model)
         self.module_bucket = {}
@@ -77,12 +81,12 @@ class FlatGradDataParallel:
     # -- hooks -------------------------------------------------------------------------------------
     def _boundary(self, x, module):
         bi = self.module_bucket.get(id(module))
-        if bi is None or self.world == 1 or not x.requires_grad:
+        if bi is None or not self.collectives or not x.requires_grad:
             return x
         return _Trigger.apply(x, self, bi)
 
     def _bucket_ready(self, bi):
-        if self._launched[bi] is None and self.world > 1:
+        if self._launched[bi] is None and self.collectives:
             s, e = self.buckets[bi]
             self._launched[bi] = dist.all_reduce(self.flat[s:e], group=self.pg, async_op=True)
 
@@ -93,12 +97,13 @@ class FlatGradDataParallel:
 
     def finish(self):
         """Call after backward: reduce the remaining buckets, wait for all, average over ranks."""
-        if self.world > 1:
+        if self.collectives:
             for bi in range(len(self.buckets)):
                 self._bucket_ready(bi)
             for w in self._launched:
                 w.wait()
-            self.flat.mul_(1.0 / self.world)
+            if self.world > 1:
+                self.flat.mul_(1.0 / self.world)
         self._launched = [None] * len(self.buckets)
 
 
