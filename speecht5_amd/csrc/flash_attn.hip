@@ -18,6 +18,9 @@
 
 namespace {
 
+#ifndef FLASH_ABL
+#define FLASH_ABL 0
+#endif
 #ifdef FLASH_TIMING
 #define TPROBE(i) do { __builtin_amdgcn_s_waitcnt(0xC07F); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += (unsigned int)(t_ - tprev); tprev = t_; } while (0)
 #else
@@ -836,7 +839,9 @@ __device__ __forceinline__ void dkv_sub(f32x16& s, const f32x16& dp, f32x16& pd,
       bool st_ok = kvalid;
       if (SLOW) st_ok = st_ok && qq < a.T;
       if (BM == BM_GEN) st_ok = st_ok && d > -a.maxrel && d < a.maxrel - 1;
+#if FLASH_ABL != 1
       if (st_ok) dqpb[(unsigned int)(qq * (a.nb + 1) + (a.maxrel - ki))] = (bf16_t)ds;
+#endif
     }
   }
 }
@@ -898,6 +903,10 @@ __global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_bwd_dkv_kernel(const 
     st.store(smem + (qt0 & 1) * QBUF, tid);
   }
   __syncthreads();
+#ifdef FLASH_TIMING
+  unsigned int tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
   for (int qt = qt0; qt < nqt; ++qt) {
     const char* buf = smem + (qt & 1) * QBUF;
     const char* qtl = buf; const char* qtt = buf + TILE_B; const char* otl = buf + 2 * TILE_B; const char* ott = buf + 3 * TILE_B;
@@ -906,11 +915,12 @@ __global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_bwd_dkv_kernel(const 
     if (qt + 1 < nqt) st.load(a, bh, (qt + 1) * 64, kblk, tid);
     // whole-tile conditions (wave-uniform): key padding, causal boundary, rows past T
     const bool slow = any_kmasked || (a.causal && kw0 + 31 > qt * 64 + (a.S - a.T)) || qt * 64 + 64 > a.T;
+    TPROBE(0);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       if (BIAS) {   // fetch the next sub-tile's bias now; it is consumed one sub-tile later
         const int nn = 2 * qt + sub + 1;
-        if (nn < 2 * nqt) {
+        if (FLASH_ABL != 2 && nn < 2 * nqt) {
           if (sub_lin(nn)) load_bias_dkv<true>(bnext, qpb, nn * 32 + 4 * hi, ki, a.T, a.nb, a.maxrel);
           else load_bias_dkv<false>(bnext, qpb, nn * 32 + 4 * hi, ki, a.T, a.nb, a.maxrel);
         }
@@ -925,6 +935,7 @@ __global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_bwd_dkv_kernel(const 
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);    // S[q][key]
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ks], dp, 0, 0, 0);  // dP[q][key]
       }
+      TPROBE(1);
       f32x16 pd;
       const int qs0 = qt * 64 + sub * 32;           // first query of the sub-tile
       const int qbase = sub * 32 + 4 * hi, q0 = qs0 + 4 * hi;
@@ -945,6 +956,7 @@ __global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_bwd_dkv_kernel(const 
         else DKV_SUB(BM_GEN, false, false);
       }
 #undef DKV_SUB
+      TPROBE(2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) bcur[r] = bnext[r];
       // dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
@@ -958,10 +970,16 @@ __global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_bwd_dkv_kernel(const 
         dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_t8(qtt, kl, sstep, hi), df, dk0, 0, 0, 0);
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_t8(qtt, 32 + kl, sstep, hi), df, dk1, 0, 0, 0);
       }
+      TPROBE(3);
     }
     if (qt + 1 < nqt) st.store(smem + ((qt + 1) & 1) * QBUF, tid);
+    TPROBE(4);
     __syncthreads();
+    TPROBE(5);
   }
+#ifdef FLASH_TIMING
+  if (lane < 8) a.dvec[(long long)bh * a.T + kblk + wave_u * 32 + 8 + lane] = (float)tacc[lane];
+#endif
   if (kvalid) {
     bf16_t* krow = a.dk + ((long long)b * a.S + ki) * a.dk_ld + h * HD;
     bf16_t* vrow = a.dv + ((long long)b * a.S + ki) * a.dv_ld + h * HD;

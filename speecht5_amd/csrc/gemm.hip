@@ -14,7 +14,6 @@
 // bf16 uses v_mfma_f32_32x32x16_bf16; f32 uses v_mfma_f32_32x32x2_f32 (exact f32, parity mode).
 // The epilogue goes through LDS so that bias/activation/residual/dropout are applied on 8
 // consecutive columns per lane and stored as 16-byte vectors.
-#include <cstdlib>
 #include "common.h"
 #include "../../include/speecht5_hip.h"
 
@@ -738,133 +737,6 @@ namespace {
 #endif
 
 
-// ------------------------------------------------------------------------------------------------------
-// 256 x 128 block tile variant of the NT LDS-DMA kernel: 8 waves (4 x 2, each 64 x 64), NB-deep ring of 48 KB stages
-// (A 256 rows + B 128 rows of 128 B), one block per CU.  Per FLOP it pulls 25 % fewer bytes through L2 than the
-// 128 x 128 tile and with NB = 3 keeps two k-tiles of loads in flight across the barrier (counted vmcnt).
-// ------------------------------------------------------------------------------------------------------
-template <typename T, int NB>
-__global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const st5_gemm_params p, const int c_vec_ok) {
-  constexpr int VEC = Elem<T>::VEC;
-  constexpr int BK = 128 / (int)sizeof(T);
-  constexpr int BMB = 256;
-  constexpr int STAGE = 3 * TILE_BYTES;   // 32 KB A + 16 KB B
-  typedef typename Frag<T>::type frag_t;
-  extern __shared__ __attribute__((aligned(16))) char dsm[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int z = blockIdx.z;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
-    bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
-  }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
-  const int m0 = tm * BMB, n0 = tn * BN;
-  const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
-  const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
-  const OpAddr aa = make_addr(p.A.ld, p.A.bstride, 0, p.A.rpb, 0);
-  const OpAddr ab = make_addr(p.B.ld, p.B.bstride, 0, p.B.rpb, 0);
-
-  const T* asrc[4];
-  const T* bsrc[2];
-  const int rsub = lane >> 3, pc = lane & 7;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 8 + wave) * 8 + rsub;
-    const int c = pc ^ ((row >> 1) & 7);
-    int gr = m0 + row; gr = gr < p.M ? gr : p.M - 1;
-    asrc[i] = Ap + aa.outer(gr) + c * VEC;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (i * 8 + wave) * 8 + rsub;
-    const int c = pc ^ ((row >> 1) & 7);
-    int gc = n0 + row; gc = gc < p.N ? gc : p.N - 1;
-    bsrc[i] = Bp + ab.outer(gc) + c * VEC;
-  }
-  auto issue = [&](int kt, int buf) {
-    char* base = dsm + buf * STAGE + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[i] + (long long)kt * BK), (lds_ptr_t)(base + 2 * TILE_BYTES + i * 8192), 16, 0, 0);
-  };
-
-  f32x16 acc00, acc01, acc10, acc11;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
-
-  const int nk = p.K / BK;
-#pragma unroll
-  for (int t = 0; t < NB - 1; ++t)
-    if (t < nk) issue(t, t);
-  const int frow = lane & 31, fhalf = lane >> 5;
-  const int arow0 = wr * 64 + frow, brow0 = wc * 64 + frow;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed when at most the 6 loads of the next stage are still outstanding
-    if (NB >= 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + NB - 1 < nk) issue(kt + NB - 1, (kt + NB - 1) % NB);
-    const char* cur = dsm + (kt % NB) * STAGE;
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      const frag_t a0 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0, kg * 2 + fhalf));
-      const frag_t a1 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0 + 32, kg * 2 + fhalf));
-      const frag_t b0 = *reinterpret_cast<const frag_t*>(cur + 2 * TILE_BYTES + lds_off(brow0, kg * 2 + fhalf));
-      const frag_t b1 = *reinterpret_cast<const frag_t*>(cur + 2 * TILE_BYTES + lds_off(brow0 + 32, kg * 2 + fhalf));
-      mma<T>(a0, b0, acc00); mma<T>(a0, b1, acc01); mma<T>(a1, b0, acc10); mma<T>(a1, b1, acc11);
-    }
-  }
-  __syncthreads();
-
-  EpiArgs ea;
-  ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
-  ea.bias = p.bias ? p.bias + (long long)z * p.bias_zs : nullptr;
-  ea.c_ld = p.C.ld; ea.c_bs = p.C.bstride; ea.r_ld = p.R.ld; ea.r_bs = p.R.bstride;
-  ea.p_ld = p.P.ld; ea.p_bs = p.P.bstride; ea.q_ld = p.Cpre.ld; ea.q_bs = p.Cpre.bstride;
-  ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
-  ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
-  ea.atomic = 0;
-  ea.fast = c_vec_ok && (p.N % 8 == 0) && !p.C.rpb;
-  ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
-  ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
-  {
-    const long long zc = z_off(p.C.zs0, p.C.zs1, z, p.zdiv);
-    if (ea.out_f32) ea.C = reinterpret_cast<float*>(ea.C) + zc; else ea.C = reinterpret_cast<T*>(ea.C) + zc;
-    if (ea.R) {
-      const long long zr = z_off(p.R.zs0, p.R.zs1, z, p.zdiv);
-      if (ea.out_f32) ea.R = reinterpret_cast<const float*>(ea.R) + zr; else ea.R = reinterpret_cast<const T*>(ea.R) + zr;
-    }
-    if (ea.P) ea.P = reinterpret_cast<const T*>(ea.P) + z_off(p.P.zs0, p.P.zs1, z, p.zdiv);
-    if (ea.Cpre) ea.Cpre = reinterpret_cast<T*>(ea.Cpre) + z_off(p.Cpre.zs0, p.Cpre.zs1, z, p.zdiv);
-  }
-  float* stage = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
-  run_epilogue<T>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
-}
-
-int g_big_mode = -1;   // -1: read ST5_GEMM_BIG once; 0 off; 2 / 3: ring depth
-template <typename T>
-int launch_big(const st5_gemm_params& p, int c_vec_ok, int nb, hipStream_t s) {
-  const int tiles = ((p.M + 255) / 256) * ((p.N + BN - 1) / BN);
-  dim3 grid(tiles, 1, p.batch), block(512);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_big_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_nt_big_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return ST5_ERR_LAUNCH;
-    attr = true;
-  }
-  if (nb == 3) hipLaunchKernelGGL((gemm_nt_big_kernel<T, 3>), grid, block, (size_t)3 * 3 * TILE_BYTES, s, p, c_vec_ok);
-  else hipLaunchKernelGGL((gemm_nt_big_kernel<T, 2>), grid, block, (size_t)2 * 3 * TILE_BYTES, s, p, c_vec_ok);
-  HIP_CHECK_LAUNCH();
-  return ST5_OK;
-}
-
 template <typename T>
 int launch_glds(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -1106,11 +978,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   // the data-gradient GEMMs)
   const int bk = 128 / es;
   if (g_use_glds && !p.asum && !(p.flags & (ST5_GEMM_A_KSTRIDED | ST5_GEMM_B_KSTRIDED)) && p.K % bk == 0 && p.K >= 2 * bk && !p.A.seg && !p.B.seg)
-  {
-    if (g_big_mode < 0) { const char* e = getenv("ST5_GEMM_BIG"); g_big_mode = e ? atoi(e) : 0; }
-    if (g_big_mode >= 2 && dtype == ST5_BF16 && p.M >= 512) return launch_big<bf16_t>(p, c_vec_ok, g_big_mode, s);
     return dtype == ST5_BF16 ? launch_glds<bf16_t>(p, c_vec_ok, s) : launch_glds<float>(p, c_vec_ok, s);
-  }
   if (g_use_glds && tn_glds_ok(p, dtype)) return launch_tn_glds(p, c_vec_ok, nsplit, s);
   if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, nsplit, s);
   return launch<float>(p, c_vec_ok, nsplit, s);
