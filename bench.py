@@ -164,6 +164,12 @@ def main():
             "launches_per_step": n, "sampled_steps": 1, "avg_launch_us": round(secs / max(n, 1) * 1e6, 2),
             "all_variants": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None,
                                  "ms_per_step": round(v[2] * 1e3, 3)} for k, v in sorted(prof.items())}}
+    # HBM-bound leg ("HBM GB/s (conv frontend)"): conv layer 0 + GroupNorm + GELU, same HIP-event method
+    hbm = {}
+    for name, (n_, b_, t_) in sorted(hip.profiler.region_summary().items()):
+        hbm[name] = {"launches": n_, "algorithmic_MB": round(b_ / n_ / 1e6, 1), "achieved_GBps": round(b_ / t_ / 1e9, 1) if t_ > 0 else None,
+                     "frac_of_8TBps": round(b_ / t_ / 8e12, 4) if t_ > 0 else None}
+    roof["hbm_bound_kernels"] = hbm
     if rank == 0:
         out = {"metric": "audio-sec/s fwd+bwd SpeechT5-Base", "value": round(audio_seconds / dt, 2), "unit": "audio-sec/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),

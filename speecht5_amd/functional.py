@@ -951,9 +951,11 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
         stats = torch.empty(B, C0, 2, dtype=torch.float32, device=dev)
         wsb = hip.workspace(L.st5_conv0_ws_bytes(B, S, C0, k0, s0), dev)
         w0f = w0.detach().reshape(C0, k0).contiguous()
-        hip.check(L.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), y.data_ptr(),
-                                          stats.data_ptr(), wsb.data_ptr(), B, S, C0, k0, s0, 1e-5, _dt(dtype), hip.stream()),
-                  "st5_conv0_gn_gelu_fwd")
+        # algorithmic HBM bytes: waveform in (fp32) + channels-last output once
+        with hip.profiler.region("conv0_gn_gelu_fwd", B * S * 4 + B * L0 * C0 * y.element_size()):
+            hip.check(L.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), y.data_ptr(),
+                                              stats.data_ptr(), wsb.data_ptr(), B, S, C0, k0, s0, 1e-5, _dt(dtype), hip.stream()),
+                      "st5_conv0_gn_gelu_fwd")
         acts, pres, lens = [y], [None], [L0]
         x, Lin, Cin = y, L0, C0
         for i, (C, k, s) in enumerate(layers[1:]):
@@ -1055,10 +1057,12 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
         if need:
             wsb = hip.workspace(L.st5_conv0_ws_bytes(B, S, C0, k0, s0), dev)
             gw0 = grad_buffer(w0) if w0.requires_grad else None
-            hip.check(L.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), stats.data_ptr(),
-                                              dpre.data_ptr(), hip.ptr(gw0), hip.ptr(grad_buffer(gn_w)) if gn_w.requires_grad else 0,
-                                              hip.ptr(grad_buffer(gn_b)) if gn_b.requires_grad else 0, wsb.data_ptr(), B, S, C0, k0, s0,
-                                              1.0, _dt(dtype), hip.stream()), "st5_conv0_gn_gelu_bwd")
+            # algorithmic HBM bytes: waveform + ONE read of dY (the kernels read dY twice: GroupNorm sums, then dW)
+            with hip.profiler.region("conv0_gn_gelu_bwd", B * S * 4 + dpre.numel() * dpre.element_size()):
+                hip.check(L.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), stats.data_ptr(),
+                                                  dpre.data_ptr(), hip.ptr(gw0), hip.ptr(grad_buffer(gn_w)) if gn_w.requires_grad else 0,
+                                                  hip.ptr(grad_buffer(gn_b)) if gn_b.requires_grad else 0, wsb.data_ptr(), B, S, C0, k0, s0,
+                                                  1.0, _dt(dtype), hip.stream()), "st5_conv0_gn_gelu_bwd")
             for p in (w0, gn_w, gn_b):
                 if p.requires_grad:
                     _grad_done(p)

@@ -156,9 +156,36 @@ class GemmProfiler:
     def __init__(self):
         self.enabled = False
         self.records = []  # (variant, flops, start_event, end_event)
+        self.regions = []  # (name, algorithmic_bytes, start_event, end_event): HBM-bound kernels timed the same way
 
     def reset(self):
         self.records = []
+        self.regions = []
+
+    def region(self, name, nbytes):
+        """Context manager: HIP events around a launch sequence on the current stream (no-op unless enabled)."""
+        prof = self
+
+        class _R:
+            def __enter__(self_):
+                if prof.enabled:
+                    self_.e0 = torch.cuda.Event(enable_timing=True); self_.e1 = torch.cuda.Event(enable_timing=True)
+                    self_.e0.record()
+                return self_
+
+            def __exit__(self_, *exc):
+                if prof.enabled:
+                    self_.e1.record()
+                    prof.regions.append((name, float(nbytes), self_.e0, self_.e1))
+                return False
+        return _R()
+
+    def region_summary(self):
+        out = {}
+        for name, nbytes, e0, e1 in self.regions:
+            n, b, t = out.get(name, (0, 0.0, 0.0))
+            out[name] = (n + 1, b + nbytes, t + e0.elapsed_time(e1) * 1e-3)
+        return out
 
     def summary(self):
         """{variant: (launches, total_flops, total_seconds)} -- call after torch.cuda.synchronize()."""
