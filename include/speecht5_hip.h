@@ -180,6 +180,11 @@ int st5_embed_rows(const float* table, const int32_t* tok, const float* pos, con
 int st5_embed_rows_bwd(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, float scale,
                        int dtype, void* stream);
 /* zero-padded copy: dst [B, pad_l + T + pad_r, C] <- src [B, T, C] */
+/* out[(b,t), j] = wav[b, t*stride + j] (j < k), 0 (k <= j < kpad); out is [B*L, kpad] (dtype), L = (S-k)/stride + 1.
+ * Turns the Cin = 1 first convolution of the extractor_mode=layer_norm feature extractor
+ * (speech_encoder_prenet.py:300-318) into rows for st5_gemm. */
+int st5_unfold_rows(const float* wav, void* out, int32_t B, int32_t S, int32_t k, int32_t stride, int32_t kpad, int dtype,
+                    void* stream);
 int st5_pad_time(const void* src, void* dst, int32_t B, int32_t T, int32_t C, int32_t pad_l, int32_t pad_r,
                  int dtype, void* stream);
 

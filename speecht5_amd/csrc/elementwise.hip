@@ -282,6 +282,20 @@ float* scratch() {
   return g_scratch;
 }
 
+
+// out[(b, t), j] = wav[b, t*stride + j] for j < k, 0 for k <= j < kpad: the windows of a Cin = 1 convolution as GEMM rows
+template <typename T>
+__global__ void unfold_rows_kernel(const float* __restrict__ wav, T* __restrict__ out, int B, int S, int L, int k, int stride,
+                                   int kpad) {
+  const long long n = (long long)B * L * kpad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % kpad);
+    const long long row = i / kpad;
+    const int t = (int)(row % L), b = (int)(row / L);
+    out[i] = Elem<T>::from_f(j < k ? wav[(long long)b * S + (long long)t * stride + j] : 0.f);
+  }
+}
+
 }  // namespace
 
 #define DISPATCH(dtype, CALL_BF, CALL_F)   \
@@ -452,6 +466,17 @@ extern "C" int st5_pad_time(const void* src, void* dst, int32_t B, int32_t T, in
   dim3 grid((unsigned)((nrow + 3) / 4));
   DISPATCH(dtype, hipLaunchKernelGGL(pad_time_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, B, T, C, pad_l, pad_r),
            hipLaunchKernelGGL(pad_time_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, B, T, C, pad_l, pad_r));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_unfold_rows(const float* wav, void* out, int32_t B, int32_t S, int32_t k, int32_t stride, int32_t kpad,
+                               int dtype, void* stream) {
+  if (!wav || !out || B <= 0 || k < 1 || stride < 1 || kpad < k || S < k) return ST5_ERR_ARG;
+  const int L = (S - k) / stride + 1;
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)B * L * kpad;
+  DISPATCH(dtype, hipLaunchKernelGGL(unfold_rows_kernel<bf16_t>, grid_for(n), dim3(256), 0, s, wav, (bf16_t*)out, B, S, L, k, stride, kpad),
+           hipLaunchKernelGGL(unfold_rows_kernel<float>, grid_for(n), dim3(256), 0, s, wav, (float*)out, B, S, L, k, stride, kpad));
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

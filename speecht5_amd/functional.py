@@ -825,6 +825,38 @@ def masked_fill_rows(x, mask_bool, v):
     return MaskedFillRowsFunction.apply(x.contiguous(), mask_bool.to(torch.uint8).contiguous(), v)
 
 
+class ChannelMaskFunction(torch.autograd.Function):
+    """x[b, :, c] = 0 where the channel mask is set (apply_hubert_mask, speech_encoder_prenet.py:253-270): a per-clip
+    per-channel 0/1 scale applied with st5_channel_affine; the gradient is scaled the same way."""
+
+    @staticmethod
+    def _apply(x, keep):
+        B, T, C = x.shape
+        y = torch.empty_like(x)
+        zero = torch.zeros(C, dtype=torch.float32, device=x.device)
+        L = hip.lib()
+        for b in range(B):
+            hip.check(L.st5_channel_affine(x[b].data_ptr(), keep[b].data_ptr(), zero.data_ptr(), y[b].data_ptr(), T, C, ACT_NONE,
+                                           _dt(x), hip.stream()), "st5_channel_affine")
+        return y
+
+    @staticmethod
+    def forward(ctx, x, keep):
+        ctx.save_for_backward(keep)
+        return ChannelMaskFunction._apply(x, keep)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (keep,) = ctx.saved_tensors
+        return ChannelMaskFunction._apply(dy.contiguous(), keep), None
+
+
+def mask_channels(x, channel_mask_bool):
+    """x [B,T,C]; channel_mask_bool [B,C] (True = zero that channel for the whole clip)."""
+    keep = (~channel_mask_bool).to(torch.float32).contiguous()
+    return ChannelMaskFunction.apply(x.contiguous(), keep)
+
+
 class AddTableRowsFunction(torch.autograd.Function):
     """y[r] = x[r] + scale * table[idx[r]] with a constant fp32 table (sinusoidal positions)."""
 
@@ -1071,6 +1103,145 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
 
 def conv_feature_extractor(wav, layers, gscale, w0, gn_w, gn_b, ws):
     return ConvFeatureExtractorFunction.apply(wav, tuple(layers), float(gscale), w0, gn_w, gn_b, *ws)
+
+
+# -------------------------------------------------------------------------------------------------
+# extractor_mode=layer_norm (SpeechT5-Large recipe, speech_encoder_prenet.py:290-354): every block is
+# Conv1d(bias) -> LayerNorm over channels -> GELU.  Channels-last makes the LayerNorm a plain row LayerNorm; the
+# convolutions are differentiable autograd functions on the GEMM kernels, composed with layer_norm()/activation().
+# -------------------------------------------------------------------------------------------------
+class Conv0UnfoldFunction(torch.autograd.Function):
+    """Conv1d(1 -> C, k, stride, bias) on the waveform: windows unfolded to [B*L, 16] rows (st5_unfold_rows) x W^T."""
+
+    @staticmethod
+    def forward(ctx, wav, w, bias, k, stride):
+        dtype = _S.dtype
+        B, S = wav.shape
+        C = w.shape[0]
+        L0 = (S - k) // stride + 1
+        kpad = (k + 15) // 16 * 16
+        wav = wav.contiguous().float()
+        rows = torch.empty(B * L0, kpad, dtype=dtype, device=wav.device)
+        hip.check(hip.lib().st5_unfold_rows(wav.data_ptr(), rows.data_ptr(), B, S, k, stride, kpad, _dt(dtype), hip.stream()),
+                  "st5_unfold_rows")
+        wk = torch.zeros(C, kpad, dtype=torch.float32, device=wav.device)
+        wk[:, :k] = w.detach().reshape(C, k)
+        wk = wk.to(dtype)
+        y = torch.empty(B * L0, C, dtype=dtype, device=wav.device)
+        hip.gemm(hip.operand(rows, kpad), hip.operand(wk, kpad), hip.operand(y, C), B * L0, C, kpad, _dt(dtype),
+                 bias=bias.detach() if bias is not None else None)
+        ctx.save_for_backward(rows)
+        ctx.meta = (w, bias, k, kpad, B, L0, C)
+        return y.view(B, L0, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rows,) = ctx.saved_tensors
+        w, bias, k, kpad, B, L0, C = ctx.meta
+        g = dy.contiguous().view(B * L0, C)
+        if w.requires_grad:
+            tmp = torch.zeros(C, kpad, dtype=torch.float32, device=g.device)
+            want_db = bias is not None and bias.requires_grad
+            hip.gemm(hip.operand(g, C), hip.operand(rows, kpad), hip.operand(tmp, kpad), C, kpad, B * L0, _dt(g.dtype),
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, asum=grad_buffer(bias) if want_db else None)
+            grad_buffer(w).add_(tmp[:, :k].reshape(w.shape))
+            _grad_done(w)
+            if want_db:
+                _grad_done(bias)
+        elif bias is not None and bias.requires_grad:
+            _colsum_into(g, C, C, grad_buffer(bias))
+            _grad_done(bias)
+        return None, None, None, None, None
+
+
+class Conv1dStridedFunction(torch.autograd.Function):
+    """Channels-last Conv1d(Cin -> Cout, k in {2,3}, stride 2, bias) as an implicit GEMM (overlapping rows); the data
+    gradient is the transposed convolution split into its even / odd output phases (as in ConvFeatureExtractorFunction)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, k, s):
+        dtype = x.dtype
+        B, Lin, Cin = x.shape
+        Cout = w.shape[0]
+        Lo = (Lin - k) // s + 1
+        x = x.contiguous()
+        Wk = _conv_w_fwd(w, dtype)
+        y = torch.empty(B, Lo, Cout, dtype=dtype, device=x.device)
+        hip.gemm(hip.operand(x, s * Cin, rpb=Lo, bstride=Lin * Cin), hip.operand(Wk, k * Cin), hip.operand(y, Cout),
+                 B * Lo, Cout, k * Cin, _dt(dtype), bias=bias.detach() if bias is not None else None)
+        ctx.save_for_backward(x)
+        ctx.meta = (w, bias, k, s, B, Lin, Cin, Cout, Lo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, bias, k, s, B, Lin, Cin, Cout, Lo = ctx.meta
+        dtype, dev = dy.dtype, dy.device
+        dpre = torch.zeros(B, Lo + 2, Cout, dtype=dtype, device=dev)   # one zero row each side (k = 3 even phase)
+        dpre[:, 1:-1] = dy
+        ioff = Cout
+        want_db = bias is not None and bias.requires_grad
+        if w.requires_grad:
+            tmpw = torch.empty(Cout, k * Cin, dtype=torch.float32, device=dev)
+            hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout),
+                     hip.operand(x, s * Cin, rpb=Lo, bstride=Lin * Cin), hip.operand(tmpw, k * Cin),
+                     Cout, k * Cin, B * Lo, _dt(dtype), flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
+            grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))
+            _grad_done(w)
+        if want_db:
+            _colsum_into(dy.contiguous().view(B * Lo, Cout), Cout, Cout, grad_buffer(bias))
+            _grad_done(bias)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros(B, Lin, Cin, dtype=dtype, device=dev)
+            Wk = _conv_w_fwd(w, dtype)
+            if k == 2 and s == 2:
+                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wk, k * Cin),
+                         hip.operand(dx, 2 * Cin, rpb=Lo, bstride=Lin * Cin), B * Lo, 2 * Cin, Cout, _dt(dtype),
+                         flags=hip.B_KSTRIDED)
+            elif k == 3 and s == 2:
+                We, Wo = _conv_w_even_odd(w, dtype)
+                hip.gemm(hip.operand(dpre, Cout, rpb=Lo + 1, bstride=(Lo + 2) * Cout), hip.operand(We, Cin),
+                         hip.operand(dx, 2 * Cin, rpb=Lo + 1, bstride=Lin * Cin), B * (Lo + 1), Cin, 2 * Cout, _dt(dtype),
+                         flags=hip.B_KSTRIDED)
+                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wo, Cin),
+                         hip.operand(dx, 2 * Cin, off=Cin, rpb=Lo, bstride=Lin * Cin), B * Lo, Cin, Cout, _dt(dtype),
+                         flags=hip.B_KSTRIDED)
+            else:
+                raise NotImplementedError(f"conv feature layer (k={k}, stride={s}) backward")
+        return dx, None, None, None, None
+
+
+def conv_feature_extractor_layer_norm(wav, layers, gscale, params):
+    """params[i] = (conv_weight, conv_bias or None, ln_weight, ln_bias); returns channels-last features [B,T,C]."""
+    x = None
+    for i, (dim, k, s) in enumerate(layers):
+        w, b, lw, lb = params[i]
+        if i == 0:
+            x = Conv0UnfoldFunction.apply(wav, w, b, k, s)
+        else:
+            x = Conv1dStridedFunction.apply(x, w, b, k, s)
+        x = activation(layer_norm(x, lw, lb), ACT_GELU)
+    if gscale != 1.0:
+        x = GradScaleFunction.apply(x, float(gscale))
+    return x
+
+
+class GradScaleFunction(torch.autograd.Function):
+    """fairseq GradMultiply (speech_encoder_prenet.py:158-160): identity forward, gradient scaled."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = dy.contiguous()
+        out = torch.empty_like(g)
+        hip.check(hip.lib().st5_axpby(g.data_ptr(), out.data_ptr(), g.numel(), ctx.scale, 0.0, _dt(g), hip.stream()), "st5_axpby")
+        return out, None
 
 
 # -------------------------------------------------------------------------------------------------

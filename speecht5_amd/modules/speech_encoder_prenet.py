@@ -19,15 +19,21 @@ class ConvFeatureExtractionModel(nn.Module):
     def __init__(self, conv_layers, dropout=0.0, mode="default", conv_bias=False):
         super().__init__()
         assert mode in {"default", "layer_norm"}
-        if mode != "default" or conv_bias or dropout != 0.0:
-            raise NotImplementedError("only extractor_mode=default without conv bias/dropout has HIP kernels (Base configs)")
+        if dropout != 0.0:
+            raise NotImplementedError("feature-extractor dropout != 0 is used by no SpeechT5 recipe and has no HIP path")
+        if mode == "default" and conv_bias:
+            raise NotImplementedError("extractor_mode=default with conv bias is used by no SpeechT5 recipe")
+        self.mode = mode
         self.conv_layers = nn.ModuleList()
         self.conv_layers_infos = conv_layers
         in_d = 1
         for i, (dim, k, stride) in enumerate(conv_layers):
-            conv = nn.Conv1d(in_d, dim, k, stride=stride, bias=False)
+            conv = nn.Conv1d(in_d, dim, k, stride=stride, bias=conv_bias)
             nn.init.kaiming_normal_(conv.weight)
-            if i == 0:
+            if mode == "layer_norm":   # parameter names of the reference: conv_layers.{i}.0.*, conv_layers.{i}.2.1.*
+                block = nn.Sequential(conv, nn.Dropout(p=dropout),
+                                      nn.Sequential(nn.Identity(), nn.LayerNorm(dim, elementwise_affine=True), nn.Identity()), nn.GELU())
+            elif i == 0:
                 block = nn.Sequential(conv, nn.Dropout(p=dropout), nn.GroupNorm(dim, dim, affine=True), nn.GELU())
             else:
                 block = nn.Sequential(conv, nn.Dropout(p=dropout), nn.GELU())
@@ -36,6 +42,9 @@ class ConvFeatureExtractionModel(nn.Module):
 
     def forward(self, x, grad_scale=1.0):
         """x: waveform [B, S] fp32 -> features [B, T, C] (channels-last, compute dtype)."""
+        if self.mode == "layer_norm":
+            params = [(blk[0].weight, blk[0].bias, blk[2][1].weight, blk[2][1].bias) for blk in self.conv_layers]
+            return Fn.conv_feature_extractor_layer_norm(x.float(), self.conv_layers_infos, grad_scale, params)
         l0 = self.conv_layers[0]
         ws = [blk[0].weight for blk in list(self.conv_layers)[1:]]
         return Fn.conv_feature_extractor(x.float(), self.conv_layers_infos, grad_scale, l0[0].weight, l0[2].weight, l0[2].bias, ws)
@@ -195,7 +204,11 @@ class SpeechEncoderPrenet(nn.Module):
             mask_indices = pre_mask if pre_mask is not None else self._sample_mask(B, T, padding_mask.cpu(), x.device)
             x = Fn.masked_fill_rows(x, mask_indices.reshape(-1), self.mask_emb)
         if self.mask_channel_prob > 0:
-            raise NotImplementedError("channel masking (ASR fine-tuning regulariser) has no HIP kernel yet")
+            # same numpy draw as the reference (speech_encoder_prenet.py:253-263), taken right after the time mask
+            mc = compute_mask_indices((B, C), None, self.mask_channel_prob, self.mask_channel_length, self.mask_channel_selection,
+                                      self.mask_channel_other, no_overlap=self.no_mask_channel_overlap,
+                                      min_space=self.mask_channel_min_space)
+            x = Fn.mask_channels(x, torch.from_numpy(mc).to(x.device, non_blocking=True))
         return x, mask_indices
 
     def set_num_updates(self, num_updates):

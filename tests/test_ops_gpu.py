@@ -422,3 +422,21 @@ def test_elementwise_and_losses(cuda, dtype):
     close(loss, ref.view(1), dtype, what="ce loss")
     (0.5 * ref).backward()
     close(DL[:, :V], lr.grad, dtype, scale=1.0, what="ce grad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_channel_mask(cuda, dtype):
+    """apply_hubert_mask's channel masking (speech_encoder_prenet.py:253-270): x[b, :, c] = 0, gradient likewise."""
+    from speecht5_amd import functional as Fn
+    torch.manual_seed(23)
+    B, T, C = 3, 17, 64
+    x = torch.randn(B, T, C)
+    m = torch.rand(B, C) < 0.3
+    X = dev(x, dtype, cuda).requires_grad_(True)
+    old = Fn.get_compute_dtype() if hasattr(Fn, "get_compute_dtype") else None
+    y = Fn.mask_channels(X, m.to(cuda))
+    ref = rt(x, dtype).masked_fill(m.unsqueeze(1).expand(-1, T, -1), 0.0)
+    close(y, ref, dtype, what="channel mask fwd")
+    g = torch.randn(B, T, C)
+    y.backward(dev(g, dtype, cuda))
+    close(X.grad, rt(g, dtype).masked_fill(m.unsqueeze(1).expand(-1, T, -1), 0.0), dtype, what="channel mask bwd")
