@@ -9,6 +9,11 @@ from .encoder import RelativePositionalEncoding
 from .transformer_layer import TransformerDecoderLayer
 
 
+def state_B(state, rows):
+    """Batch size of a cached [B*S, C] row tensor (S is recorded when the encoder rows are first cached)."""
+    return rows.shape[0] // state["S"]
+
+
 class TransformerDecoder(FairseqIncrementalDecoder):
     def __init__(self, args, no_encoder_attn=False):
         self.args = args
@@ -45,11 +50,15 @@ class TransformerDecoder(FairseqIncrementalDecoder):
 
     def extract_features_scriptable(self, prev_output_tokens, tgt_mask, encoder_out, incremental_state=None,
                                     full_context_alignment=False, alignment_layer=None, alignment_heads=None):
-        """prev_output_tokens: decoder pre-net output [B,T,C].  With `incremental_state` the whole prefix is
-        expected (the pre-nets hand it over) and recomputed: numerically the reference's KV-cache path."""
+        """prev_output_tokens: decoder pre-net output [B,T,C].  With `incremental_state` (inference) the pre-nets hand over
+        the NEWEST position only (T = 1, as in the reference) and every layer keeps its projected keys/values in the state
+        dict (multihead_attention.py:269-307 of the reference), so a step costs O(prefix) instead of O(prefix^2)."""
         B, T, C = prev_output_tokens.shape
         if alignment_layer is None:
             alignment_layer = self.num_layers - 1
+        if incremental_state is not None and not self.training:
+            return self._extract_features_incremental(prev_output_tokens, tgt_mask, encoder_out, incremental_state,
+                                                      alignment_layer, alignment_heads)
         enc_rows, S, enc_pad = None, None, None
         if encoder_out is not None and len(encoder_out["encoder_out"]) > 0:
             enc = encoder_out["encoder_out"][0]  # T x B x C
@@ -80,8 +89,61 @@ class TransformerDecoder(FairseqIncrementalDecoder):
         x = x.view(B, T, C)
         return x, {"attn": [attn if len(attn_list) <= 1 else attn_list], "inner_states": inner_states}
 
+    _CACHE_KEY = "st5_decoder_kv_cache"
+
+    @torch.no_grad()
+    def _extract_features_incremental(self, prev_output_tokens, tgt_mask, encoder_out, incremental_state, alignment_layer,
+                                      alignment_heads):
+        B, T, C = prev_output_tokens.shape
+        state = incremental_state.setdefault(self._CACHE_KEY, {"layers": [dict() for _ in self.layers]})
+        enc_rows, S, enc_pad = None, None, None
+        if encoder_out is not None and len(encoder_out["encoder_out"]) > 0:
+            enc = encoder_out["encoder_out"][0]  # T x B x C
+            assert enc.size(1) == B, f"Expected enc.shape == (t, {B}, c) got {enc.shape}"
+            S = enc.size(0)
+            if "enc_rows" not in state:
+                state["enc_rows"] = Fn.as_compute(enc.transpose(0, 1).contiguous()).view(B * S, -1)
+                state["S"] = S
+            enc_rows = state["enc_rows"]
+        if encoder_out is not None and len(encoder_out["encoder_padding_mask"]) > 0:
+            enc_pad = encoder_out["encoder_padding_mask"][0]
+        x_all = Fn.as_compute(prev_output_tokens.contiguous())
+        attn_list, attn, inner_states = [], None, []
+        x = None
+        for t in range(T):   # T == 1 in the generator loop; a longer first chunk is fed position by position
+            x = x_all[:, t].contiguous()
+            inner_states = [x.view(B, 1, C).transpose(0, 1)]
+            attn_list, attn = [], None
+            for idx, layer in enumerate(self.layers):
+                want = bool(idx == alignment_layer or alignment_layer == -1)
+                x, layer_attn = layer.forward_rows_cached(x, B, state["layers"][idx], enc_rows, S, enc_pad, tgt_mask, want)
+                inner_states.append(x.view(B, 1, C).transpose(0, 1))
+                if layer_attn is not None and want:
+                    attn = layer_attn.transpose(0, 1)       # [H,B,1,S]
+                    attn_list.append(layer_attn)             # [B,H,1,S]
+        if attn is not None and len(attn_list) == 1:
+            if alignment_heads is not None:
+                attn = attn[:alignment_heads]
+            attn = attn.mean(dim=0)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        return x.view(B, 1, C), {"attn": [attn if len(attn_list) <= 1 else attn_list], "inner_states": inner_states}
+
     def reorder_incremental_state_scripting(self, incremental_state, new_order):
-        return incremental_state  # the prefix is recomputed each step: nothing is cached
+        """Beam search re-ordering (decoder.py:301-314 of the reference): every cached tensor is batch-major."""
+        state = incremental_state.get(self._CACHE_KEY) if incremental_state is not None else None
+        if state is None:
+            return incremental_state
+        for lc in state["layers"]:
+            if "kv" in lc.get("self", {}):
+                lc["self"]["kv"] = lc["self"]["kv"].index_select(0, new_order)
+            if "kvp" in lc.get("cross", {}):
+                kvp = lc["cross"]["kvp"]
+                lc["cross"]["kvp"] = kvp.view(state_B(state, kvp), -1, kvp.shape[1]).index_select(0, new_order).reshape(-1, kvp.shape[1])
+        if "enc_rows" in state:
+            er = state["enc_rows"]
+            state["enc_rows"] = er.view(state_B(state, er), -1, er.shape[1]).index_select(0, new_order).reshape(-1, er.shape[1])
+        return incremental_state
 
     def set_num_updates(self, num_updates):
         def _apply(m):

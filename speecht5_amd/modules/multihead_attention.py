@@ -83,6 +83,30 @@ class MultiheadAttention(nn.Module, IncrementalState):
                         dropout_p=out_dropout if self.training else 0.0)
         return out, probs
 
+    # ---- incremental decoding (multihead_attention.py:269-307 of the reference: saved_state prev_key / prev_value) ----
+    @torch.no_grad()
+    def forward_rows_cached(self, x, B, cache, *, kv=None, S=None, key_padding_mask=None, residual=None, need_weights=False):
+        """One new position per sequence: x [B, C] rows.  Self-attention appends this step's (k, v) to cache["kv"]
+        ([B, t, 2C], projected) and attends over all t cached keys; cross-attention projects the encoder rows once
+        (cache["kvp"], [B*S, 2C]) and re-uses them every step.  Returns (out rows [B, C], probs [B,H,1,S] or None)."""
+        H, hd, C = self.num_heads, self.head_dim, self.embed_dim
+        kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
+        if kv is None:
+            qkv = Fn.linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight],
+                            [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias])          # [B, 3C]
+            q = qkv[:, :C].contiguous()
+            step = qkv[:, C:].reshape(B, 1, 2 * C)
+            cache["kv"] = step.contiguous() if "kv" not in cache else torch.cat([cache["kv"], step], dim=1)
+            t = cache["kv"].shape[1]
+            ctx, probs = Fn.CrossAttentionFunction.apply(q, cache["kv"].view(B * t, 2 * C), kpm, (B, H, 1, t, hd, 0.0, need_weights))
+        else:
+            if "kvp" not in cache:
+                cache["kvp"] = Fn.linear(kv, [self.k_proj.weight, self.v_proj.weight], [self.k_proj.bias, self.v_proj.bias])
+            q = Fn.linear(x, self.q_proj.weight, self.q_proj.bias)
+            ctx, probs = Fn.CrossAttentionFunction.apply(q, cache["kvp"], kpm, (B, H, 1, S, hd, 0.0, need_weights))
+        out = Fn.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual)
+        return out, probs
+
     # ---- reference-compatible Time x Batch x Channel interface ----
     def forward(self, query, key, value, key_padding_mask=None, incremental_state=None, need_weights=True,
                 static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False, position_bias=None):

@@ -32,12 +32,14 @@ class TextDecoderPrenet(nn.Module):
             return self._forward(prev_output_tokens, incremental_state)
 
     def _forward(self, prev_output_tokens, incremental_state=None):
-        """With an incremental state the reference embeds only the last token (:102-105); this mirror always
-        embeds the whole prefix and the decoder recomputes it (identical outputs for the last position)."""
+        """With an incremental state (inference) only the newest token is embedded (:102-105 of the reference); the padding
+        mask still covers the whole prefix, it is the key mask of the cached self-attention."""
         pad = prev_output_tokens.eq(self.padding_idx)
         x_mask = pad  # the reference returns None when nothing is padded (a host sync); an all-False mask is equivalent
         positions = self.embed_positions.positions(~pad)
         table = self.embed_positions.table(prev_output_tokens.shape[1] + self.padding_idx + 2, prev_output_tokens.device)
+        if incremental_state is not None and not self.training:
+            prev_output_tokens, positions = prev_output_tokens[:, -1:], positions[:, -1:]
         x = Fn.embed_rows(self.embed_tokens.weight, prev_output_tokens, pos=table, pidx=positions, emb_scale=self.embed_scale)
         x = Fn.dropout(x, self.dropout, self.training)
         return x, x_mask, incremental_state

@@ -118,6 +118,29 @@ class TransformerDecoderLayer(nn.Module):
                 x = self.final_layer_norm(x)
         return x, attn
 
+    @torch.no_grad()
+    def forward_rows_cached(self, x, B, cache, enc_rows, S, enc_padding_mask, self_padding_mask, need_attn):
+        """Incremental step (transformer_layer.py:262-404 with incremental_state): x [B, C] = the newest position only;
+        `cache` = {"self": {...}, "cross": {...}} of this layer.  Returns (rows [B, C], cross-attn probs [B,H,1,S] or None)."""
+        nb = self.normalize_before
+        h = self.self_attn_layer_norm(x) if nb else x
+        x, _ = self.self_attn.forward_rows_cached(h, B, cache.setdefault("self", {}), key_padding_mask=self_padding_mask, residual=x)
+        if not nb:
+            x = self.self_attn_layer_norm(x)
+        attn = None
+        if self.encoder_attn is not None and enc_rows is not None:
+            h = self.encoder_attn_layer_norm(x) if nb else x
+            x, attn = self.encoder_attn.forward_rows_cached(h, B, cache.setdefault("cross", {}), kv=enc_rows, S=S,
+                                                            key_padding_mask=enc_padding_mask, residual=x,
+                                                            need_weights=need_attn or self.need_attn)
+            if not nb:
+                x = self.encoder_attn_layer_norm(x)
+        h = self.final_layer_norm(x) if nb else x
+        x = Fn.ffn(h, x, self.fc1, self.fc2, self.act, 0.0, 0.0)
+        if not nb:
+            x = self.final_layer_norm(x)
+        return x, attn
+
     def forward(self, x, encoder_out=None, encoder_padding_mask=None, incremental_state=None, prev_self_attn_state=None,
                 prev_attn_state=None, self_attn_mask=None, self_attn_padding_mask=None, need_attn=False,
                 need_head_weights=False, pos_bias=None):

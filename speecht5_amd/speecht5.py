@@ -281,8 +281,8 @@ class T5TransformerModel(FairseqEncoderDecoderModel):
         return self.encoder(encoder_input, encoder_padding_mask)
 
     def forward_decoder(self, tokens, encoder_out, incremental_state):
-        """`tokens` is the whole prefix (as fairseq's SequenceGenerator passes it); the prefix is recomputed and,
-        like the reference's incremental path, only the last position is returned when a state dict is given."""
+        """`tokens` is the whole prefix (as fairseq's SequenceGenerator passes it).  With a state dict (inference) only
+        the newest token is embedded and run through the decoder, whose layers keep their keys/values in the state."""
         prev_output_tokens, tgt_mask, incremental_state = self.text_decoder_prenet(tokens, incremental_state)
         decoder_output, extra = self.decoder(prev_output_tokens, tgt_mask, encoder_out=encoder_out,
                                              incremental_state=incremental_state)
@@ -318,10 +318,11 @@ class T5TransformerModel(FairseqEncoderDecoderModel):
         ys = encoder_out["encoder_out"][0].new_zeros(1, 1, odim, dtype=torch.float32)
         outs, probs, attns = [], [], []
         post = self.speech_decoder_postnet
+        incremental_states = {}
         while True:
             idx += 1
             decoder_in, _ = self.speech_decoder_prenet(ys, spkembs=spkembs)
-            z, extra = self.decoder(decoder_in, None, encoder_out, None, alignment_layer=-1)
+            z, extra = self.decoder(decoder_in[:, -1:], None, encoder_out, incremental_states, alignment_layer=-1)
             zl = Fn.as_compute(z[:, -1:].contiguous())
             both = Fn.as_float(Fn.linear(zl, [post.feat_out.weight, post.prob_out.weight], [post.feat_out.bias, post.prob_out.bias]))
             nf = post.feat_out.weight.shape[0]

@@ -97,8 +97,9 @@ def test_s2t_fp32_matches_reference_and_greedy_ids_bit_exact(cuda):
         B = ni["source"].shape[0]
         tokens = torch.full((B, 1), 2, dtype=torch.long, device=cuda)
         done = torch.zeros(B, dtype=torch.bool, device=cuda)
+        inc = {}   # one incremental state for the whole decode (KV cache), as fairseq's SequenceGenerator keeps it
         for step in range(fx["max_len"]):
-            out, _ = model.forward_decoder(tokens, enc, {})
+            out, _ = model.forward_decoder(tokens, enc, inc)
             lp = torch.log_softmax(out[:, -1].float(), -1)
             for f in fx["forbid"]:
                 lp[:, f] = -float("inf")
@@ -112,6 +113,18 @@ def test_s2t_fp32_matches_reference_and_greedy_ids_bit_exact(cuda):
             if bool(done.all()):
                 break
     assert tokens[:, 1:].cpu().tolist() == fx["greedy_tokens"].tolist()  # bit-exact token ids (BASELINE.json)
+    # the KV-cache path reproduces the full (teacher-forced) forward position by position, and survives a beam re-order
+    with torch.no_grad():
+        prev = ni["prev_output_tokens"]
+        full, _ = model.forward_decoder(prev, enc, None)
+        inc = {}
+        for t in range(prev.shape[1]):
+            step_out, _ = model.forward_decoder(prev[:, : t + 1], enc, inc)
+            close(step_out[:, 0], full[:, t], 2e-4, what=f"cached step {t}")
+            if t == 2:   # swap the two hypotheses' caches and swap them back: a no-op overall
+                order = torch.tensor([1, 0], device=cuda)
+                model.decoder.reorder_incremental_state_scripting(inc, order)
+                model.decoder.reorder_incremental_state_scripting(inc, order)
 
 
 def test_t2s_fp32_matches_reference_and_generated_mel(cuda):
