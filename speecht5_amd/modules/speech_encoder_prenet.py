@@ -157,7 +157,11 @@ class SpeechEncoderPrenet(nn.Module):
             mask_indices = None
         if self.use_conv_pos:
             conv = self.pos_conv[0]
-            w = torch._weight_norm(conv.weight_v, conv.weight_g, 2)  # g * v / ||v||  (parameter glue, 4.7 M elements)
+            # weight_norm(dim=2): w = g * v / ||v||, the norm over (out, in) per tap.  Written as a reduction + one
+            # broadcast multiply: torch._weight_norm's dim=2 kernels need 0.75 ms fwd+bwd for this 4.7 M-element
+            # parameter on MI355X, this form 0.17 ms
+            v = conv.weight_v
+            w = v * (conv.weight_g / torch.linalg.vector_norm(v, dim=(0, 1), keepdim=True))
             x = Fn.pos_conv(x, w, conv.bias, self.conv_pos_groups)
         if self.use_sinc_pos:
             positions = self.embed_positions.positions(~encoder_padding_mask)
