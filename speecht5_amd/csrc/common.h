@@ -72,10 +72,20 @@ __device__ __forceinline__ void store8f<bf16_t>(bf16_t* p, const float (&v)[8]) 
   *reinterpret_cast<bf16x8*>(p) = o;
 }
 
+// Wave64 sum on the DPP cross-lane paths (row_shr within 16-lane rows, then row_bcast:15 / row_bcast:31): six VALU
+// instructions and one readlane, no LDS-crossbar (ds_bpermute) round trips as the __shfl_xor butterfly needs.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  int x = __float_as_int(v);
+#define ST5_DPP_ADD(ctrl, row_mask, bank_mask) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, bank_mask, false)); x = __float_as_int(v)
+  ST5_DPP_ADD(0x111, 0xf, 0xf);   // row_shr:1
+  ST5_DPP_ADD(0x112, 0xf, 0xf);   // row_shr:2
+  ST5_DPP_ADD(0x114, 0xf, 0xe);   // row_shr:4
+  ST5_DPP_ADD(0x118, 0xf, 0xc);   // row_shr:8  -> lane 15 of every row holds the row sum
+  ST5_DPP_ADD(0x142, 0xa, 0xf);   // row_bcast:15 -> rows 1 and 3 add the previous row's total
+  ST5_DPP_ADD(0x143, 0xc, 0xf);   // row_bcast:31 -> lane 63 holds the wave total
+#undef ST5_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

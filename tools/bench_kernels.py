@@ -83,6 +83,14 @@ if __name__ == "__main__":
         mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
         t = timeit(lambda: L.st5_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, cols, 1e-5, hip.dt(dtype), hip.stream()))
         print(f"layernorm fwd {rows}x{cols}: {t*1e6:.1f} us  {2*rows*cols*2/t/1e9:.0f} GB/s")
+        for rows2 in (3992, 8192):
+            x2 = torch.randn(rows2, cols, device=dev).to(dtype); dy2 = torch.randn_like(x2); dx2 = torch.empty_like(x2)
+            mean2 = torch.zeros(rows2, device=dev); rstd2 = torch.ones(rows2, device=dev)
+            dg = torch.zeros(cols, device=dev); db = torch.zeros(cols, device=dev)
+            ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows2, cols), dev)
+            t = timeit(lambda: L.st5_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), g.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), dx2.data_ptr(),
+                                                   dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows2, cols, hip.dt(dtype), hip.stream()))
+            print(f"layernorm bwd (dx + dgamma/dbeta) {rows2}x{cols}: {t*1e6:.1f} us  {3*rows2*cols*2/t/1e9:.0f} GB/s")
         BH, T = 96, 499; lds = 504
         sc = torch.randn(BH, T, lds, device=dev).to(dtype); qp = torch.randn(BH, T, 320, device=dev).to(dtype)
         P = torch.empty_like(sc)
