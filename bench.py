@@ -21,6 +21,10 @@ import sys
 import time
 from argparse import Namespace
 
+# kernel arguments in device memory: ~3 us less launch latency per kernel on MI300-class parts, ~3000 launches per step
+# (must be in the environment before the HIP runtime initialises)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import torch
 import torch.distributed as dist
 

@@ -125,7 +125,14 @@ def dt(t):
     raise TypeError(f"unsupported dtype {t}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device.  Called once per kernel launch (~3000 per training
+    step): the raw C getter costs ~0.3 us, `torch.cuda.current_stream().cuda_stream` ~3 us."""
+    if _raw_stream is not None:
+        return _raw_stream(torch._C._cuda_getDevice())
     return torch.cuda.current_stream().cuda_stream
 
 

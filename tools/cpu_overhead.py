@@ -30,4 +30,5 @@ print("enqueue ms per step:", [round(e * 1e3, 1) for e in enq])
 print(f"mean enqueue {t_enq/n*1e3:.1f} ms/step, synchronized wall {t_all/n*1e3:.1f} ms/step")
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); step(0); pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(25)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
+st.sort_stats("cumulative").print_stats(45)
