@@ -200,7 +200,14 @@ int st5_cross_entropy(const void* logits, const int32_t* target, float* loss_sum
  * One fused pass over the flat fp32 buffers: g' = g * grad_scale * min(1, max_norm / (sqrt(*gnorm_sq) * grad_scale));
  * m,v update; p = p*(1 - lr*wd) - lr/bc1 * m / (sqrt(v/bc2) + eps).  gnorm_sq is a DEVICE scalar (may be NULL). */
 int st5_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale, void* stream);
+                  float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
+                  void* bf16_mirror /* optional bf16 [n]: receives the updated parameters in the compute dtype */, void* stream);
+/* Batched bf16 matrix transposes in one launch.  jobs_dev: device array of {int64 src_off, int64 dst_off, int32 rows,
+ * int32 cols, int32 tile0, int32 pad} sorted by tile0 (first 64x64 tile index of the job), offsets in elements into
+ * src_flat / dst_flat; ntiles = total tile count.  Used for the transposed weight copies of the data-gradient GEMMs
+ * (dX = dY.W as an NT product), refreshed once per optimizer step. */
+int st5_multi_transpose_bf16(const void* src_flat, void* dst_flat, const void* jobs_dev, int32_t njobs, int32_t ntiles,
+                             void* stream);
 
 const char* st5_version(void);
 

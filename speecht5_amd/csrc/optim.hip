@@ -8,7 +8,8 @@
 
 namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16_t* __restrict__ mirror, long long n,
                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
                                                    float bc2, const float* __restrict__ gnorm_sq, float max_norm,
                                                    float gscale) {
@@ -37,6 +38,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     reinterpret_cast<f32x4*>(p)[i] = pp;
     reinterpret_cast<f32x4*>(m)[i] = mm;
     reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (mirror) {   // compute-dtype copy of the updated parameters (the next forward's weights: no cast kernels)
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)pp[e];
+      reinterpret_cast<bf16x4*>(mirror)[i] = o;
+    }
   }
   for (long long i = nv * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
@@ -45,21 +52,59 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float vi = b2 * v[i] + (1.f - b2) * ge * ge;
     m[i] = mi; v[i] = vi;
     p[i] = p[i] * (1.f - lr * wd) - step * mi / (sqrtf(vi) * inv_bc2 + eps);
+    if (mirror) mirror[i] = (bf16_t)p[i];
+  }
+}
+
+// Batched bf16 transposes: job j turns src[j] ([rows, cols], row-major) into dst[j] ([cols, rows]).  One launch per
+// optimizer step for every transposed weight copy the data-gradient GEMMs use (instead of one launch per weight).
+struct TrJob { long long src, dst; int rows, cols, tile0, pad; };   // element offsets into the two flat buffers
+__global__ __launch_bounds__(256) void multi_transpose_kernel(const bf16_t* __restrict__ sflat, bf16_t* __restrict__ dflat,
+                                                              const TrJob* __restrict__ jobs, int njobs) {
+  __shared__ bf16_t tile[64][66];
+  // find the job of this 64x64 tile (jobs are sorted by tile0; njobs is a few hundred: binary search)
+  int lo = 0, hi = njobs - 1;
+  const int t = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].tile0 <= t) lo = mid; else hi = mid - 1; }
+  const TrJob jb = jobs[lo];
+  const int tc = (jb.cols + 63) / 64;
+  const int lt = t - jb.tile0, r0 = (lt / tc) * 64, c0 = (lt % tc) * 64;
+  const bf16_t* src = sflat + jb.src;
+  bf16_t* dst = dflat + jb.dst;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int j = ty; j < 64; j += 4) {
+    const int r = r0 + j, c = c0 + tx;
+    if (r < jb.rows && c < jb.cols) tile[j][tx] = src[(long long)r * jb.cols + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4) {
+    const int c = c0 + j, r = r0 + tx;
+    if (r < jb.rows && c < jb.cols) dst[(long long)c * jb.rows + r] = tile[tx][j];
   }
 }
 }  // namespace
 
 extern "C" int st5_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int32_t step, const float* gnorm_sq,
-                             float max_norm, float grad_scale, void* stream) {
+                             float max_norm, float grad_scale, void* bf16_mirror, void* stream) {
   if (!p || !g || !m || !v || n < 0 || step < 1) return ST5_ERR_ARG;
   if (n == 0) return ST5_OK;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)bf16_mirror,
+                     (long long)n,
                      lr, beta1, beta2, eps, weight_decay, bc1, bc2, gnorm_sq, max_norm, grad_scale);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+extern "C" int st5_multi_transpose_bf16(const void* src_flat, void* dst_flat, const void* jobs_dev, int32_t njobs,
+                                        int32_t ntiles, void* stream) {
+  if (!src_flat || !dst_flat || !jobs_dev || njobs <= 0 || ntiles <= 0) return ST5_ERR_ARG;
+  hipLaunchKernelGGL(multi_transpose_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src_flat,
+                     (bf16_t*)dst_flat, (const TrJob*)jobs_dev, njobs);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

@@ -52,7 +52,7 @@ class FlatGradDataParallel:
         for bi, mods in enumerate(groups):
             for m in mods:
                 self.module_bucket[id(m)] = bi
-                for p in m.parameters():
+                for p in _fusion_ordered_parameters(m):
                     if id(p) not in seen and p.requires_grad:
                         seen.add(id(p))
                         order.append((bi, p))
@@ -62,19 +62,27 @@ class FlatGradDataParallel:
                 seen.add(id(p))
                 order.append((nb, p))
         order.sort(key=lambda t: t[0])
-        total = sum(p.numel() for _, p in order)
+        # matrices start on 8-element boundaries (16-byte rows in the bf16 parameter image the GEMM loaders read);
+        # the few padding elements stay zero in the gradient / optimizer buffers
+        offs, off = [], 0
+        for _, p in order:
+            if p.dim() >= 2:
+                off = (off + 7) // 8 * 8
+            offs.append(off)
+            off += p.numel()
+        total = (off + 7) // 8 * 8
         dev = order[0][1].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.buckets = []  # (start, end)
-        off, cur, start = 0, order[0][0], 0
-        for bi, p in order:
+        cur, start = order[0][0], 0
+        for (bi, p), o in zip(order, offs):
             if bi != cur:
-                self.buckets.append((start, off))
-                start, cur = off, bi
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        self.buckets.append((start, off))
+                self.buckets.append((start, o))
+                start, cur = o, bi
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        self.buckets.append((start, total))
         self.params = [p for _, p in order]
+        self.offsets = offs
         self._launched = [None] * len(self.buckets)
         Fn.set_layer_boundary_hook(self._boundary)
 
@@ -107,6 +115,37 @@ class FlatGradDataParallel:
         self._launched = [None] * len(self.buckets)
 
 
+def _fusion_ordered_parameters(module):
+    """module.parameters() with the projections an attention block fuses into one GEMM made ADJACENT, in the order they are
+    stacked ([Wq; Wk; Wv] / [Wk; Wv] and their biases), so that the optimizer's bf16 parameter image holds the stacked
+    weight as one contiguous matrix (functional.bf16_mirror) and their gradients are one contiguous block too."""
+    from .modules.multihead_attention import MultiheadAttention
+    params = list(module.parameters())
+    pos = {id(p): i for i, p in enumerate(params)}
+    groups = []
+    for m in module.modules():
+        if isinstance(m, MultiheadAttention):
+            projs = [m.q_proj, m.k_proj, m.v_proj] if m.self_attention else [m.k_proj, m.v_proj]
+            groups.append([q.weight for q in projs])
+            if all(q.bias is not None for q in projs):
+                groups.append([q.bias for q in projs])
+    out, done = [], set()
+    head = {id(g[0]): g for g in groups}
+    member = {id(p) for g in groups for p in g[1:]}
+    for p in params:
+        if id(p) in done or id(p) in member:
+            continue
+        if id(p) in head:
+            for q in head[id(p)]:
+                out.append(q); done.add(id(q))
+        else:
+            out.append(p); done.add(id(p))
+    for p in params:   # members whose head was not in this module's list (cannot happen for whole attention blocks)
+        if id(p) not in done:
+            out.append(p); done.add(id(p))
+    return out
+
+
 def default_buckets(model):
     """Backward-completion order of a T5TransformerModel: post-nets + NCE head + quantizer, decoder layers (last
     first), decoder pre-nets, encoder layers (last first), encoder pre-nets.  The remaining parameters (layer-less
@@ -137,13 +176,22 @@ class FusedAdam:
         self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip_norm
         total = ddp.flat.numel()
         dev = ddp.flat.device
-        self.pflat = torch.empty(total, dtype=torch.float32, device=dev)
-        off = 0
-        for p in ddp.params:
+        self.pflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        offsets = list(ddp.offsets)
+        for p, off in zip(ddp.params, offsets):
             n = p.numel()
             self.pflat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.pflat[off:off + n].view_as(p)
-            off += n
+        # bf16 image of the parameters, written by the Adam kernel itself (no per-weight cast launches), plus a pool for
+        # the transposed copies of the >= 2-D ones (refreshed by one batched transpose per step)
+        self.mirror = None
+        if dev.type == "cuda" and Fn._S.dtype == torch.bfloat16:
+            self.wflat = self.pflat.to(torch.bfloat16)
+            Fn.bf16_mirror.attach(self.wflat, ddp.params, offsets)
+            cap = sum(p.numel() + 8 for p in ddp.params if p.dim() >= 2)
+            Fn.bf16_mirror.tflat = torch.empty(cap, dtype=torch.bfloat16, device=dev)
+            Fn.bf16_mirror.tcap = cap
+            self.mirror = Fn.bf16_mirror
         self.m = torch.zeros_like(self.pflat)
         self.v = torch.zeros_like(self.pflat)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -161,9 +209,13 @@ class FusedAdam:
             hip.check(L.st5_sumsq(g.data_ptr(), self.gnorm_sq.data_ptr(), g.numel(), 1.0, 0, hip.F32, hip.stream()), "st5_sumsq")
         hip.check(L.st5_adam_step(self.pflat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), g.numel(), self.lr,
                                   self.betas[0], self.betas[1], self.eps, self.wd, self.t,
-                                  self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale, hip.stream()),
+                                  self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
+                                  self.wflat.data_ptr() if self.mirror is not None else 0, hip.stream()),
                   "st5_adam_step")
-        # parameters changed in place through the flat view: invalidate the compute-dtype weight cache
-        for p in self.ddp.params:
-            p.data = p.data  # noqa  (keeps views)
+        # parameters changed in place through the flat view: invalidate the compute-dtype weight cache (entries that do
+        # not come from the bf16 image: conv / fp32 / non-adjacent stacks) and refresh the transposed copies
         Fn.weight_cache.clear()
+        if self.mirror is not None:
+            for p in self.ddp.params:
+                p._st5_mver = p._version
+            self.mirror.refresh_transposes()

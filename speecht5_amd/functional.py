@@ -96,10 +96,103 @@ def _cast_into(src, dst, transpose=False):
                                           _dt(dst), hip.stream()), "st5_cast_from_f32")
 
 
+class _Bf16Mirror:
+    """bf16 copies of the parameters kept current by the fused optimizer step (ddp.FusedAdam): the Adam kernel writes the
+    updated fp32 master AND its bf16 image in one pass, and every transposed weight copy the data-gradient GEMMs need
+    is refreshed by ONE batched transpose launch per step -- instead of ~300 cast / transpose launches per step.
+    A parameter's image is used only while `p._version` still equals the version recorded at the last refresh."""
+
+    def __init__(self):
+        self.flat = None        # bf16 [total], same element layout as the optimizer's flat fp32 buffer
+        self.tflat = None       # bf16 pool of transposed copies
+        self.tcap = 0
+        self.tused = 0
+        self.jobs = {}          # (src_off, rows, cols) -> (dst_off, view [cols, rows])
+        self.jobs_dev = None
+        self.ntiles = 0
+        self.dirty = False      # job table changed since it was last uploaded
+
+    def attach(self, flat_bf16, params, offsets):
+        self.__init__()
+        self.flat = flat_bf16
+        for p, off in zip(params, offsets):
+            p._st5_moff = off
+            p._st5_mver = p._version
+
+    def valid(self, p):
+        return self.flat is not None and getattr(p, "_st5_moff", None) is not None and p._st5_mver == p._version and \
+            p.device == self.flat.device
+
+    def stacked(self, weights):
+        """View [sum N_i, K] of the mirror if the weights are valid, 2-D-able and adjacent in this order, else None."""
+        if not all(self.valid(w) for w in weights):
+            return None
+        K = weights[0].numel() // weights[0].shape[0]
+        off = weights[0]._st5_moff
+        nxt = off
+        for w in weights:
+            if w._st5_moff != nxt or w.numel() // w.shape[0] != K:
+                return None
+            nxt += w.numel()
+        if off % 8:   # 16-byte rows for the GEMM loaders
+            return None
+        return off, self.flat[off:nxt].view(-1, K)
+
+    def transposed(self, off, rows, cols):
+        key = (off, rows, cols)
+        hit = self.jobs.get(key)
+        if hit is not None:
+            return hit[1]
+        n = rows * cols
+        need = (self.tused + n + 7) // 8 * 8
+        if need > self.tcap:
+            return None   # pool exhausted (sized for every >= 2-D parameter once): caller falls back to the cast path
+        view = self.tflat[self.tused:self.tused + n].view(cols, rows)
+        self.jobs[key] = (self.tused, view)
+        self.tused = need
+        self.dirty = True
+        # first use: produce this copy now (the batched refresh only runs after optimizer steps)
+        _cast_free_transpose(self.flat[off:off + n].view(rows, cols), view)
+        return view
+
+    def refresh_transposes(self):
+        if not self.jobs:
+            return
+        if self.dirty or self.jobs_dev is None:
+            import struct
+            recs, tile0 = [], 0
+            for (off, rows, cols), (doff, _v) in self.jobs.items():
+                recs.append(struct.pack("<qqiiii", off, doff, rows, cols, tile0, 0))
+                tile0 += ((rows + 63) // 64) * ((cols + 63) // 64)
+            self.ntiles = tile0
+            raw = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8)
+            self.jobs_dev = raw.to(self.flat.device)
+            self.dirty = False
+        hip.check(hip.lib().st5_multi_transpose_bf16(self.flat.data_ptr(), self.tflat.data_ptr(), self.jobs_dev.data_ptr(),
+                                                     len(self.jobs), self.ntiles, hip.stream()), "st5_multi_transpose_bf16")
+
+
+bf16_mirror = _Bf16Mirror()
+
+
+def _cast_free_transpose(src_bf16, dst_bf16):
+    """dst [cols, rows] <- src [rows, cols]^T for one bf16 matrix (single-job batched transpose)."""
+    import struct
+    rows, cols = src_bf16.shape
+    rec = struct.pack("<qqiiii", 0, 0, rows, cols, 0, 0)
+    job = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(src_bf16.device)
+    hip.check(hip.lib().st5_multi_transpose_bf16(src_bf16.data_ptr(), dst_bf16.data_ptr(), job.data_ptr(), 1,
+                                                 ((rows + 63) // 64) * ((cols + 63) // 64), hip.stream()), "st5_multi_transpose_bf16")
+
+
 def fused_weight(weights, dtype):
     """[sum N_i, K] compute-dtype matrix stacking the given nn.Linear weights (cached)."""
     if len(weights) == 1 and dtype == torch.float32 and weights[0].is_contiguous():
         return weights[0].detach()
+    if dtype == torch.bfloat16:
+        hit = bf16_mirror.stacked(weights)
+        if hit is not None:
+            return hit[1]
 
     def build():
         K = weights[0].shape[1]
@@ -117,6 +210,14 @@ def fused_weight(weights, dtype):
 def fused_weight_t(weights, dtype):
     """[K, sum N_i] compute-dtype TRANSPOSE of the stacked weights (cached): the B operand of the data-gradient GEMM
     dX = G . W in K-major form, so that dgrad runs on the same LDS-DMA NT kernel as the forward."""
+    if dtype == torch.bfloat16:
+        hit = bf16_mirror.stacked(weights)
+        if hit is not None:
+            off, st = hit
+            tv = bf16_mirror.transposed(off, st.shape[0], st.shape[1])
+            if tv is not None:
+                return tv
+
     def build():
         src = weights[0].detach() if len(weights) == 1 else torch.cat([w.detach() for w in weights], 0)
         src = src.reshape(src.shape[0], -1).contiguous().float()
@@ -132,6 +233,16 @@ def fused_bias(biases):
         return None
     if len(biases) == 1:
         return biases[0].detach()
+    if all(b is not None and b.is_contiguous() for b in biases):
+        # adjacent in the optimizer's flat buffer (ddp._fusion_ordered_parameters): the stacked bias is a view, no cat
+        nxt, st = biases[0].data_ptr(), biases[0].untyped_storage().data_ptr()
+        for b in biases:
+            if b.data_ptr() != nxt or b.untyped_storage().data_ptr() != st or b.dtype != torch.float32:
+                nxt = None
+                break
+            nxt += b.numel() * 4
+        if nxt is not None:
+            return torch.as_strided(biases[0].detach(), (sum(b.numel() for b in biases),), (1,))
     return weight_cache.get(("b",) + tuple(id(b) for b in biases), biases,
                             lambda: torch.cat([b.detach() for b in biases]))
 
@@ -251,6 +362,20 @@ def _rows(x):
 # -------------------------------------------------------------------------------------------------
 # Linear (+ fused bias / activation / dropout / residual), N-fused over several weight matrices
 # -------------------------------------------------------------------------------------------------
+def _adjacent_grads(params):
+    """True when every parameter wants a gradient and their gradient buffers follow each other in memory (same storage)."""
+    if any(p is None or not p.requires_grad for p in params):
+        return False
+    bufs = [grad_buffer(p) for p in params]
+    st = bufs[0].untyped_storage().data_ptr()
+    nxt = bufs[0].data_ptr()
+    for b in bufs:
+        if b.data_ptr() != nxt or b.untyped_storage().data_ptr() != st or not b.is_contiguous():
+            return False
+        nxt += b.numel() * b.element_size()
+    return True
+
+
 class LinearFunction(torch.autograd.Function):
     """y = dropout(act(x W^T + b)) + residual with W = stack(weights).  Reference call sites: nn.Linear
     in multihead_attention.py:213-231,397, speech_encoder_prenet.py:177, speech_decoder_prenet.py,
@@ -314,6 +439,21 @@ class LinearFunction(torch.autograd.Function):
                 hip.gemm(hip.operand(g, ldn), hip.operand(Wc, Wc.shape[1]), hip.operand(dx, K), M, K, N, _dt(dtype),
                          flags=hip.B_KSTRIDED)
             dx = dx.view(xshape)
+        if len(weights) > 1 and _adjacent_grads(weights) and (all(b is None for b in biases) or _adjacent_grads(biases)):
+            # the stacked projections' gradients are ONE contiguous [sum N_i, K] block of the flat gradient buffer
+            # (ddp._fusion_ordered_parameters): a single weight-gradient GEMM (+ bias column) for all of them
+            gw = torch.as_strided(grad_buffer(weights[0]), (N, K), (K, 1))
+            gb = None
+            if biases[0] is not None:
+                gb = torch.as_strided(grad_buffer(biases[0]), (N,), (1,))
+            hip.gemm(hip.operand(g, ldn), hip.operand(x2, K), hip.operand(gw, K), N, K, M, _dt(dtype),
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0, asum=gb)
+            for w in weights:
+                _grad_done(w)
+            for b in biases:
+                if b is not None:
+                    _grad_done(b)
+            return (dx, d_res, None, None, None) + (None,) * (2 * len(weights))
         off = 0
         for i, w in enumerate(weights):
             n_i = w.shape[0]
