@@ -33,6 +33,7 @@ extern "C" {
 #define ST5_GEMM_B_KSTRIDED 2  /* B(j,k) stored k-outer (j contiguous)                            */
 #define ST5_GEMM_OUT_F32 4     /* C / R are fp32 regardless of dtype (weight gradients)           */
 #define ST5_GEMM_DACT 8        /* multiply result by act'(P) (P = saved pre-activation, C layout) */
+#define ST5_GEMM_DEFERRABLE 16 /* C is not read before st5_gemm_flush_splitk: a split-K reduction may be queued (st5_gemm_defer_splitk) */
 
 /* Generalised operand addressing (elements):
  *   off(outer, inner) = (rpb ? (outer / rpb) * bstride + (outer % rpb) * ld : outer * ld)
@@ -81,6 +82,12 @@ typedef struct st5_gemm_params {
 int st5_gemm(const st5_gemm_params* p, int dtype, void* stream);
 /* 1 (default): plain NT GEMMs use the LDS-DMA pipelined kernel; 0: always the register-staged kernel (A/B testing). */
 int st5_gemm_set_glds(int enabled);
+/* Batch the slab reductions of split-K GEMMs (weight gradients): while enabled, a split-K st5_gemm only queues its reduction;
+ * st5_gemm_flush_splitk launches ONE kernel that folds every queued reduction into its output (the outputs are complete
+ * only after the flush; same stream as the GEMMs).  Used by the data-parallel wrapper, which flushes before it reduces a
+ * gradient bucket across ranks and at the end of backward.  Disabling flushes. */
+int st5_gemm_defer_splitk(int enabled, void* stream);
+int st5_gemm_flush_splitk(void* stream);
 
 /* ---- row-wise normalisation (encoder.py:226, transformer_layer.py:124,132, speech_encoder_prenet.py:174) */
 /* y = LN(x) * gamma + beta over the last dim (cols); saves mean/rstd (fp32 [rows]). */

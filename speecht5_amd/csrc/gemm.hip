@@ -545,6 +545,51 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// Deferred split-K reduction: with st5_gemm_defer_splitk(1) the slab reductions of consecutive weight-gradient GEMMs are
+// not launched one by one; their descriptors queue up (each GEMM keeps its slabs alive in a bump arena) and
+// st5_gemm_flush_splitk() folds all of them into their outputs with ONE launch (up to MR_MAX per launch).
+constexpr int MR_MAX = 48;
+struct MrDesc { const float* slabs; float* C; long long ldc; int nsplit, M, N; float beta; int blk0; int pad; };
+struct MrArgs { MrDesc d[MR_MAX]; int n; };
+__global__ __launch_bounds__(256) void splitk_multi_reduce_kernel(const MrArgs a) {
+  int j = 0;
+  while (j + 1 < a.n && a.d[j + 1].blk0 <= (int)blockIdx.x) ++j;
+  const MrDesc d = a.d[j];
+  const int nblk = (j + 1 < a.n ? a.d[j + 1].blk0 : (int)gridDim.x) - d.blk0;
+  const long long nv = (long long)d.M * d.N / 4, slab = (long long)d.M * d.N;
+  for (long long i = (long long)(blockIdx.x - d.blk0) * 256 + threadIdx.x; i < nv; i += (long long)nblk * 256) {
+    const long long e0 = i * 4;
+    const int m = (int)(e0 / d.N), n = (int)(e0 % d.N);
+    f32x4 acc = *reinterpret_cast<const f32x4*>(d.slabs + e0);
+    for (int s2 = 1; s2 < d.nsplit; ++s2) acc += *reinterpret_cast<const f32x4*>(d.slabs + s2 * slab + e0);
+    f32x4* dst = reinterpret_cast<f32x4*>(d.C + (long long)m * d.ldc + n);
+    if (d.beta != 0.f) acc += d.beta * *dst;
+    *dst = acc;
+  }
+}
+
+bool g_defer = false;
+MrArgs g_pending;            // g_pending.n descriptors queued
+int g_pending_blocks = 0;
+float* g_arena = nullptr;    // slab arena for deferred reductions (grown between flushes only)
+size_t g_arena_bytes = 0, g_arena_used = 0;
+
+int flush_pending(hipStream_t s) {
+  if (g_pending.n == 0) return ST5_OK;
+  hipLaunchKernelGGL(splitk_multi_reduce_kernel, dim3((unsigned)g_pending_blocks), dim3(256), 0, s, g_pending);
+  g_pending.n = 0; g_pending_blocks = 0; g_arena_used = 0;
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+// slab space for one deferred GEMM, or nullptr when the arena must grow (caller flushes, grows, retries)
+float* arena_take(size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (g_arena_used + bytes > g_arena_bytes) return nullptr;
+  float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(g_arena) + g_arena_used);
+  g_arena_used += bytes;
+  return p;
+}
+
 float* g_slab = nullptr;
 size_t g_slab_bytes = 0;
 float* slab_workspace(size_t bytes) {
@@ -958,6 +1003,39 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
       nsplit = (nk + per - 1) / per;
     }
   }
+  if (nsplit > 1 && g_defer && (p.flags & ST5_GEMM_DEFERRABLE) && !p.C.rpb && p.C.ld % 4 == 0) {
+    const size_t need = (size_t)nsplit * p.M * p.N * sizeof(float);
+    // the same output twice in one batch (tied weights) would race inside the batched reduction: fold what is pending first
+    for (int j = 0; j < g_pending.n; ++j)
+      if (g_pending.d[j].C == p.C.ptr) { const int rc = flush_pending(s); if (rc) return rc; break; }
+    if (g_pending.n == MR_MAX) { const int rc = flush_pending(s); if (rc) return rc; }
+    float* slabs = arena_take(need);
+    if (!slabs) {
+      const int rc = flush_pending(s);
+      if (rc) return rc;
+      if (need > g_arena_bytes || g_arena_bytes == 0) {
+        if (g_arena) (void)hipFree(g_arena);   // synchronises with in-flight users
+        size_t want = g_arena_bytes ? g_arena_bytes * 2 : (size_t(1) << 30);
+        while (want < need * 4) want *= 2;
+        if (hipMalloc(&g_arena, want) != hipSuccess) { g_arena = nullptr; g_arena_bytes = 0; return ST5_ERR_LAUNCH; }
+        g_arena_bytes = want;
+      }
+      slabs = arena_take(need);
+      if (!slabs) return ST5_ERR_LAUNCH;
+    }
+    st5_gemm_params q = p;
+    q.C.ptr = slabs; q.C.ld = p.N; q.C.rpb = 0; q.C.bstride = 0; q.C.zs0 = q.C.zs1 = 0; q.beta = 0.f;
+    const int rc = (g_use_glds && tn_glds_ok(q, dtype)) ? launch_tn_glds(q, 1, nsplit, s)
+                   : dtype == ST5_BF16 ? launch<bf16_t>(q, 1, nsplit, s) : launch<float>(q, 1, nsplit, s);
+    if (rc) return rc;
+    MrDesc& d = g_pending.d[g_pending.n++];
+    d.slabs = slabs; d.C = reinterpret_cast<float*>(const_cast<void*>(p.C.ptr)); d.ldc = p.C.ld; d.nsplit = nsplit;
+    d.M = p.M; d.N = p.N; d.beta = p.beta; d.blk0 = g_pending_blocks; d.pad = 0;
+    long long blocks = ((long long)p.M * p.N / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    g_pending_blocks += (int)blocks;
+    return ST5_OK;
+  }
   if (nsplit > 1) {
     float* slabs = slab_workspace((size_t)nsplit * p.M * p.N * sizeof(float));
     if (!slabs) return ST5_ERR_LAUNCH;
@@ -983,6 +1061,15 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, nsplit, s);
   return launch<float>(p, c_vec_ok, nsplit, s);
 }
+
+/* Deferred split-K reductions (see splitk_multi_reduce_kernel).  While enabled, outputs of split-K GEMMs are complete only
+ * after st5_gemm_flush_splitk(); disabling flushes. */
+extern "C" int st5_gemm_defer_splitk(int enabled, void* stream) {
+  if (!enabled && g_defer) { const int rc = flush_pending(reinterpret_cast<hipStream_t>(stream)); if (rc) return rc; }
+  g_defer = enabled != 0;
+  return ST5_OK;
+}
+extern "C" int st5_gemm_flush_splitk(void* stream) { return flush_pending(reinterpret_cast<hipStream_t>(stream)); }
 
 /* A/B switch for the LDS-DMA NT kernel (tools/bench_kernels.py uses it for within-process comparisons). */
 extern "C" int st5_gemm_set_glds(int enabled) { g_use_glds = enabled != 0; return ST5_OK; }

@@ -85,6 +85,11 @@ class FlatGradDataParallel:
         self.offsets = offs
         self._launched = [None] * len(self.buckets)
         Fn.set_layer_boundary_hook(self._boundary)
+        if dev.type == "cuda":
+            # batched split-K reductions: this wrapper owns the points where gradients must be complete (bucket
+            # all-reduce, finish()), so the per-GEMM slab reductions can be deferred and folded in one launch
+            from . import hip
+            hip.check(hip.lib().st5_gemm_defer_splitk(1, hip.stream()), "st5_gemm_defer_splitk")
 
     # -- hooks -------------------------------------------------------------------------------------
     def _boundary(self, x, module):
@@ -93,18 +98,32 @@ class FlatGradDataParallel:
             return x
         return _Trigger.apply(x, self, bi)
 
+    def _flush_splitk(self):
+        from . import hip
+        if self.flat.is_cuda:
+            hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")
+
     def _bucket_ready(self, bi):
         if self._launched[bi] is None and self.collectives:
+            self._flush_splitk()   # the bucket's weight gradients may still be slabs awaiting their batched reduction
             s, e = self.buckets[bi]
             self._launched[bi] = dist.all_reduce(self.flat[s:e], group=self.pg, async_op=True)
 
     # -- step API ----------------------------------------------------------------------------------
+    def close(self):
+        """Undo the process-wide switches this wrapper turned on (deferred split-K reductions, layer-boundary hook)."""
+        from . import hip
+        if self.flat.is_cuda:
+            hip.check(hip.lib().st5_gemm_defer_splitk(0, hip.stream()), "st5_gemm_defer_splitk")
+        Fn.set_layer_boundary_hook(None)
+
     def zero_grad(self):
         self.flat.zero_()
         self._launched = [None] * len(self.buckets)
 
     def finish(self):
         """Call after backward: reduce the remaining buckets, wait for all, average over ranks."""
+        self._flush_splitk()
         if self.collectives:
             for bi in range(len(self.buckets)):
                 self._bucket_ready(bi)

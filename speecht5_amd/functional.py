@@ -447,7 +447,7 @@ class LinearFunction(torch.autograd.Function):
             if biases[0] is not None:
                 gb = torch.as_strided(grad_buffer(biases[0]), (N,), (1,))
             hip.gemm(hip.operand(g, ldn), hip.operand(x2, K), hip.operand(gw, K), N, K, M, _dt(dtype),
-                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0, asum=gb)
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32 | hip.DEFERRABLE, beta=1.0, asum=gb)
             for w in weights:
                 _grad_done(w)
             for b in biases:
@@ -464,7 +464,7 @@ class LinearFunction(torch.autograd.Function):
                 # dW_i += G[:, off:off+n_i]^T . X   (both operands k-strided, fp32 accumulate in place); the bias
                 # gradient db_i += colsum(G_i) rides along as one extra MFMA column of the same kernel
                 hip.gemm(hip.operand(g, ldn, off=off), hip.operand(x2, K), hip.operand(gw, K), n_i, K, M, _dt(dtype),
-                         flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0,
+                         flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32 | hip.DEFERRABLE, beta=1.0,
                          asum=grad_buffer(b) if want_db else None)
                 _grad_done(w)
             elif want_db:
@@ -530,7 +530,7 @@ class FFNFunction(torch.autograd.Function):
                  P=hip.operand(hpre, Fd), act=act, flags=hip.DACT, dropout_p=p_act, seed=s1)
         if w2.requires_grad:
             hip.gemm(hip.operand(g, dout), hip.operand(h, Fd), hip.operand(grad_buffer(w2), Fd), dout, Fd, M, _dt(dtype),
-                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0,
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32 | hip.DEFERRABLE, beta=1.0,
                      asum=grad_buffer(b2) if b2.requires_grad else None)
             _grad_done(w2)
         elif b2.requires_grad:
@@ -545,7 +545,7 @@ class FFNFunction(torch.autograd.Function):
             dx = dx.view(xshape)
         if w1.requires_grad:
             hip.gemm(hip.operand(dh, Fd), hip.operand(x2, d), hip.operand(grad_buffer(w1), d), Fd, d, M, _dt(dtype),
-                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0,
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32 | hip.DEFERRABLE, beta=1.0,
                      asum=grad_buffer(b1) if b1.requires_grad else None)
             _grad_done(w1)
         elif b1.requires_grad:

@@ -13,6 +13,7 @@ import torch
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_LRELU_01, ACT_LRELU_001 = 0, 1, 2, 3, 4, 5
 A_KSTRIDED, B_KSTRIDED, OUT_F32, DACT = 1, 2, 4, 8
+DEFERRABLE = 16  # output not read before the data-parallel wrapper flushes the batched split-K reductions
 
 _LIB_PATH = os.environ.get("ST5_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libspeecht5_hip.so")
 
@@ -41,6 +42,8 @@ class GemmParams(Structure):
 _SIGS = {
     "st5_gemm": (c_int, [POINTER(GemmParams), c_int, c_void_p]),
     "st5_gemm_set_glds": (c_int, [c_int]),
+    "st5_gemm_defer_splitk": (c_int, [c_int, c_void_p]),
+    "st5_gemm_flush_splitk": (c_int, [c_void_p]),
     "st5_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                   c_float, c_int, c_void_p]),
     "st5_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

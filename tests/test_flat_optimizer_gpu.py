@@ -61,6 +61,8 @@ def test_flat_layout_fused_wgrad_and_bf16_image():
         assert abs(l_img - l_cast) <= 2e-3 * abs(l_cast), (l_img, l_cast)
         assert abs(l_img - float(l0.detach())) > 0   # the step changed something
     finally:
+        if "ddp" in locals():
+            ddp.close()
         Fn.bf16_mirror.__init__()
         Fn.weight_cache.clear()
         Fn.set_layer_boundary_hook(None)
