@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_fwd_kernel(const Args
 
 
 // =====================================================================================================
-// Backward.  D[bh,q] = dO[q].O[q] (prep), then two kernels that recompute P from (Q, K, bias, LSE):
+// Backward.  Two kernels that recompute P from (Q, K, bias, LSE); D[bh,q] = dO[q].O[q] is computed by the first:
 //   * flash_bwd_dq_kernel : per 128-query block, loops over key tiles (same orientation as the forward:
 //     every lane owns one query) -> dQ, and the relative-position bucket gradients dQP;
 //   * flash_bwd_dkv_kernel: per 128-key block, loops over query tiles (every lane owns one key) -> dK, dV.
@@ -425,26 +425,6 @@ struct BwdArgs {
   float scale, dropout_p;
   unsigned long long seed;
 };
-
-// D[bh, t] = sum_d dO[b,t,h,d] * O[b,t,h,d]: one wave per (b,t) row, 8 lanes per head chunk
-__global__ __launch_bounds__(256) void flash_bwd_prep_kernel(const BwdArgs a) {
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long long)a.B * a.T) return;
-  const int b = (int)(row / a.T), t = (int)(row % a.T);
-  const int d = a.H * HD;
-  for (int c = lane * 8; c < d; c += 512) {
-    float x[8], y[8];
-    load8f<bf16_t>(a.dout + row * a.do_ld + c, x);
-    load8f<bf16_t>(a.o + row * a.o_ld + c, y);
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s = fmaf(x[e], y[e], s);
-    // 8 lanes cover one head (64 dims)
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-    if ((lane & 7) == 0) a.dvec[((long long)b * a.H + c / HD) * a.T + t] = s;
-  }
-}
 
 // stage of one key tile for the dq kernel: K [key][d], K^T [d][key], V [key][d]
 struct KVStageBwd {
@@ -580,7 +560,17 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const BwdArgs a) {
     dof[ks] = *reinterpret_cast<const bf16x8*>(a.dout + ((long long)b * a.T + qc) * a.do_ld + h * HD + ks * 16 + hi * 8);
   }
   const float lse = a.lse[(long long)bh * a.T + qc];
-  const float dsum = a.dvec[(long long)bh * a.T + qc];
+  // D[q] = dO[q] . O[q] (the softmax-backward row term), computed here from the fragments this lane already holds and
+  // published for the dkv kernel (which runs after this one on the same stream) -- no separate preparation launch
+  float dsum = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.o + ((long long)b * a.T + qc) * a.o_ld + h * HD + ks * 16 + hi * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dsum = fmaf((float)dof[ks][e], (float)of[e], dsum);
+  }
+  dsum += __shfl_xor(dsum, 32, 64);
+  if (qvalid && hi == 0) a.dvec[(long long)bh * a.T + qi] = dsum;
   bf16_t* dqp_row = a.dqp ? a.dqp + ((long long)bh * a.T + qc) * a.nb : nullptr;
 
   int nkeys = a.S;
@@ -1063,7 +1053,6 @@ extern "C" int st5_flash_attn_bwd(const void* q, int64_t q_ld, const void* k, in
       return ST5_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(flash_bwd_prep_kernel, dim3((unsigned)(((long long)B * T + 3) / 4)), dim3(256), 0, s, a);
   if (pe && hipMemsetAsync(dqp, 0, (size_t)B * H * T * nb * 2, s) != hipSuccess) return ST5_ERR_LAUNCH;
   const size_t shm_dq = 6 * TILE_B + (pe ? (size_t)4 * 32 * (nb + 4) * 2 : 0);
   const size_t shm_dkv = 2 * QBUF;

@@ -503,23 +503,27 @@ class FFNFunction(torch.autograd.Function):
         y = torch.empty(M, w2.shape[0], dtype=dtype, device=x.device)
         s1 = next_seed() if p_act > 0 else 0
         s2 = next_seed() if p_out > 0 else 0
-        res2 = _rows(residual) if residual is not None else None
+        # residual == "x": the block input itself is the residual (post-LN layers).  Its gradient dY is then added in the
+        # epilogue of the dX GEMM instead of by a separate autograd accumulation kernel.
+        res_is_x = isinstance(residual, str)
+        res2 = x2 if res_is_x else (_rows(residual) if residual is not None else None)
         hip.gemm(hip.operand(x2, d), hip.operand(W1, d), hip.operand(h, Fd), M, Fd, d, _dt(dtype), Cpre=hip.operand(hpre, Fd),
                  bias=b1.detach(), act=act, dropout_p=p_act, seed=s1)
         hip.gemm(hip.operand(h, Fd), hip.operand(W2, Fd), hip.operand(y, w2.shape[0]), M, w2.shape[0], Fd, _dt(dtype),
                  R=hip.operand(res2, w2.shape[0]) if res2 is not None else None, bias=b2.detach(), dropout_p=p_out, seed=s2)
         ctx.save_for_backward(x2, h, hpre, W1, W2)
-        ctx.meta = (w1, b1, w2, b2, act, p_act, p_out, s1, s2, x.shape, residual is not None)
+        ctx.meta = (w1, b1, w2, b2, act, p_act, p_out, s1, s2, x.shape, residual is not None and not res_is_x, res_is_x)
         return y.view(x.shape[:-1] + (w2.shape[0],))
 
     @staticmethod
     def backward(ctx, dy):
         x2, h, hpre, W1, W2 = ctx.saved_tensors
-        w1, b1, w2, b2, act, p_act, p_out, s1, s2, xshape, has_res = ctx.meta
+        w1, b1, w2, b2, act, p_act, p_out, s1, s2, xshape, has_res, res_is_x = ctx.meta
         dtype = x2.dtype
         M, d = x2.shape
         Fd, dout = w1.shape[0], w2.shape[0]
         g = dy.contiguous().view(M, dout)
+        g_in = g
         d_res = dy if has_res else None
         if p_out > 0:
             g = _dropout(g, p_out, s2)
@@ -541,7 +545,8 @@ class FFNFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=dtype, device=x2.device)
             W1t = fused_weight_t([w1], dtype)  # [d, Fd]
-            hip.gemm(hip.operand(dh, Fd), hip.operand(W1t, Fd), hip.operand(dx, d), M, d, Fd, _dt(dtype))
+            hip.gemm(hip.operand(dh, Fd), hip.operand(W1t, Fd), hip.operand(dx, d), M, d, Fd, _dt(dtype),
+                     R=hip.operand(g_in, d) if res_is_x else None)
             dx = dx.view(xshape)
         if w1.requires_grad:
             hip.gemm(hip.operand(dh, Fd), hip.operand(x2, d), hip.operand(grad_buffer(w1), d), Fd, d, M, _dt(dtype),
@@ -556,7 +561,10 @@ class FFNFunction(torch.autograd.Function):
 
 
 def ffn(x, residual, fc1, fc2, act=ACT_GELU, p_act=0.0, p_out=0.0):
-    return FFNFunction.apply(x.contiguous(), residual, fc1.weight, fc1.bias, fc2.weight, fc2.bias, act, float(p_act), float(p_out))
+    xc = x.contiguous()
+    if residual is x and fc2.weight.shape[0] == x.shape[-1]:
+        residual = "x"
+    return FFNFunction.apply(xc, residual, fc1.weight, fc1.bias, fc2.weight, fc2.bias, act, float(p_act), float(p_out))
 
 
 # -------------------------------------------------------------------------------------------------
