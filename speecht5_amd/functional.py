@@ -383,6 +383,12 @@ class LinearFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, act, dropout_p, nw, *wb):
+        relay_in = None
+        if isinstance(nw, tuple):
+            nw, relay_in = nw
+        relay_out = None
+        if isinstance(residual, _RelayedResidual):
+            residual, relay_out = residual.tensor, residual.relay
         weights, biases = wb[:nw], wb[nw:]
         dtype = x.dtype
         x2 = _rows(x)
@@ -407,7 +413,8 @@ class LinearFunction(torch.autograd.Function):
                      Cpre=hip.operand(pre, ldn) if pre is not None else None,
                      bias=bc, act=act, dropout_p=dropout_p, seed=seed)
         ctx.save_for_backward(x2, pre, Wc)
-        ctx.meta = (weights, biases, act, dropout_p, seed, M, N, K, ldn, x.shape, residual is not None)
+        ctx.meta = (weights, biases, act, dropout_p, seed, M, N, K, ldn, x.shape, residual is not None and relay_out is None)
+        ctx.relays = (relay_out, relay_in)
         out = y if ldn == N else y[:, :N]
         return out.reshape(x.shape[:-1] + (N,))
 
@@ -418,6 +425,12 @@ class LinearFunction(torch.autograd.Function):
         dtype = x2.dtype
         dy2 = dy.reshape(M, N)
         d_res = dy if has_res else None
+        relay_out, relay_in = ctx.relays
+        if relay_out is not None:
+            relay_out.grad = dy.contiguous().view(M, N)   # picked up by the block's first Linear (same backward pass)
+        extra = None
+        if relay_in is not None and relay_in.grad is not None:
+            extra, relay_in.grad = relay_in.grad, None
         g = _padded(dy2, ldn) if (not dy2.is_contiguous() or ldn != N) else dy2
         if M == 0:
             return (torch.zeros(xshape, dtype=dtype, device=x2.device), d_res, None, None, None) + (None,) * (2 * len(weights))
@@ -434,11 +447,15 @@ class LinearFunction(torch.autograd.Function):
             if N % 8 == 0:
                 # dX = G . W as an NT GEMM against the cached transposed weights W^T [K, N]
                 Wt = fused_weight_t(weights, dtype)
-                hip.gemm(hip.operand(g, ldn), hip.operand(Wt, N), hip.operand(dx, K), M, K, N, _dt(dtype))
+                hip.gemm(hip.operand(g, ldn), hip.operand(Wt, N), hip.operand(dx, K), M, K, N, _dt(dtype),
+                         R=hip.operand(extra, K) if extra is not None else None)
+                extra = None
             else:  # odd widths (vocabulary): B operand k-strided, W is [N, K], reduction over N
                 hip.gemm(hip.operand(g, ldn), hip.operand(Wc, Wc.shape[1]), hip.operand(dx, K), M, K, N, _dt(dtype),
-                         flags=hip.B_KSTRIDED)
+                         flags=hip.B_KSTRIDED, R=hip.operand(extra, K) if extra is not None else None)
+                extra = None
             dx = dx.view(xshape)
+        assert extra is None, "a relayed residual gradient reached a Linear whose input needs no gradient"
         if len(weights) > 1 and _adjacent_grads(weights) and (all(b is None for b in biases) or _adjacent_grads(biases)):
             # the stacked projections' gradients are ONE contiguous [sum N_i, K] block of the flat gradient buffer
             # (ddp._fusion_ordered_parameters): a single weight-gradient GEMM (+ bias column) for all of them
@@ -475,15 +492,35 @@ class LinearFunction(torch.autograd.Function):
         return (dx, d_res, None, None, None) + (None,) * (2 * len(weights))
 
 
-def linear(x, weights, biases=None, act=ACT_NONE, residual=None, dropout_p=0.0):
-    """x [..., K] (compute dtype); weights: a Parameter [N,K] or a list of them (outputs concatenated)."""
+class GradRelay:
+    """Carries the gradient of a residual connection from the Linear that ADDS the residual (end of an attention block) to
+    the Linear that CONSUMES the same tensor (start of the block): the consumer's dX GEMM adds it in its epilogue, so
+    autograd never has to sum the two gradients of the forked tensor with a separate kernel.  Valid when the residual IS
+    the block input (post-LN layers); backward visits the adding Linear first by construction of the graph."""
+
+    def __init__(self):
+        self.grad = None
+
+
+def linear(x, weights, biases=None, act=ACT_NONE, residual=None, dropout_p=0.0, relay_out=None, relay_in=None):
+    """x [..., K] (compute dtype); weights: a Parameter [N,K] or a list of them (outputs concatenated).
+    relay_out: this call adds `residual`; hand its gradient to the relay instead of returning it to autograd.
+    relay_in: add the relayed gradient to this call's input gradient."""
     if isinstance(weights, torch.Tensor):
         weights, biases = [weights], [biases]
     if biases is None:
         biases = [None] * len(weights)
     x = x.contiguous()
-    y = LinearFunction.apply(x, residual, act, float(dropout_p), len(weights), *weights, *biases)
+    if relay_out is not None and residual is not None:
+        residual = _RelayedResidual(residual.detach(), relay_out)
+    y = LinearFunction.apply(x, residual, act, float(dropout_p), len(weights) if relay_in is None else (len(weights), relay_in),
+                             *weights, *biases)
     return y
+
+
+class _RelayedResidual:
+    def __init__(self, tensor, relay):
+        self.tensor, self.relay = tensor, relay
 
 
 # -------------------------------------------------------------------------------------------------

@@ -68,19 +68,21 @@ class MultiheadAttention(nn.Module, IncrementalState):
         if key_padding_mask is not None:
             kpm = key_padding_mask.to(torch.uint8).contiguous()
         probs = None
+        # post-LN blocks add the block input itself as the residual: relay its gradient into the first projection's dX GEMM
+        relay = Fn.GradRelay() if (residual is x and x.requires_grad and torch.is_grad_enabled()) else None
         if kv is None:
             qkv = Fn.linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight],
-                            [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias])
+                            [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], relay_in=relay)
             pe, maxrel = None, 0
             if position_bias is not None and self.has_relative_attention_bias:
                 pe, maxrel = position_bias.table, position_bias.maxlen
             ctx = Fn.SelfAttentionFunction.apply(qkv, pe, kpm, (B, H, T, hd, maxrel, causal, p))
         else:
-            q = Fn.linear(x, self.q_proj.weight, self.q_proj.bias)
+            q = Fn.linear(x, self.q_proj.weight, self.q_proj.bias, relay_in=relay)
             kvp = Fn.linear(kv, [self.k_proj.weight, self.v_proj.weight], [self.k_proj.bias, self.v_proj.bias])
             ctx, probs = Fn.CrossAttentionFunction.apply(q, kvp, kpm, (B, H, T, S, hd, p, need_weights))
         out = Fn.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual,
-                        dropout_p=out_dropout if self.training else 0.0)
+                        dropout_p=out_dropout if self.training else 0.0, relay_out=relay)
         return out, probs
 
     # ---- incremental decoding (multihead_attention.py:269-307 of the reference: saved_state prev_key / prev_value) ----
