@@ -144,7 +144,7 @@ class _Bf16Mirror:
         if hit is not None:
             return hit[1]
         n = rows * cols
-        need = (self.tused + n + 7) // 8 * 8
+        need = (self.tused + n + 63) // 64 * 64
         if need > self.tcap:
             return None   # pool exhausted (sized for every >= 2-D parameter once): caller falls back to the cast path
         view = self.tflat[self.tused:self.tused + n].view(cols, rows)
