@@ -94,9 +94,11 @@ int st5_gemm_flush_splitk(void* stream);
 int st5_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                       float* rstd, int64_t rows, int32_t cols, float eps, int dtype, void* stream);
 /* dx; dgamma/dbeta are ACCUMULATED (+=) into fp32 [cols]; ws >= st5_layernorm_bwd_ws_bytes(). */
-int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                      const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws,
-                      int64_t rows, int32_t cols, int dtype, void* stream);
+int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                      float* dgamma, float* dbeta, void* ws, int64_t rows, int32_t cols,
+                      void* dx_dropped /* optional 2nd output dx * dropout_mask(seed, row*cols + c): the gradient of the
+                                          dropout-epilogue Linear in front of this LayerNorm (cols % 4 == 0) */,
+                      float drop_p, uint64_t drop_seed, int dtype, void* stream);
 int64_t st5_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols);
 
 /* ---- attention probabilities (multihead_attention.py:343-386) ----

@@ -213,6 +213,18 @@ __device__ __forceinline__ void dropout_scale8(unsigned long long seed, unsigned
     out[2 * e + 1] = drop_pick(bits, 1, thresh16, inv_keep);
   }
 }
+// scale factors of the 4 elements idx4 .. idx4+3 (idx4 % 4 == 0): one block key, two pair hashes
+__device__ __forceinline__ void dropout_scale4(unsigned long long seed, unsigned long long idx4, unsigned int thresh16,
+                                               float inv_keep, float (&out)[4]) {
+  const unsigned int key = drop_block_key(seed, idx4 >> 6);
+  const unsigned int p0 = ((unsigned int)idx4 & 63u) >> 1;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const unsigned int bits = drop_pair_bits(key, p0 + e);
+    out[2 * e] = drop_pick(bits, 0, thresh16, inv_keep);
+    out[2 * e + 1] = drop_pick(bits, 1, thresh16, inv_keep);
+  }
+}
 __device__ __forceinline__ long long drop_row_stride(int row_len) { return ((long long)row_len + 63) & ~63ll; }
 
 #define HIP_CHECK_LAUNCH()                                   \

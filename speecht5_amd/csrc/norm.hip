@@ -214,11 +214,17 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
 }
 
 // dx (+ block partials of dgamma/dbeta when PG).  part: [gridDim.x][2][cols]
+// dxd (optional): second output dx * dropout_mask(seed, row * cols + c) -- the gradient the Linear in front of this
+// LayerNorm needs when its output went through the fused dropout epilogue (y = residual + drop(x W^T + b); LN(y)),
+// produced here instead of by a separate dropout kernel over dx.
 template <typename T, int NV, bool PG>
 __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, T* __restrict__ dx,
-                                                         float* __restrict__ part, long long rows, int cols) {
+                                                         float* __restrict__ part, long long rows, int cols,
+                                                         T* __restrict__ dxd, float drop_p, unsigned long long seed) {
+  const unsigned int thresh = dxd ? dropout_thresh(drop_p) : 0u;
+  const float inv_keep = dxd ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ float red[];   // PG: [4 waves][2][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float g[NV][4], dg[NV][4], db[NV][4];
@@ -275,6 +281,13 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rs[r] * (gv[r][i][e] - s1 - xv[r][i][e] * s2);
             store4f<T>(dx + (row0 + r) * cols + c, o);
+            if (dxd) {
+              float dsc[4];
+              dropout_scale4(seed, (unsigned long long)((row0 + r) * cols + c), thresh, inv_keep, dsc);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = Elem<T>::to_f(Elem<T>::from_f(o[e])) * dsc[e];  // mask the ROUNDED dX
+              store4f<T>(dxd + (row0 + r) * cols + c, o);
+            }
           }
         }
       }
@@ -498,7 +511,8 @@ extern "C" int64_t st5_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols) {
 
 extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                  const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t rows,
-                                 int32_t cols, int dtype, void* stream) {
+                                 int32_t cols, void* dx_dropped, float drop_p, uint64_t drop_seed, int dtype, void* stream) {
+  if (dx_dropped && (!dx || cols % 4 || cols > 2048 || drop_p <= 0.f || drop_p >= 1.f)) return ST5_ERR_ARG;
   if (!dy || !x || !gamma || !mean || !rstd || rows < 0 || cols <= 0 || cols > MAXCH * 512) return ST5_ERR_ARG;
   if ((dgamma || dbeta) && !ws) return ST5_ERR_ARG;
   if (rows == 0) return ST5_OK;
@@ -511,9 +525,11 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
 #define LBV(TT, NV_)                                                                                                    \
   do {                                                                                                                  \
     if (pg) hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, true>), dim3(nb), dim3(256), shm, s, (const TT*)dy, (const TT*)x, gamma, \
-                               mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols);                                 \
+                               mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols, (TT*)dx_dropped, drop_p,          \
+                               (unsigned long long)drop_seed);                                                          \
     else hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, false>), dim3(nb), dim3(256), 0, s, (const TT*)dy, (const TT*)x, gamma, \
-                            mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols);                                    \
+                            mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols, (TT*)dx_dropped, drop_p,            \
+                            (unsigned long long)drop_seed);                                                             \
   } while (0)
 #define LBV_T(TT)                                                                                                     \
   do {                                                                                                                \

@@ -337,6 +337,29 @@ def _colsum_into(x2d, ld, cols, out, col_off=0, scale=1.0):
                               ld, scale, 1, _dt(x2d), hip.stream()), "st5_colsum_ws")
 
 
+# Dropout-epilogue producers (Linear / FFN with dropout_p > 0) tag their output buffer; the LayerNorm that reads that
+# buffer then emits, from its backward kernel, BOTH dX and dX * mask(seed) -- the masked copy is what the producer's
+# backward needs, so no separate dropout kernel runs over the gradient (post-LN layers: ~110 launches per step).
+# Matching is by buffer address and verified by (p, seed, shape) at the consumer, so a stale or recycled address can only
+# cost a wasted second output, never a wrong gradient.
+_drop_tags = {}      # forward:  y.data_ptr() -> (p, seed, rows, cols)
+_drop_grads = {}     # backward: dX.data_ptr() -> (p, seed, rows, cols, dX_dropped)
+
+
+def _tag_dropout_output(y, p, seed, rows, cols):
+    if len(_drop_tags) > 64:
+        _drop_tags.clear()
+    _drop_tags[y.data_ptr()] = (p, seed, rows, cols)
+
+
+def _dropped_grad(g, p, seed):
+    """g * dropout_mask(p, seed): taken from the LayerNorm backward that produced g when it made one, else computed."""
+    hit = _drop_grads.pop(g.data_ptr(), None)
+    if hit is not None and hit[:4] == (p, seed, g.shape[0], g.shape[1]):
+        return hit[4]
+    return _dropout(g, p, seed)
+
+
 def _dropout(x, p, seed):
     y = torch.empty_like(x)
     hip.check(hip.lib().st5_dropout(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _dt(x), hip.stream()), "st5_dropout")
@@ -412,6 +435,8 @@ class LinearFunction(torch.autograd.Function):
                      R=hip.operand(res2, ldn) if res2 is not None else None,
                      Cpre=hip.operand(pre, ldn) if pre is not None else None,
                      bias=bc, act=act, dropout_p=dropout_p, seed=seed)
+        if dropout_p > 0 and act == ACT_NONE and M > 0:
+            _tag_dropout_output(y, dropout_p, seed, M, N)
         ctx.save_for_backward(x2, pre, Wc)
         ctx.meta = (weights, biases, act, dropout_p, seed, M, N, K, ldn, x.shape, residual is not None and relay_out is None)
         ctx.relays = (relay_out, relay_in)
@@ -435,7 +460,7 @@ class LinearFunction(torch.autograd.Function):
         if M == 0:
             return (torch.zeros(xshape, dtype=dtype, device=x2.device), d_res, None, None, None) + (None,) * (2 * len(weights))
         if p > 0:
-            g = _dropout(g, p, seed)
+            g = _dropped_grad(g, p, seed)
         if act != ACT_NONE:
             g2 = torch.empty_like(g)
             hip.check(hip.lib().st5_act_bwd(g.data_ptr(), pre.data_ptr(), g2.data_ptr(), g.numel(), act, _dt(g),
@@ -548,6 +573,8 @@ class FFNFunction(torch.autograd.Function):
                  bias=b1.detach(), act=act, dropout_p=p_act, seed=s1)
         hip.gemm(hip.operand(h, Fd), hip.operand(W2, Fd), hip.operand(y, w2.shape[0]), M, w2.shape[0], Fd, _dt(dtype),
                  R=hip.operand(res2, w2.shape[0]) if res2 is not None else None, bias=b2.detach(), dropout_p=p_out, seed=s2)
+        if p_out > 0:
+            _tag_dropout_output(y, p_out, s2, M, w2.shape[0])
         ctx.save_for_backward(x2, h, hpre, W1, W2)
         ctx.meta = (w1, b1, w2, b2, act, p_act, p_out, s1, s2, x.shape, residual is not None and not res_is_x, res_is_x)
         return y.view(x.shape[:-1] + (w2.shape[0],))
@@ -563,7 +590,7 @@ class FFNFunction(torch.autograd.Function):
         g_in = g
         d_res = dy if has_res else None
         if p_out > 0:
-            g = _dropout(g, p_out, s2)
+            g = _dropped_grad(g, p_out, s2)
         # dHpre = (G . W2) * act'(Hpre) [* activation-dropout mask]   (fused epilogue)
         dh = torch.empty(M, Fd, dtype=dtype, device=x2.device)
         W2t = fused_weight_t([w2], dtype)  # [Fd, dout]
@@ -617,23 +644,33 @@ class LayerNormFunction(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         hip.check(hip.lib().st5_layernorm_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
                                               rstd.data_ptr(), rows, cols, eps, _dt(x), hip.stream()), "st5_layernorm_fwd")
+        tag = _drop_tags.pop(x2.data_ptr(), None)
+        if tag is not None and (tag[2:] != (rows, cols) or cols % 4 or cols > 2048):
+            tag = None
         ctx.save_for_backward(x2, mean, rstd)
-        ctx.meta = (weight, bias, x.shape)
+        ctx.meta = (weight, bias, x.shape, tag)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         x2, mean, rstd = ctx.saved_tensors
-        weight, bias, xshape = ctx.meta
+        weight, bias, xshape, tag = ctx.meta
         rows, cols = x2.shape
         g = dy.contiguous().view(rows, cols)
         L = hip.lib()
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dxd = None
+        if tag is not None and dx is not None:
+            dxd = torch.empty_like(x2)
+            if len(_drop_grads) > 64:
+                _drop_grads.clear()
+            _drop_grads[dx.data_ptr()] = (tag[0], tag[1], rows, cols, dxd)
         gw = grad_buffer(weight) if weight.requires_grad else None
         gb = grad_buffer(bias) if bias.requires_grad else None
         ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows, cols), x2.device)
         hip.check(L.st5_layernorm_bwd(g.data_ptr(), x2.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                      hip.ptr(dx), hip.ptr(gw), hip.ptr(gb), ws.data_ptr(), rows, cols, _dt(x2),
+                                      hip.ptr(dx), hip.ptr(gw), hip.ptr(gb), ws.data_ptr(), rows, cols, hip.ptr(dxd),
+                                      tag[0] if dxd is not None else 0.0, tag[1] if dxd is not None else 0, _dt(x2),
                                       hip.stream()), "st5_layernorm_bwd")
         if gw is not None:
             _grad_done(weight)

@@ -228,10 +228,25 @@ def test_layernorm(cuda, dtype, rows, cols):
     ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows, cols), cuda)
     hip.check(L.st5_layernorm_bwd(DY.data_ptr(), X.data_ptr(), G.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                   DX.data_ptr(), dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), rows, cols,
-                                  hip.dt(dtype), hip.stream()), "ln bwd")
+                                  None, 0.0, 0, hip.dt(dtype), hip.stream()), "ln bwd")
     close(DX, xr.grad, dtype, what="ln dx")
     close(dG - 1, gr.grad, dtype, what="ln dgamma")
     close(dB - 1, br.grad, dtype, what="ln dbeta")
+    if cols % 4 == 0:
+        # second output: dX under the dropout mask of the Linear in front (same counter stream as st5_dropout / the
+        # GEMM epilogue: element index row * cols + col) -- bit-identical to masking dX afterwards
+        DX2 = torch.empty_like(X); DXD = torch.empty_like(X)
+        hip.check(L.st5_layernorm_bwd(DY.data_ptr(), X.data_ptr(), G.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      DX2.data_ptr(), dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), rows, cols,
+                                      DXD.data_ptr(), 0.25, 991, hip.dt(dtype), hip.stream()), "ln bwd + dropped")
+        assert torch.equal(DX2, DX)
+        want = torch.empty_like(X)
+        hip.check(L.st5_dropout(DX.data_ptr(), want.data_ptr(), rows * cols, 0.25, 991, hip.dt(dtype), hip.stream()), "dropout")
+        assert torch.equal(DXD, want)
+    else:
+        assert L.st5_layernorm_bwd(DY.data_ptr(), X.data_ptr(), G.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                   DX.data_ptr(), dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), rows, cols,
+                                   DX.data_ptr(), 0.25, 991, hip.dt(dtype), hip.stream()) != 0
 
 
 def _ref_attn_probs(scores, qp, kpm, H, causal, maxrel):

@@ -89,7 +89,7 @@ if __name__ == "__main__":
             dg = torch.zeros(cols, device=dev); db = torch.zeros(cols, device=dev)
             ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows2, cols), dev)
             t = timeit(lambda: L.st5_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), g.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), dx2.data_ptr(),
-                                                   dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows2, cols, hip.dt(dtype), hip.stream()))
+                                                   dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows2, cols, None, 0.0, 0, hip.dt(dtype), hip.stream()))
             print(f"layernorm bwd (dx + dgamma/dbeta) {rows2}x{cols}: {t*1e6:.1f} us  {3*rows2*cols*2/t/1e9:.0f} GB/s")
         BH, T = 96, 499; lds = 504
         sc = torch.randn(BH, T, lds, device=dev).to(dtype); qp = torch.randn(BH, T, 320, device=dev).to(dtype)
