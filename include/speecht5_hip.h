@@ -81,7 +81,13 @@ typedef struct st5_gemm_params {
  * (pos_conv); torch.bmm at multihead_attention.py:340,389; and their autograd backward passes. */
 int st5_gemm(const st5_gemm_params* p, int dtype, void* stream);
 /* 1 (default): plain NT GEMMs use the LDS-DMA pipelined kernel; 0: always the register-staged kernel (A/B testing). */
+/* Stream ordering for the host side (no torch types): everything enqueued on `to` after this call runs after everything
+ * enqueued on `from` before it.  Used to run the weight-gradient GEMMs of a backward pass (off the critical path: only the
+ * optimizer / gradient all-reduce needs them) on a second stream beside the data-gradient chain. */
+int st5_stream_fork(void* from_stream, void* to_stream);
 int st5_gemm_set_glds(int enabled);
+/* NT block tile: 0 = chosen per problem (default), 1 = 128x128 always, 2 = 256x256 always (A/B measurements only). */
+int st5_gemm_set_nt_tile(int mode);
 /* Batch the slab reductions of split-K GEMMs (weight gradients): while enabled, a split-K st5_gemm only queues its reduction;
  * st5_gemm_flush_splitk launches ONE kernel that folds every queued reduction into its output (the outputs are complete
  * only after the flush; same stream as the GEMMs).  Used by the data-parallel wrapper, which flushes before it reduces a

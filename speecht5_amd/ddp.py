@@ -16,6 +16,8 @@ the recipe needs --find-unused-parameters).  Same semantics here, re-designed fo
 xGMI note: the 8-GPU node is a full mesh of point-to-point links, so a ring all-reduce is bound
 by one link (~153 GB/s).  Buckets default to 64 MB so that several collectives are in flight during backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -91,6 +93,16 @@ class FlatGradDataParallel:
             # all-reduce, finish()), so the per-GEMM slab reductions can be deferred and folded in one launch
             from . import hip
             hip.check(hip.lib().st5_gemm_defer_splitk(1, hip.stream()), "st5_gemm_defer_splitk")
+            # weight-gradient GEMMs of the transformer layers on their own stream (functional.set_wgrad_stream): their
+            # gradient buffers have no other writer (no tied weights inside a layer)
+            if os.environ.get("ST5_WGRAD_STREAM", "1") == "1":
+                from .modules.transformer_layer import TransformerSentenceEncoderLayer, TransformerDecoderLayer
+                for m in model.modules():
+                    if isinstance(m, (TransformerSentenceEncoderLayer, TransformerDecoderLayer)):
+                        for p in m.parameters():
+                            p._st5_side_ok = True
+                self._side = torch.cuda.Stream(device=dev)
+                Fn.set_wgrad_stream(self._side)
 
     # -- hooks -------------------------------------------------------------------------------------
     def _boundary(self, x, module):
@@ -100,9 +112,13 @@ class FlatGradDataParallel:
         return _Trigger.apply(x, self, bi)
 
     def _flush_splitk(self):
+        """Gradients complete on the current stream: batched split-K reductions folded, weight-gradient stream joined."""
         from . import hip
         if self.flat.is_cuda:
-            hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")
+            if Fn.wgrad_stream() is not None:
+                Fn.join_wgrad_stream()   # the deferred reductions belong to the side stream: folded there, then joined
+            else:
+                hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")
 
     def _bucket_ready(self, bi):
         if self._launched[bi] is None and self.collectives:
@@ -115,6 +131,7 @@ class FlatGradDataParallel:
         """Undo the process-wide switches this wrapper turned on (deferred split-K reductions, layer-boundary hook)."""
         from . import hip
         if self.flat.is_cuda:
+            Fn.set_wgrad_stream(None)
             hip.check(hip.lib().st5_gemm_defer_splitk(0, hip.stream()), "st5_gemm_defer_splitk")
         Fn.set_layer_boundary_hook(None)
 

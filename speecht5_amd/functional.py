@@ -17,7 +17,8 @@ import torch
 from . import hip
 from .hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH  # noqa: F401
 
-_S = SimpleNamespace(dtype=torch.float32, seed=0x5EED, counter=0, grad_hook=None, boundary_hook=None)
+_S = SimpleNamespace(dtype=torch.float32, seed=0x5EED, counter=0, grad_hook=None, boundary_hook=None, side=None, side_raw=0,
+                     side_keep=[])
 
 
 def set_compute_dtype(dtype):
@@ -360,6 +361,49 @@ def _dropped_grad(g, p, seed):
     return _dropout(g, p, seed)
 
 
+# Weight-gradient stream.  dW = G^T X of a Linear is off the backward critical path (only the optimizer / the bucket
+# all-reduce needs it) and is a short-M x N, long-K problem that cannot fill the chip on its own; launched on a second
+# stream it runs beside the data-gradient chain instead of in front of it.  The owner of the gradient buffers
+# (ddp.FlatGradDataParallel) switches it on, marks the parameters whose gradients ONLY these GEMMs write (`_st5_side_ok`:
+# no tied weights, no other writer) and joins the streams wherever gradients must be complete.
+def set_wgrad_stream(stream):
+    join_wgrad_stream()
+    _S.side = stream
+    _S.side_raw = stream.cuda_stream if stream is not None else 0
+
+
+def wgrad_stream():
+    return _S.side
+
+
+def join_wgrad_stream():
+    """The current stream waits for every weight-gradient GEMM issued so far (and their batched split-K reduction)."""
+    if _S.side is None:
+        return
+    L = hip.lib()
+    hip.check(L.st5_gemm_flush_splitk(_S.side_raw), "st5_gemm_flush_splitk")
+    hip.check(L.st5_stream_fork(_S.side_raw, hip.stream()), "st5_stream_fork")
+    _S.side_keep.clear()
+
+
+def _wgrad_gemm(params, A, B, C, M, N, K, dt, asum, keep):
+    """C[M,N] += A^T B (fp32, both operands k-strided), bias-gradient column into `asum`.  `keep`: the tensors the GEMM
+    reads -- held until the next join so that the caching allocator cannot hand their memory to a main-stream kernel
+    while the side stream still reads them."""
+    flags = hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32
+    if _S.side is None:
+        hip.gemm(A, B, C, M, N, K, dt, flags=flags | hip.DEFERRABLE, beta=1.0, asum=asum)
+        return
+    for q in params:
+        if not getattr(q, "_st5_side_ok", False):
+            # another kernel may write this gradient on the main stream (tied weights): stay there, reduce at once
+            hip.gemm(A, B, C, M, N, K, dt, flags=flags, beta=1.0, asum=asum)
+            return
+    hip.check(hip.lib().st5_stream_fork(hip.stream(), _S.side_raw), "st5_stream_fork")
+    _S.side_keep.extend(keep)
+    hip.gemm(A, B, C, M, N, K, dt, flags=flags | hip.DEFERRABLE, beta=1.0, asum=asum, on=_S.side)
+
+
 def _dropout(x, p, seed):
     y = torch.empty_like(x)
     hip.check(hip.lib().st5_dropout(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _dt(x), hip.stream()), "st5_dropout")
@@ -488,8 +532,7 @@ class LinearFunction(torch.autograd.Function):
             gb = None
             if biases[0] is not None:
                 gb = torch.as_strided(grad_buffer(biases[0]), (N,), (1,))
-            hip.gemm(hip.operand(g, ldn), hip.operand(x2, K), hip.operand(gw, K), N, K, M, _dt(dtype),
-                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32 | hip.DEFERRABLE, beta=1.0, asum=gb)
+            _wgrad_gemm(weights, hip.operand(g, ldn), hip.operand(x2, K), hip.operand(gw, K), N, K, M, _dt(dtype), gb, (g, x2))
             for w in weights:
                 _grad_done(w)
             for b in biases:
@@ -505,9 +548,8 @@ class LinearFunction(torch.autograd.Function):
                 gw = grad_buffer(w)
                 # dW_i += G[:, off:off+n_i]^T . X   (both operands k-strided, fp32 accumulate in place); the bias
                 # gradient db_i += colsum(G_i) rides along as one extra MFMA column of the same kernel
-                hip.gemm(hip.operand(g, ldn, off=off), hip.operand(x2, K), hip.operand(gw, K), n_i, K, M, _dt(dtype),
-                         flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32 | hip.DEFERRABLE, beta=1.0,
-                         asum=grad_buffer(b) if want_db else None)
+                _wgrad_gemm((w, b) if want_db else (w,), hip.operand(g, ldn, off=off), hip.operand(x2, K), hip.operand(gw, K),
+                            n_i, K, M, _dt(dtype), grad_buffer(b) if want_db else None, (g, x2))
                 _grad_done(w)
             elif want_db:
                 _colsum_into(g, ldn, n_i, grad_buffer(b), col_off=off)
@@ -596,15 +638,6 @@ class FFNFunction(torch.autograd.Function):
         W2t = fused_weight_t([w2], dtype)  # [Fd, dout]
         hip.gemm(hip.operand(g, dout), hip.operand(W2t, dout), hip.operand(dh, Fd), M, Fd, dout, _dt(dtype),
                  P=hip.operand(hpre, Fd), act=act, flags=hip.DACT, dropout_p=p_act, seed=s1)
-        if w2.requires_grad:
-            hip.gemm(hip.operand(g, dout), hip.operand(h, Fd), hip.operand(grad_buffer(w2), Fd), dout, Fd, M, _dt(dtype),
-                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32 | hip.DEFERRABLE, beta=1.0,
-                     asum=grad_buffer(b2) if b2.requires_grad else None)
-            _grad_done(w2)
-        elif b2.requires_grad:
-            _colsum_into(g, dout, dout, grad_buffer(b2))
-        if b2.requires_grad:
-            _grad_done(b2)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=dtype, device=x2.device)
@@ -612,10 +645,18 @@ class FFNFunction(torch.autograd.Function):
             hip.gemm(hip.operand(dh, Fd), hip.operand(W1t, Fd), hip.operand(dx, d), M, d, Fd, _dt(dtype),
                      R=hip.operand(g_in, d) if res_is_x else None)
             dx = dx.view(xshape)
+        # weight gradients last: both data-gradient GEMMs of the block are enqueued before the side stream forks
+        if w2.requires_grad:
+            _wgrad_gemm((w2, b2), hip.operand(g, dout), hip.operand(h, Fd), hip.operand(grad_buffer(w2), Fd), dout, Fd, M,
+                        _dt(dtype), grad_buffer(b2) if b2.requires_grad else None, (g, h))
+            _grad_done(w2)
+        elif b2.requires_grad:
+            _colsum_into(g, dout, dout, grad_buffer(b2))
+        if b2.requires_grad:
+            _grad_done(b2)
         if w1.requires_grad:
-            hip.gemm(hip.operand(dh, Fd), hip.operand(x2, d), hip.operand(grad_buffer(w1), d), Fd, d, M, _dt(dtype),
-                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32 | hip.DEFERRABLE, beta=1.0,
-                     asum=grad_buffer(b1) if b1.requires_grad else None)
+            _wgrad_gemm((w1, b1), hip.operand(dh, Fd), hip.operand(x2, d), hip.operand(grad_buffer(w1), d), Fd, d, M,
+                        _dt(dtype), grad_buffer(b1) if b1.requires_grad else None, (dh, x2))
             _grad_done(w1)
         elif b1.requires_grad:
             _colsum_into(dh, Fd, Fd, grad_buffer(b1))

@@ -42,6 +42,8 @@ class GemmParams(Structure):
 _SIGS = {
     "st5_gemm": (c_int, [POINTER(GemmParams), c_int, c_void_p]),
     "st5_gemm_set_glds": (c_int, [c_int]),
+    "st5_stream_fork": (c_int, [c_void_p, c_void_p]),
+    "st5_gemm_set_nt_tile": (c_int, [c_int]),
     "st5_gemm_defer_splitk": (c_int, [c_int, c_void_p]),
     "st5_gemm_flush_splitk": (c_int, [c_void_p]),
     "st5_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
@@ -231,7 +233,8 @@ profiler = GemmProfiler()
 
 
 def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_zs=0, batch=1, zdiv=1, act=ACT_NONE,
-         flags=0, alpha=1.0, beta=0.0, dropout_p=0.0, seed=0, asum=None):
+         flags=0, alpha=1.0, beta=0.0, dropout_p=0.0, seed=0, asum=None, on=None):
+    """on: torch.cuda.Stream to launch on instead of the current one (the caller orders it: st5_stream_fork)."""
     p = GemmParams()
     p.A, p.B, p.C = A, B, C
     p.R = R if R is not None else _NULL_OP
@@ -245,13 +248,13 @@ def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_
     p.asum = ptr(asum)
     if profiler.enabled:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib().st5_gemm(byref(p), dtype, stream()), "st5_gemm")
-        e1.record()
+        e0.record(on)
+        check(lib().st5_gemm(byref(p), dtype, stream() if on is None else on.cuda_stream), "st5_gemm")
+        e1.record(on)
         variant = ("bf16" if dtype == BF16 else "f32") + "_" + ("T" if flags & A_KSTRIDED else "N") + ("N" if flags & B_KSTRIDED else "T")
         profiler.records.append((variant, 2.0 * M * N * K * batch, e0, e1, (M, N, K, batch)))
         return
-    check(lib().st5_gemm(byref(p), dtype, stream()), "st5_gemm")
+    check(lib().st5_gemm(byref(p), dtype, stream() if on is None else on.cuda_stream), "st5_gemm")
 
 
 # ---------------------------------------------------------------------------------------------

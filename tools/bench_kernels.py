@@ -46,6 +46,34 @@ if __name__ == "__main__":
                                   (127992, 512, 1536), (8192, 8192, 8192)):
                     gemm_case("NT", M, N, K, dtype, act=1)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "nt256":
+        # A/B of the two NT block tiles (st5_gemm_set_nt_tile) on the model's shapes + equality of the results
+        dtype = torch.bfloat16
+        L = hip.lib()
+        shapes = ((3992, 2304, 768), (3992, 768, 768), (3992, 3072, 768), (3992, 768, 3072), (3992, 768, 2304), (8192, 2304, 768), (8192, 768, 768),
+                  (8192, 3072, 768), (8192, 768, 3072), (8192, 768, 2304), (5008, 768, 768), (5008, 1536, 768), (127992, 512, 1536), (63992, 512, 1536),
+                  (63992, 512, 1024), (8192, 8192, 8192), (301, 520, 768))
+        for (M, N, K) in shapes:
+            A = torch.randn(M, K, device=dev).to(dtype); B = torch.randn(N, K, device=dev).to(dtype)
+            bias = torch.randn(N, device=dev); R = torch.randn(M, N, device=dev).to(dtype)
+            outs = []
+            line = f"M={M:6d} N={N:5d} K={K:5d}"
+            for mode in (1, 2, 0):
+                L.st5_gemm_set_nt_tile(mode)
+                C = torch.zeros(M, N, device=dev, dtype=dtype)
+                if len(sys.argv) > 2 and sys.argv[2] == "plain":
+                    f = lambda: hip.gemm(hip.operand(A, K), hip.operand(B, K), hip.operand(C, N), M, N, K, hip.dt(dtype), bias=bias)
+                else:
+                    f = lambda: hip.gemm(hip.operand(A, K), hip.operand(B, K), hip.operand(C, N), M, N, K, hip.dt(dtype), bias=bias, act=1,
+                                         R=hip.operand(R, N), dropout_p=0.1, seed=5)
+                t = timeit(f)
+                outs.append(C.clone())
+                line += f"  | tile{mode}: {t*1e6:7.1f} us {2*M*N*K/t/1e12:6.0f} TF"
+            L.st5_gemm_set_nt_tile(0)
+            t = timeit(lambda: torch.matmul(A, B.t()))
+            line += f"  | hipblaslt {t*1e6:7.1f} us   equal={torch.equal(outs[0], outs[1])}"
+            print(line)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "blas":
         # reference point only: the library GEMM (hipBLASLt through torch.matmul) on the same shapes
         dtype = torch.bfloat16
