@@ -131,6 +131,13 @@ int st5_flash_attn_fwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld,
                        int32_t S, int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal, int32_t lds, float scale,
                        float dropout_p, uint64_t seed, int dtype, void* stream);
 
+/* st5_flash_attn_fwd that also saves the relative-position bucket table it builds (qp_out [B*H, T, nb], dtype, =
+ * scale*log2(e)*q.pe^T; NULL = do not save): the backward's `qp` input, so the caller needs no q.pe^T GEMM there. */
+int st5_flash_attn_fwd_qp(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld, void* o,
+                          int64_t o_ld, float* lse, const void* pe, const uint8_t* kpm, int32_t B, int32_t H, int32_t T,
+                          int32_t S, int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal, int32_t lds, float scale,
+                          float dropout_p, uint64_t seed, void* qp_out, int dtype, void* stream);
+
 /* Backward of st5_flash_attn_fwd: recomputes P from (q, k, bias, lse).  Writes dq/dk/dv (dtype, same row layouts as
  * q/k/v with their own leading dimensions); dvec fp32 [B*H*T] scratch (D = rowsum(dO*O)).  With pe: qp = scale*log2(e)*q.pe^T
  * [B*H, T, nb] (dtype, caller computes it with st5_gemm; the kernels evaluate exp2 in the log2 domain) and dqp [B*H, T, nb] receives the bucket gradients
@@ -141,6 +148,15 @@ int st5_flash_attn_bwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld,
                        const uint8_t* kpm, int32_t B, int32_t H, int32_t T, int32_t S, int32_t head_dim, int32_t nb,
                        int32_t maxrel, int32_t causal, int32_t lds, float scale, float dropout_p, uint64_t seed, int dtype,
                        void* stream);
+/* The same with the dq and dkv kernels side by side: D on `stream`, then dq on `stream` and dkv on `stream2`
+ * (ordered after everything enqueued on `stream`), `stream` joined with `stream2` before returning.  stream2 NULL =
+ * st5_flash_attn_bwd.  Results are bit-identical to the single-stream form. */
+int st5_flash_attn_bwd_2s(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld, const void* o,
+                          int64_t o_ld, const void* dout, int64_t do_ld, void* dq, int64_t dq_ld, void* dk, int64_t dk_ld,
+                          void* dv, int64_t dv_ld, const float* lse, float* dvec, const void* pe, const void* qp, void* dqp,
+                          const uint8_t* kpm, int32_t B, int32_t H, int32_t T, int32_t S, int32_t head_dim, int32_t nb,
+                          int32_t maxrel, int32_t causal, int32_t lds, float scale, float dropout_p, uint64_t seed, int dtype,
+                          void* stream, void* stream2);
 
 /* ---- speech pre-net layer 0: Conv1d(1->C,k,stride,no bias) + GroupNorm(C groups) + GELU
  *      (speech_encoder_prenet.py:300,323-324).  wav fp32 [B,S]; out channels-last [B,L,C] (dtype);

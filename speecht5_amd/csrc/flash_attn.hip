@@ -36,6 +36,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 struct Args {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o; float* lse;
   const bf16_t* pe; const uint8_t* kpm;
+  bf16_t* qp_out;                           // optional [BH,T,nb]: the bucket table scale*log2e*q.pe^T, saved for the backward
   long long q_ld, k_ld, v_ld, o_ld;
   int B, H, T, S, nb, maxrel, causal, lds;
   float scale, dropout_p;
@@ -205,7 +206,7 @@ __device__ __forceinline__ unsigned int kpm_raw(const uint8_t* mrow, int key, in
 
 // QP^T[bucket][q] = sc2 * pe . q^T -> per-wave LDS table [32 q][qp_ld] (bf16); pe rows are fetched one bucket tile ahead
 __device__ __forceinline__ void build_qp_table(bf16_t* qp, int qp_ld, const bf16_t* pe, int nb, float sc2, const bf16x8 (&qf)[4],
-                                               int ql, int hi) {
+                                               int ql, int hi, bf16_t* gout = nullptr) {
   const int nbt = (nb + 31) / 32;
   bf16x8 pf[4], pn[4];
   {
@@ -233,6 +234,7 @@ __device__ __forceinline__ void build_qp_table(bf16_t* qp, int qp_ld, const bf16
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(acc[4 * g + e] * sc2);
         *reinterpret_cast<bf16x4*>(qp + ql * qp_ld + b0) = w;
+        if (gout) *reinterpret_cast<bf16x4*>(gout + b0) = w;   // this lane's query row of the global copy
       }
     }
 #pragma unroll
@@ -280,7 +282,8 @@ __global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_fwd_kernel(const Args
   const uint8_t* mrow = a.kpm ? a.kpm + (long long)b * a.S : nullptr;
   unsigned int raw_next = kpm_raw(mrow, lane, a.S);
 
-  if (BIAS) build_qp_table(qp, qp_ld, a.pe, a.nb, a.scale * LOG2E, qf, ql, hi);
+  if (BIAS) build_qp_table(qp, qp_ld, a.pe, a.nb, a.scale * LOG2E, qf, ql, hi,
+                           (a.qp_out && qvalid) ? a.qp_out + ((long long)bh * a.T + qi) * a.nb : nullptr);
   st.store(kbuf, vbuf, tid);
   __syncthreads();
 
@@ -422,9 +425,34 @@ struct BwdArgs {
   const uint8_t* kpm;
   long long q_ld, k_ld, v_ld, o_ld, do_ld, dq_ld, dk_ld, dv_ld;
   int B, H, T, S, nb, maxrel, causal, lds;
+  int write_dvec;                           // dq kernel publishes D (single-stream order: dq, then dkv)
   float scale, dropout_p;
   unsigned long long seed;
 };
+
+// D[bh,q] = dO[q] . O[q] on its own (two-stream backward: dq and dkv run side by side, both need D up front).  Two
+// lanes per row, same summation order as the dq kernel's in-register version (bit-identical D).
+__global__ __launch_bounds__(256) void flash_dvec_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ dvec, long long o_ld, long long do_ld, int H,
+                                                         int T, long long rows) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long r = t >> 1;
+  const int hi = (int)(t & 1);
+  float dsum = 0.f;
+  if (r < rows) {
+    const long long bh = r / T, q = r % T;
+    const long long b = bh / H, h = bh % H;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 df = *reinterpret_cast<const bf16x8*>(dout + (b * T + q) * do_ld + h * HD + ks * 16 + hi * 8);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(o + (b * T + q) * o_ld + h * HD + ks * 16 + hi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum = fmaf((float)df[e], (float)of[e], dsum);
+    }
+  }
+  dsum += __shfl_xor(dsum, 1, 64);
+  if (r < rows && hi == 0) dvec[r] = dsum;
+}
 
 // stage of one key tile for the dq kernel: K [key][d], K^T [d][key], V [key][d]
 struct KVStageBwd {
@@ -570,7 +598,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const BwdArgs a) {
     for (int e = 0; e < 8; ++e) dsum = fmaf((float)dof[ks][e], (float)of[e], dsum);
   }
   dsum += __shfl_xor(dsum, 32, 64);
-  if (qvalid && hi == 0) a.dvec[(long long)bh * a.T + qi] = dsum;
+  if (a.write_dvec && qvalid && hi == 0) a.dvec[(long long)bh * a.T + qi] = dsum;
   bf16_t* dqp_row = a.dqp ? a.dqp + ((long long)bh * a.T + qc) * a.nb : nullptr;
 
   int nkeys = a.S;
@@ -991,10 +1019,11 @@ __global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_bwd_dkv_kernel(const 
 
 }  // namespace
 
-extern "C" int st5_flash_attn_fwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
-                                  void* o, int64_t o_ld, float* lse, const void* pe, const uint8_t* kpm, int32_t B, int32_t H,
-                                  int32_t T, int32_t S, int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal,
-                                  int32_t lds, float scale, float dropout_p, uint64_t seed, int dtype, void* stream) {
+extern "C" int st5_flash_attn_fwd_qp(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
+                                     void* o, int64_t o_ld, float* lse, const void* pe, const uint8_t* kpm, int32_t B, int32_t H,
+                                     int32_t T, int32_t S, int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal,
+                                     int32_t lds, float scale, float dropout_p, uint64_t seed, void* qp_out, int dtype,
+                                     void* stream) {
   if (!q || !k || !v || !o || B <= 0 || H <= 0 || T <= 0 || S <= 0) return ST5_ERR_ARG;
   if (dtype != ST5_BF16 || head_dim != HD) return ST5_ERR_ARG;  // fp32 / other head sizes use the unfused path
   if (q_ld % 8 || k_ld % 8 || v_ld % 4 || o_ld % 4) return ST5_ERR_ALIGN;
@@ -1002,7 +1031,7 @@ extern "C" int st5_flash_attn_fwd(const void* q, int64_t q_ld, const void* k, in
   if (pe && (nb != 2 * maxrel || nb % 8 || nb > 1024)) return ST5_ERR_ARG;
   Args a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
-  a.pe = (const bf16_t*)pe; a.kpm = kpm;
+  a.pe = (const bf16_t*)pe; a.kpm = kpm; a.qp_out = pe ? (bf16_t*)qp_out : nullptr;
   a.q_ld = q_ld; a.k_ld = k_ld; a.v_ld = v_ld; a.o_ld = o_ld;
   a.B = B; a.H = H; a.T = T; a.S = S; a.nb = pe ? nb : 0; a.maxrel = maxrel; a.causal = causal; a.lds = lds;
   a.scale = scale; a.dropout_p = dropout_p; a.seed = seed;
@@ -1024,12 +1053,20 @@ extern "C" int st5_flash_attn_fwd(const void* q, int64_t q_ld, const void* k, in
   return ST5_OK;
 }
 
-extern "C" int st5_flash_attn_bwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
-                                  const void* o, int64_t o_ld, const void* dout, int64_t do_ld, void* dq, int64_t dq_ld, void* dk,
-                                  int64_t dk_ld, void* dv, int64_t dv_ld, const float* lse, float* dvec, const void* pe,
-                                  const void* qp, void* dqp, const uint8_t* kpm, int32_t B, int32_t H, int32_t T, int32_t S,
-                                  int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal, int32_t lds, float scale,
-                                  float dropout_p, uint64_t seed, int dtype, void* stream) {
+extern "C" int st5_flash_attn_fwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
+                                  void* o, int64_t o_ld, float* lse, const void* pe, const uint8_t* kpm, int32_t B, int32_t H,
+                                  int32_t T, int32_t S, int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal,
+                                  int32_t lds, float scale, float dropout_p, uint64_t seed, int dtype, void* stream) {
+  return st5_flash_attn_fwd_qp(q, q_ld, k, k_ld, v, v_ld, o, o_ld, lse, pe, kpm, B, H, T, S, head_dim, nb, maxrel, causal, lds, scale,
+                               dropout_p, seed, nullptr, dtype, stream);
+}
+
+extern "C" int st5_flash_attn_bwd_2s(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
+                                     const void* o, int64_t o_ld, const void* dout, int64_t do_ld, void* dq, int64_t dq_ld, void* dk,
+                                     int64_t dk_ld, void* dv, int64_t dv_ld, const float* lse, float* dvec, const void* pe,
+                                     const void* qp, void* dqp, const uint8_t* kpm, int32_t B, int32_t H, int32_t T, int32_t S,
+                                     int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal, int32_t lds, float scale,
+                                     float dropout_p, uint64_t seed, int dtype, void* stream, void* stream2) {
   if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !lse || !dvec || B <= 0 || H <= 0 || T <= 0 || S <= 0) return ST5_ERR_ARG;
   if (dtype != ST5_BF16 || head_dim != HD) return ST5_ERR_ARG;
   if (q_ld % 8 || k_ld % 8 || v_ld % 8 || o_ld % 8 || do_ld % 8 || dq_ld % 4 || dk_ld % 4 || dv_ld % 4) return ST5_ERR_ALIGN;
@@ -1056,13 +1093,36 @@ extern "C" int st5_flash_attn_bwd(const void* q, int64_t q_ld, const void* k, in
   if (pe && hipMemsetAsync(dqp, 0, (size_t)B * H * T * nb * 2, s) != hipSuccess) return ST5_ERR_LAUNCH;
   const size_t shm_dq = 6 * TILE_B + (pe ? (size_t)4 * 32 * (nb + 4) * 2 : 0);
   const size_t shm_dkv = 2 * QBUF;
+  // Two-stream form: the dq and dkv kernels are independent given D and each fills the chip only ~1.5x over (384 blocks
+  // of 256 threads at B*H = 96, one block per CU with the bias tables); side by side they share the CUs.
+  hipStream_t s2 = (hipStream_t)stream2;
+  a.write_dvec = s2 ? 0 : 1;
+  if (s2) {
+    const long long rows = (long long)B * H * T;
+    hipLaunchKernelGGL(flash_dvec_kernel, dim3((unsigned)((rows * 2 + 255) / 256)), dim3(256), 0, s, a.o, a.dout, dvec, a.o_ld, a.do_ld,
+                       H, T, rows);
+    if (st5_stream_fork(s, s2) != ST5_OK) return ST5_ERR_LAUNCH;
+  } else {
+    s2 = s;
+  }
   if (pe) {
     hipLaunchKernelGGL(flash_bwd_dq_kernel<true>, dim3((T + 127) / 128, B * H), dim3(256), shm_dq, s, a);
-    hipLaunchKernelGGL(flash_bwd_dkv_kernel<true>, dim3((S + 127) / 128, B * H), dim3(256), shm_dkv, s, a);
+    hipLaunchKernelGGL(flash_bwd_dkv_kernel<true>, dim3((S + 127) / 128, B * H), dim3(256), shm_dkv, s2, a);
   } else {
     hipLaunchKernelGGL(flash_bwd_dq_kernel<false>, dim3((T + 127) / 128, B * H), dim3(256), shm_dq, s, a);
-    hipLaunchKernelGGL(flash_bwd_dkv_kernel<false>, dim3((S + 127) / 128, B * H), dim3(256), shm_dkv, s, a);
+    hipLaunchKernelGGL(flash_bwd_dkv_kernel<false>, dim3((S + 127) / 128, B * H), dim3(256), shm_dkv, s2, a);
   }
   HIP_CHECK_LAUNCH();
+  if (s2 != s && st5_stream_fork(s2, s) != ST5_OK) return ST5_ERR_LAUNCH;
   return ST5_OK;
+}
+
+extern "C" int st5_flash_attn_bwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
+                                  const void* o, int64_t o_ld, const void* dout, int64_t do_ld, void* dq, int64_t dq_ld, void* dk,
+                                  int64_t dk_ld, void* dv, int64_t dv_ld, const float* lse, float* dvec, const void* pe,
+                                  const void* qp, void* dqp, const uint8_t* kpm, int32_t B, int32_t H, int32_t T, int32_t S,
+                                  int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal, int32_t lds, float scale,
+                                  float dropout_p, uint64_t seed, int dtype, void* stream) {
+  return st5_flash_attn_bwd_2s(q, q_ld, k, k_ld, v, v_ld, o, o_ld, dout, do_ld, dq, dq_ld, dk, dk_ld, dv, dv_ld, lse, dvec, pe, qp, dqp,
+                               kpm, B, H, T, S, head_dim, nb, maxrel, causal, lds, scale, dropout_p, seed, dtype, stream, nullptr);
 }

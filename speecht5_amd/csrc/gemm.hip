@@ -590,17 +590,27 @@ float* arena_take(size_t bytes) {
   return p;
 }
 
-float* g_slab = nullptr;
-size_t g_slab_bytes = 0;
-float* slab_workspace(size_t bytes) {
-  if (bytes > g_slab_bytes) {
-    if (g_slab) (void)hipFree(g_slab);  // synchronises with in-flight users
-    g_slab = nullptr;
-    const size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
-    if (hipMalloc(&g_slab, want) != hipSuccess) { g_slab_bytes = 0; return nullptr; }
-    g_slab_bytes = want;
+// split-K slab workspace, one per stream (the weight-gradient stream runs split-K GEMMs beside the main stream's)
+struct SlabWs { hipStream_t stream; float* ptr; size_t bytes; };
+SlabWs g_slabs[4] = {};
+int g_nslabs = 0;
+float* slab_workspace(size_t bytes, hipStream_t stream) {
+  SlabWs* w = nullptr;
+  for (int i = 0; i < g_nslabs; ++i)
+    if (g_slabs[i].stream == stream) w = &g_slabs[i];
+  if (!w) {
+    if (g_nslabs == 4) return nullptr;
+    w = &g_slabs[g_nslabs++];
+    w->stream = stream; w->ptr = nullptr; w->bytes = 0;
   }
-  return g_slab;
+  if (bytes > w->bytes) {
+    if (w->ptr) (void)hipFree(w->ptr);  // synchronises with in-flight users
+    w->ptr = nullptr;
+    const size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
+    if (hipMalloc(&w->ptr, want) != hipSuccess) { w->bytes = 0; return nullptr; }
+    w->bytes = want;
+  }
+  return w->ptr;
 }
 
 template <typename T>
@@ -887,23 +897,49 @@ __global__ __launch_bounds__(NT2) void gemm_nt256_kernel(const st5_gemm_params p
   for (int kt = 0; kt < nk; ++kt) {
     // publish stage kt+1 (own loads landed, then the barrier); the same barrier retires every wave's reads of stage kt-1,
     // whose buffer the loads of stage kt+3 overwrite
+#if GEMM_ABL == 5      // throughput probe: loads + barriers only, 12 loads (3 stages) allowed in flight per lane (results invalid)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#elif GEMM_ABL == 6    // the same without any wait (the issue rate of the LDS-DMA path itself)
+#else
     if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     GPROBE(1);
+#if GEMM_ABL != 2
     if (kt + NSTAGE2 - 1 < nk) issue(kt + NSTAGE2 - 1);
+#endif
     const char* cur = dsm + (kt & (NSTAGE2 - 1)) * STAGE2_BYTES;
     const char* nxt = dsm + ((kt + 1) & (NSTAGE2 - 1)) * STAGE2_BYTES;
+#if GEMM_ABL < 4
     read1(cur);
+#endif
+#if GEMM_ABL >= 4
+    asm volatile("" :: "v"(cur), "v"(nxt));
+#elif GEMM_ABL == 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(a0[i]));
+    asm volatile("" :: "v"(b0[0]), "v"(b0[1]));
+#else
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) mma<T>(a0[i], b0[j], acc[i][j]);
+#endif
+#if GEMM_ABL < 4
     read0(nxt);   // after the last stage: reads a stale (valid) buffer, unused
+#endif
+#if GEMM_ABL >= 4
+#elif GEMM_ABL == 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(a1[i]));
+    asm volatile("" :: "v"(b1[0]), "v"(b1[1]));
+#else
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) mma<T>(a1[i], b1[j], acc[i][j]);
+#endif
     GPROBE(2);
   }
   __syncthreads();
@@ -1232,7 +1268,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
     return ST5_OK;
   }
   if (nsplit > 1) {
-    float* slabs = slab_workspace((size_t)nsplit * p.M * p.N * sizeof(float));
+    float* slabs = slab_workspace((size_t)nsplit * p.M * p.N * sizeof(float), s);
     if (!slabs) return ST5_ERR_LAUNCH;
     st5_gemm_params q = p;
     q.C.ptr = slabs; q.C.ld = p.N; q.C.rpb = 0; q.C.bstride = 0; q.C.zs0 = q.C.zs1 = 0; q.beta = 0.f;

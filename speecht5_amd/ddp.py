@@ -97,12 +97,20 @@ class FlatGradDataParallel:
             # gradient buffers have no other writer (no tied weights inside a layer)
             if os.environ.get("ST5_WGRAD_STREAM", "1") == "1":
                 from .modules.transformer_layer import TransformerSentenceEncoderLayer, TransformerDecoderLayer
+                from .modules.speech_encoder_prenet import ConvFeatureExtractionModel
                 for m in model.modules():
                     if isinstance(m, (TransformerSentenceEncoderLayer, TransformerDecoderLayer)):
                         for p in m.parameters():
                             p._st5_side_ok = True
+                    elif isinstance(m, ConvFeatureExtractionModel) and os.environ.get("ST5_WGRAD_CONV", "1") == "1":
+                        for p in m.parameters():
+                            if p.dim() == 3:   # convolution weights (GroupNorm / LayerNorm parameters stay on the main stream)
+                                p._st5_side_ok = True
                 self._side = torch.cuda.Stream(device=dev)
                 Fn.set_wgrad_stream(self._side)
+            if os.environ.get("ST5_ATTN_STREAM", "1") == "1":
+                self._attn_side = torch.cuda.Stream(device=dev)   # dq / dkv kernels of the attention backward side by side
+                Fn.set_attention_stream(self._attn_side)
 
     # -- hooks -------------------------------------------------------------------------------------
     def _boundary(self, x, module):
@@ -132,6 +140,7 @@ class FlatGradDataParallel:
         from . import hip
         if self.flat.is_cuda:
             Fn.set_wgrad_stream(None)
+            Fn.set_attention_stream(None)
             hip.check(hip.lib().st5_gemm_defer_splitk(0, hip.stream()), "st5_gemm_defer_splitk")
         Fn.set_layer_boundary_hook(None)
 

@@ -18,7 +18,7 @@ from . import hip
 from .hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH  # noqa: F401
 
 _S = SimpleNamespace(dtype=torch.float32, seed=0x5EED, counter=0, grad_hook=None, boundary_hook=None, side=None, side_raw=0,
-                     side_keep=[])
+                     side_keep=[], attn_side=None, attn_side_raw=None)
 
 
 def set_compute_dtype(dtype):
@@ -402,6 +402,22 @@ def _wgrad_gemm(params, A, B, C, M, N, K, dt, asum, keep):
     hip.check(hip.lib().st5_stream_fork(hip.stream(), _S.side_raw), "st5_stream_fork")
     _S.side_keep.extend(keep)
     hip.gemm(A, B, C, M, N, K, dt, flags=flags | hip.DEFERRABLE, beta=1.0, asum=asum, on=_S.side)
+
+
+def _conv_wgrad(w, opA, opB, Cout, k, Cin, Kred, dt, keep):
+    """grad(w)[Cout, Cin, k] += (A^T B)[Cout, k*Cin] re-laid out (implicit-GEMM convolution weight gradient); on the
+    weight-gradient stream when nothing else writes w's gradient."""
+    def run():
+        tmpw = torch.empty(Cout, k * Cin, dtype=torch.float32, device=w.device)
+        hip.gemm(opA, opB, hip.operand(tmpw, k * Cin), Cout, k * Cin, Kred, dt, flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
+        grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))  # (glue: layout permute of a <= 3 MB tensor)
+    if _S.side is not None and getattr(w, "_st5_side_ok", False):
+        hip.check(hip.lib().st5_stream_fork(hip.stream(), _S.side_raw), "st5_stream_fork")
+        _S.side_keep.extend(keep)
+        with torch.cuda.stream(_S.side):
+            run()
+    else:
+        run()
 
 
 def _dropout(x, p, seed):
@@ -844,19 +860,28 @@ def _eptr(t3):
 _LOG2E = 1.4426950408889634
 
 
-def _flash_fwd(q, k, v, B, H, T, S, hd, pe, maxrel, kpm, causal, p_drop, seed):
+def _flash_fwd(q, k, v, B, H, T, S, hd, pe, maxrel, kpm, causal, p_drop, seed, save_qp=False):
+    """Returns ctx, lse, qp.  save_qp: keep the bucket table scale*log2e*q.pe^T [B*H, T, nb] the kernel builds (30 MB per
+    encoder layer at cfg 2) for the backward instead of recomputing it there with a batched GEMM."""
     dev = q[0].device
     d = H * hd
     ctx = torch.empty(B * T, d, dtype=torch.bfloat16, device=dev)
     lse = torch.empty(B * H, T, dtype=torch.float32, device=dev)
     nb = pe.shape[0] if pe is not None else 0
-    hip.check(hip.lib().st5_flash_attn_fwd(_eptr(q), q[1], _eptr(k), k[1], _eptr(v), v[1], ctx.data_ptr(), d, lse.data_ptr(),
-                                           hip.ptr(pe), hip.ptr(kpm), B, H, T, S, hd, nb, maxrel, 1 if causal else 0, _ceil8(S),
-                                           hd ** -0.5, p_drop, seed, hip.BF16, hip.stream()), "st5_flash_attn_fwd")
-    return ctx, lse
+    qp = torch.empty(B * H, T, nb, dtype=torch.bfloat16, device=dev) if (save_qp and pe is not None) else None
+    hip.check(hip.lib().st5_flash_attn_fwd_qp(_eptr(q), q[1], _eptr(k), k[1], _eptr(v), v[1], ctx.data_ptr(), d, lse.data_ptr(),
+                                              hip.ptr(pe), hip.ptr(kpm), B, H, T, S, hd, nb, maxrel, 1 if causal else 0, _ceil8(S),
+                                              hd ** -0.5, p_drop, seed, hip.ptr(qp), hip.BF16, hip.stream()), "st5_flash_attn_fwd_qp")
+    return ctx, lse, qp
 
 
-def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe, maxrel, kpm, causal, p_drop, seed):
+def set_attention_stream(stream):
+    """Second stream for the attention backward (dq and dkv kernels side by side, st5_flash_attn_bwd_2s); None = off."""
+    _S.attn_side = stream
+    _S.attn_side_raw = stream.cuda_stream if stream is not None else None
+
+
+def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe, maxrel, kpm, causal, p_drop, seed, qp=None):
     """Writes dq/dk/dv slices; returns dPE (fp32) or None."""
     dev = dctx.device
     dtype = torch.bfloat16
@@ -864,21 +889,22 @@ def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe
     BH = B * H
     alpha = hd ** -0.5
     dvec = torch.empty(BH * T, dtype=torch.float32, device=dev)
-    qp = dqp = None
+    dqp = None
     nb = 0
     qt, qld, qoff = q
     if pe is not None:
         nb = pe.shape[0]
-        qp = torch.empty(BH, T, nb, dtype=dtype, device=dev)
-        # the kernels work in the log2 domain: qp = scale * log2(e) * q.pe^T
-        hip.gemm(hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd), hip.operand(pe, hd),
-                 hip.operand(qp, nb, zs0=H * T * nb, zs1=T * nb), T, nb, hd, hip.BF16, batch=BH, zdiv=H, alpha=alpha * _LOG2E)
+        if qp is None:
+            qp = torch.empty(BH, T, nb, dtype=dtype, device=dev)
+            # the kernels work in the log2 domain: qp = scale * log2(e) * q.pe^T
+            hip.gemm(hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd), hip.operand(pe, hd),
+                     hip.operand(qp, nb, zs0=H * T * nb, zs1=T * nb), T, nb, hd, hip.BF16, batch=BH, zdiv=H, alpha=alpha * _LOG2E)
         dqp = torch.empty(BH, T, nb, dtype=dtype, device=dev)
-    hip.check(hip.lib().st5_flash_attn_bwd(_eptr(q), q[1], _eptr(k), k[1], _eptr(v), v[1], ctx.data_ptr(), d, dctx.data_ptr(), d,
-                                           _eptr(dq), dq[1], _eptr(dk), dk[1], _eptr(dv), dv[1], lse.data_ptr(), dvec.data_ptr(),
-                                           hip.ptr(pe), hip.ptr(qp), hip.ptr(dqp), hip.ptr(kpm), B, H, T, S, hd, nb, maxrel,
-                                           1 if causal else 0, _ceil8(S), alpha, p_drop, seed, hip.BF16, hip.stream()),
-              "st5_flash_attn_bwd")
+    hip.check(hip.lib().st5_flash_attn_bwd_2s(_eptr(q), q[1], _eptr(k), k[1], _eptr(v), v[1], ctx.data_ptr(), d, dctx.data_ptr(), d,
+                                              _eptr(dq), dq[1], _eptr(dk), dk[1], _eptr(dv), dv[1], lse.data_ptr(), dvec.data_ptr(),
+                                              hip.ptr(pe), hip.ptr(qp), hip.ptr(dqp), hip.ptr(kpm), B, H, T, S, hd, nb, maxrel,
+                                              1 if causal else 0, _ceil8(S), alpha, p_drop, seed, hip.BF16, hip.stream(),
+                                              _S.attn_side_raw), "st5_flash_attn_bwd_2s")
     if pe is None:
         return None
     dqt, dqld, dqoff = dq
@@ -910,9 +936,9 @@ class SelfAttentionFunction(torch.autograd.Function):
         d = H * hd
         seed = next_seed() if p_drop > 0 else 0
         if _can_flash(qkv.dtype, hd, False):
-            ctx, lse = _flash_fwd((qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), B, H, T, T, hd, pe, maxrel, kpm, causal,
-                                  p_drop, seed)
-            ctx_.save_for_backward(qkv, ctx, lse, pe, kpm)
+            ctx, lse, qp = _flash_fwd((qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), B, H, T, T, hd, pe, maxrel, kpm, causal,
+                                      p_drop, seed, save_qp=any(ctx_.needs_input_grad))
+            ctx_.save_for_backward(qkv, ctx, lse, pe, kpm, qp)
             ctx_.meta = (cfg, seed, True)
             return ctx
         ctx, probs, pdrop = _attn_fwd((qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), B, H, T, T, hd, pe, maxrel,
@@ -926,11 +952,11 @@ class SelfAttentionFunction(torch.autograd.Function):
         (B, H, T, hd, maxrel, causal, p_drop), seed, flash = ctx_.meta
         d = H * hd
         if flash:
-            qkv, ctx, lse, pe, kpm = ctx_.saved_tensors
+            qkv, ctx, lse, pe, kpm, qp = ctx_.saved_tensors
             dqkv = torch.empty_like(qkv)
             dpe = _flash_bwd(dctx.contiguous(), ctx, lse, (qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), (dqkv, 3 * d, 0),
                              (dqkv, 3 * d, d), (dqkv, 3 * d, 2 * d), B, H, T, T, hd, pe, pe is not None and ctx_.needs_input_grad[1],
-                             maxrel, kpm, causal, p_drop, seed)
+                             maxrel, kpm, causal, p_drop, seed, qp=qp)
             if dpe is not None and pe.dtype != torch.float32:
                 dpe = to_compute(dpe)
             return dqkv, dpe, None, None
@@ -954,7 +980,7 @@ class CrossAttentionFunction(torch.autograd.Function):
         d = H * hd
         seed = next_seed() if p_drop > 0 else 0
         if _can_flash(q.dtype, hd, want_probs):
-            ctx, lse = _flash_fwd((q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), B, H, T, S, hd, None, 0, kpm, False, p_drop, seed)
+            ctx, lse, _ = _flash_fwd((q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), B, H, T, S, hd, None, 0, kpm, False, p_drop, seed)
             ctx_.save_for_backward(q, kv, ctx, lse, kpm)
             ctx_.meta = (cfg, seed, True)
             return ctx, None
@@ -1301,11 +1327,8 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
             dint = dpre[:, 1:-1]  # interior view, row stride Cout, batch stride (Lo+2)*Cout
             ioff = Cout  # element offset of the interior
             if w.requires_grad:
-                tmpw = torch.empty(Cout, k * Cin, dtype=torch.float32, device=dev)
-                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout),
-                         hip.operand(xin, s * Cin, rpb=Lo, bstride=Lin * Cin), hip.operand(tmpw, k * Cin),
-                         Cout, k * Cin, B * Lo, _dt(dtype), flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
-                grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))  # (glue: layout permute of a 3 MB tensor)
+                _conv_wgrad(w, hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout),
+                            hip.operand(xin, s * Cin, rpb=Lo, bstride=Lin * Cin), Cout, k, Cin, B * Lo, _dt(dtype), (dpre, xin))
                 _grad_done(w)
             # data gradient into the (padded) pre-activation gradient of the previous layer
             last = li == 1
@@ -1446,11 +1469,8 @@ class Conv1dStridedFunction(torch.autograd.Function):
         ioff = Cout
         want_db = bias is not None and bias.requires_grad
         if w.requires_grad:
-            tmpw = torch.empty(Cout, k * Cin, dtype=torch.float32, device=dev)
-            hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout),
-                     hip.operand(x, s * Cin, rpb=Lo, bstride=Lin * Cin), hip.operand(tmpw, k * Cin),
-                     Cout, k * Cin, B * Lo, _dt(dtype), flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
-            grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))
+            _conv_wgrad(w, hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout),
+                        hip.operand(x, s * Cin, rpb=Lo, bstride=Lin * Cin), Cout, k, Cin, B * Lo, _dt(dtype), (dpre, x))
             _grad_done(w)
         if want_db:
             _colsum_into(dy.contiguous().view(B * Lo, Cout), Cout, Cout, grad_buffer(bias))

@@ -133,3 +133,54 @@ def test_flash_backward_matches_unfused(cuda, T, S, causal, rel, pad, pdrop):
         sc = b.abs().max().item()
         err = (a - b).abs().max().item()
         assert err <= 3e-2 * sc, f"{name}: flash vs unfused err {err:.3e} scale {sc:.3e}"
+
+
+@pytest.mark.parametrize("T,causal,rel,pdrop", [(499, 0, 1, 0.1), (313, 1, 0, 0.1), (150, 0, 1, 0.0)])
+def test_flash_backward_two_streams_identical(cuda, T, causal, rel, pdrop):
+    """The two-stream attention backward (D kernel, then dq and dkv side by side: st5_flash_attn_bwd_2s) and the saved
+    bucket table of st5_flash_attn_fwd_qp give bit-identical gradients to the single-stream form."""
+    torch.manual_seed(T)
+    B, H, hd = 2, 3, 64
+    maxrel = 160 if T > 200 else 16
+    d = H * hd
+    dt = torch.bfloat16
+    Fn.set_compute_dtype(dt)
+    pe0 = torch.randn(2 * maxrel, hd).to(dt).to(cuda) if rel else None
+    dout = torch.randn(B * T, d).to(dt).to(cuda)
+    side = torch.cuda.Stream()
+    res = []
+    try:
+        for two in (False, True):
+            Fn.set_attention_stream(side if two else None)
+            Fn.manual_seed(5)
+            pe = pe0.clone().requires_grad_(True) if rel else None
+            x = (torch.randn(B * T, 3 * d, generator=torch.Generator().manual_seed(1)) * 1.2).to(dt).to(cuda).requires_grad_(True)
+            out = Fn.SelfAttentionFunction.apply(x, pe, None, (B, H, T, hd, maxrel if rel else 0, bool(causal), pdrop))
+            out.backward(dout)
+            torch.cuda.synchronize()
+            res.append((out.detach().clone(), x.grad.clone(), pe.grad.clone() if rel else None))
+    finally:
+        Fn.set_attention_stream(None)
+        Fn.set_compute_dtype(torch.float32)
+    for a, b in zip(res[0], res[1]):
+        if a is not None:
+            assert torch.equal(a, b)
+
+
+def test_flash_fwd_saved_bucket_table(cuda):
+    """qp_out of st5_flash_attn_fwd_qp == scale*log2(e)*q.pe^T as the backward's GEMM computes it (bf16, <= 1 ulp)."""
+    torch.manual_seed(3)
+    B, H, T, hd, maxrel = 2, 2, 200, 64, 160
+    d, nb = H * hd, 2 * maxrel
+    qkv = torch.randn(B * T, 3 * d).to(torch.bfloat16).to(cuda)
+    pe = torch.randn(nb, hd).to(torch.bfloat16).to(cuda)
+    o = torch.empty(B * T, d, dtype=torch.bfloat16, device=cuda)
+    lse = torch.empty(B * H, T, device=cuda)
+    qp = torch.zeros(B * H, T, nb, dtype=torch.bfloat16, device=cuda)
+    hip.check(hip.lib().st5_flash_attn_fwd_qp(qkv.data_ptr(), 3 * d, qkv.data_ptr() + d * 2, 3 * d, qkv.data_ptr() + 4 * d, 3 * d,
+                                              o.data_ptr(), d, lse.data_ptr(), pe.data_ptr(), 0, B, H, T, T, hd, nb, maxrel, 0,
+                                              (T + 7) // 8 * 8, hd ** -0.5, 0.0, 0, qp.data_ptr(), hip.BF16, hip.stream()), "flash fwd qp")
+    q = qkv.float().view(B, T, 3, H, hd)[:, :, 0].permute(0, 2, 1, 3)          # [B, H, T, hd]
+    ref = (q @ pe.float().t()) * (hd ** -0.5 * 1.4426950408889634)
+    got = qp.float().view(B, H, T, nb)
+    assert (got - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
