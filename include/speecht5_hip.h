@@ -227,6 +227,13 @@ int st5_cross_entropy(const void* logits, const int32_t* target, float* loss_sum
                       int64_t rows, int32_t V, int64_t ld, float label_smoothing, int32_t ignore_index,
                       float grad_scale, int dtype, void* stream);
 
+/* The same with per-row outputs instead of atomically accumulated sums: row_loss[r] (and row_nll[r] if given) = the row's
+ * loss (0 for skipped rows); the caller sums them (deterministic).  This is what the criteria use
+ * (speech_pretrain_criterion.py:98-141 NCE cross entropy, text_pretrain_criterion.py:56-60, speech_to_text_loss.py:93-110). */
+int st5_cross_entropy_rows(const void* logits, const int32_t* target, float* row_loss, float* row_nll, void* dlogits,
+                           int64_t rows, int32_t V, int64_t ld, float label_smoothing, int32_t ignore_index,
+                           float grad_scale, int dtype, void* stream);
+
 /* ---- optimizer (fairseq `adam`: decoupled weight decay; README.md:107-115 flags) ----
  * One fused pass over the flat fp32 buffers: g' = g * grad_scale * min(1, max_norm / (sqrt(*gnorm_sq) * grad_scale));
  * m,v update; p = p*(1 - lr*wd) - lr/bc1 * m / (sqrt(v/bc2) + eps).  gnorm_sq is a DEVICE scalar (may be NULL). */

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as Fn
 from .fairseq_compat import register_criterion
 from .modules.speech_encoder_prenet import SpeechEncoderPrenet
 
@@ -167,7 +168,7 @@ class SpeechPretrainCriterion(nn.Module):
         targ_m_list = model.get_targets(None, net_output, True)
         loss_m_list = []
         for i, (lm, tm) in enumerate(zip(logp_m_list, targ_m_list)):
-            l = F.cross_entropy(lm, tm, reduction=reduction)
+            l = Fn.cross_entropy_sum(lm, tm)[0] if reduce else F.cross_entropy(lm, tm, reduction=reduction)
             loss_m_list.append(l)
             log[f"loss_m_{i}"] = _item(l, s)
         if self.pred_masked_weight > 0:
@@ -177,7 +178,7 @@ class SpeechPretrainCriterion(nn.Module):
         targ_u_list = model.get_targets(None, net_output, False)
         loss_u_list = []
         for i, (lu, tu) in enumerate(zip(logp_u_list, targ_u_list)):
-            l = F.cross_entropy(lu, tu, reduction=reduction)
+            l = Fn.cross_entropy_sum(lu, tu)[0] if reduce else F.cross_entropy(lu, tu, reduction=reduction)
             loss_u_list.append(l)
             log[f"loss_u_{i}"] = _item(l, s)
         if self.pred_nomask_weight > 0:
@@ -222,9 +223,13 @@ class TextPretrainCriterion(nn.Module):
     def forward(self, model, sample, reduce=True):
         s = self.sync_logging
         net_output, codebook_out, encoder_output = model(**sample["net_input"])
-        lprobs = model.get_normalized_probs(net_output, log_probs=True)
-        bart_loss = F.nll_loss(lprobs.view(-1, lprobs.size(-1)), sample["target"].view(-1), ignore_index=self.padding_idx,
-                               reduction="sum" if reduce else "none")
+        if reduce:   # fused log-softmax + NLL + logit gradient on the decoder logits (one kernel)
+            logits = net_output[0]
+            bart_loss = Fn.cross_entropy_sum(logits.reshape(-1, logits.size(-1)), sample["target"].view(-1), 0.0, self.padding_idx)[0]
+        else:
+            lprobs = model.get_normalized_probs(net_output, log_probs=True)
+            bart_loss = F.nll_loss(lprobs.view(-1, lprobs.size(-1)), sample["target"].view(-1), ignore_index=self.padding_idx,
+                                   reduction="sum" if reduce else "none")
         sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
         loss = self.bart_weight * bart_loss
         log = {"loss": _item(loss, s), "ntokens": sample["ntokens"], "nsentences": sample["target"].size(0),
@@ -285,9 +290,14 @@ class SpeechtoTextLoss(nn.Module):
         net_output_decoder, net_output = model(**sample["net_input"])
         loss_ce = nll = loss_ctc = None
         if self.ce_weight > 0:
-            lprobs = model.get_normalized_probs(net_output_decoder, log_probs=True)
-            loss_ce, nll = label_smoothed_nll_loss(lprobs.view(-1, lprobs.size(-1)), sample["target"].view(-1), self.eps,
-                                                   ignore_index=self.padding_idx, reduce=reduce)
+            if reduce:
+                logits = net_output_decoder[0]
+                loss_ce, nll = Fn.cross_entropy_sum(logits.reshape(-1, logits.size(-1)), sample["target"].view(-1), self.eps,
+                                                    self.padding_idx)
+            else:
+                lprobs = model.get_normalized_probs(net_output_decoder, log_probs=True)
+                loss_ce, nll = label_smoothed_nll_loss(lprobs.view(-1, lprobs.size(-1)), sample["target"].view(-1), self.eps,
+                                                       ignore_index=self.padding_idx, reduce=reduce)
         if self.ctc_weight > 0:
             loss_ctc = self.compute_loss_ctc(model, net_output, sample)
         if self.ce_weight > 0 and self.ctc_weight > 0:

@@ -229,7 +229,8 @@ template <typename T>
 __global__ void cross_entropy_kernel(const T* __restrict__ logits, const int32_t* __restrict__ target,
                                      float* __restrict__ loss_sum, float* __restrict__ nll_sum,
                                      T* __restrict__ dlogits, long long rows, int V, long long ld, float eps,
-                                     int ignore_index, float grad_scale) {
+                                     int ignore_index, float grad_scale, float* __restrict__ row_loss,
+                                     float* __restrict__ row_nll) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -239,12 +240,12 @@ __global__ void cross_entropy_kernel(const T* __restrict__ logits, const int32_t
   float mx = -INFINITY;
   for (int c = lane; c < V; c += 64) mx = fmaxf(mx, Elem<T>::to_f(lrow[c]));
   mx = wave_max(mx);
-  float se = 0.f, sl = 0.f;
+  float se = 0.f, sl = 0.f, nf = 0.f;   // nf: classes with a finite logit (-inf = excluded class: no smoothing mass either)
   for (int c = lane; c < V; c += 64) {
     const float l = Elem<T>::to_f(lrow[c]);
-    if (l != -INFINITY) { se += __expf(l - mx); sl += l; }
+    if (l != -INFINITY) { se += __expf(l - mx); sl += l; nf += 1.f; }
   }
-  se = wave_sum(se); sl = wave_sum(sl);
+  se = wave_sum(se); sl = wave_sum(sl); nf = wave_sum(nf);
   const float lse = mx + __logf(se);
   // fairseq label_smoothed_nll_loss (speech_to_text_loss.py:93-110):
   //   nll = -lprob[tgt]; smooth = -sum_c lprob[c]; loss = (1-eps-eps_i)*nll + eps_i*smooth, eps_i = eps/(V-1)
@@ -252,11 +253,15 @@ __global__ void cross_entropy_kernel(const T* __restrict__ logits, const int32_t
     const float lt = Elem<T>::to_f(lrow[tgt]);
     const float nll = lse - lt;
     const float eps_i = V > 1 ? eps / (float)(V - 1) : 0.f;
-    const float smooth = (float)V * lse - sl;
+    const float smooth = nf * lse - sl;
     if (lane == 0) {
-      atomicAdd(loss_sum, (1.f - eps - eps_i) * nll + eps_i * smooth);
-      if (nll_sum) atomicAdd(nll_sum, nll);
+      const float l = (1.f - eps - eps_i) * nll + eps_i * smooth;
+      if (row_loss) { row_loss[row] = l; if (row_nll) row_nll[row] = nll; }   // per-row outputs: deterministic caller-side sum
+      else { atomicAdd(loss_sum, l); if (nll_sum) atomicAdd(nll_sum, nll); }
     }
+  } else if (lane == 0 && row_loss) {
+    row_loss[row] = 0.f;
+    if (row_nll) row_nll[row] = 0.f;
   }
   if (dlogits) {
     T* drow = dlogits + row * ld;
@@ -266,8 +271,8 @@ __global__ void cross_entropy_kernel(const T* __restrict__ logits, const int32_t
       if (!skip) {
         const float l = Elem<T>::to_f(lrow[c]);
         const float p = l == -INFINITY ? 0.f : __expf(l - lse);
-        // d/dl_c [(1-eps-eps_i)*(lse - l_t) + eps_i*(V*lse - sum l)] = (1-eps-eps_i)(p - [c==t]) + eps_i (V p - 1)
-        g = (1.f - eps - eps_i) * (p - (c == tgt ? 1.f : 0.f)) + eps_i * ((float)V * p - 1.f);
+        // d/dl_c [(1-eps-eps_i)*(lse - l_t) + eps_i*(nf*lse - sum l)] = (1-eps-eps_i)(p - [c==t]) + eps_i (nf p - 1)
+        g = (1.f - eps - eps_i) * (p - (c == tgt ? 1.f : 0.f)) + eps_i * (nf * p - 1.f);
         if (l == -INFINITY) g = 0.f;
       }
       drow[c] = Elem<T>::from_f(g * grad_scale);
@@ -487,8 +492,20 @@ extern "C" int st5_cross_entropy(const void* logits, const int32_t* target, floa
   if (rows == 0) return ST5_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((rows + 3) / 4));
-  DISPATCH(dtype, hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)logits, target, loss_sum, nll_sum, (bf16_t*)dlogits, (long long)rows, V, (long long)ld, label_smoothing, ignore_index, grad_scale),
-           hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, dim3(256), 0, s, (const float*)logits, target, loss_sum, nll_sum, (float*)dlogits, (long long)rows, V, (long long)ld, label_smoothing, ignore_index, grad_scale));
+  DISPATCH(dtype, hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)logits, target, loss_sum, nll_sum, (bf16_t*)dlogits, (long long)rows, V, (long long)ld, label_smoothing, ignore_index, grad_scale, (float*)nullptr, (float*)nullptr),
+           hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, dim3(256), 0, s, (const float*)logits, target, loss_sum, nll_sum, (float*)dlogits, (long long)rows, V, (long long)ld, label_smoothing, ignore_index, grad_scale, (float*)nullptr, (float*)nullptr));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_cross_entropy_rows(const void* logits, const int32_t* target, float* row_loss, float* row_nll,
+                                      void* dlogits, int64_t rows, int32_t V, int64_t ld, float label_smoothing,
+                                      int32_t ignore_index, float grad_scale, int dtype, void* stream) {
+  if (!logits || !target || !row_loss || rows < 0 || V <= 0 || ld < V) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  DISPATCH(dtype, hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)logits, target, (float*)nullptr, (float*)nullptr, (bf16_t*)dlogits, (long long)rows, V, (long long)ld, label_smoothing, ignore_index, grad_scale, row_loss, row_nll),
+           hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, dim3(256), 0, s, (const float*)logits, target, (float*)nullptr, (float*)nullptr, (float*)dlogits, (long long)rows, V, (long long)ld, label_smoothing, ignore_index, grad_scale, row_loss, row_nll));
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

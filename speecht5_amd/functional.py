@@ -689,6 +689,52 @@ def ffn(x, residual, fc1, fc2, act=ACT_GELU, p_act=0.0, p_out=0.0):
 
 
 # -------------------------------------------------------------------------------------------------
+# (Label-smoothed) cross entropy, summed over rows: log-softmax, gather, smoothing term and the logit gradient in one
+# kernel (speech_pretrain_criterion.py:98-141, text_pretrain_criterion.py:56-60, speech_to_text_loss.py:93-110)
+# -------------------------------------------------------------------------------------------------
+class CrossEntropySumFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, eps, ignore_index):
+        rows, V = logits.shape
+        dev = logits.device
+        ld = logits.stride(0)
+        assert logits.stride(1) == 1 and ld >= V
+        t32 = target.to(torch.int32)
+        row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
+        row_nll = torch.empty(rows, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad[0]
+        dlogits = torch.empty(rows, ld, dtype=logits.dtype, device=dev) if need else None
+        hip.check(hip.lib().st5_cross_entropy_rows(logits.data_ptr(), t32.data_ptr(), row_loss.data_ptr(), row_nll.data_ptr(),
+                                                   hip.ptr(dlogits), rows, V, ld, float(eps),
+                                                   -1 if ignore_index is None else int(ignore_index), 1.0, _dt(logits),
+                                                   hip.stream()), "st5_cross_entropy_rows")
+        ctx.save_for_backward(dlogits)
+        ctx.V = V
+        nll = row_nll.sum()
+        ctx.mark_non_differentiable(nll)
+        return row_loss.sum(), nll
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_nll):
+        (dlogits,) = ctx.saved_tensors
+        g = dlogits[:, :ctx.V] if dlogits.shape[1] != ctx.V else dlogits
+        return g * g_loss.to(g.dtype), None, None, None
+
+
+def cross_entropy_sum(logits, target, label_smoothing=0.0, ignore_index=None):
+    """logits [rows, V] (fp32 or the compute dtype; -inf entries allowed), target int64 [rows] -> (sum of row losses,
+    sum of row NLLs), both fp32 scalars on the device; rows whose target is ignore_index (or negative) contribute 0.
+    loss_r = (1 - eps - eps_i) nll_r + eps_i smooth_r with eps_i = eps / (V - 1) (fairseq label_smoothed_nll_loss)."""
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        logits = logits.float()
+    if logits.shape[0] == 0:
+        z = logits.sum()
+        return z, z.detach()
+    return CrossEntropySumFunction.apply(logits if logits.stride(-1) == 1 else logits.contiguous(), target, float(label_smoothing),
+                                         ignore_index)
+
+
+# -------------------------------------------------------------------------------------------------
 # LayerNorm
 # -------------------------------------------------------------------------------------------------
 class LayerNormFunction(torch.autograd.Function):

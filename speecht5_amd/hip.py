@@ -98,6 +98,8 @@ _SIGS = {
     "st5_pad_time": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "st5_cross_entropy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,
                                   c_float, c_int32, c_float, c_int, c_void_p]),
+    "st5_cross_entropy_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,
+                                  c_float, c_int32, c_float, c_int, c_void_p]),
     "st5_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                               c_int32, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "st5_multi_transpose_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),

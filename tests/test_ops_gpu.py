@@ -12,6 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from speecht5_amd import hip  # noqa: E402
+from speecht5_amd import functional as Fn  # noqa: E402
 
 DTYPES = [torch.float32, torch.bfloat16]
 
@@ -455,3 +456,39 @@ def test_channel_mask(cuda, dtype):
     g = torch.randn(B, T, C)
     y.backward(dev(g, dtype, cuda))
     close(X.grad, rt(g, dtype).masked_fill(m.unsqueeze(1).expand(-1, T, -1), 0.0), dtype, what="channel mask bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,V,eps", [(37, 505, 0.0), (130, 83, 0.1), (8, 10003, 0.1), (0, 7, 0.0)])
+def test_cross_entropy_sum_function(cuda, dtype, rows, V, eps):
+    """functional.cross_entropy_sum (st5_cross_entropy_rows: per-row losses, caller-side sum) vs the reference's
+    label_smoothed_nll_loss on log_softmax (speech_to_text_loss.py:93-110), with -inf logits and ignored rows."""
+    torch.manual_seed(rows + V)
+    x = torch.randn(rows, V) * 3
+    if rows > 2:
+        x[1, 3] = float("-inf")
+    t = torch.randint(0, V, (rows,))
+    pad = 1
+    if rows > 4:
+        t[4] = pad
+    X = dev(x, dtype, cuda).requires_grad_(True)
+    loss, nll = Fn.cross_entropy_sum(X, t.to(cuda), eps, pad)
+    (loss * 0.5).backward()
+    xr = rt(x, dtype).requires_grad_(True)
+    lp = F.log_softmax(xr, -1)
+    nl = -lp.gather(1, t[:, None])
+    finite = torch.isfinite(lp)
+    sm = -(torch.where(finite, lp, torch.zeros_like(lp))).sum(-1, keepdim=True)
+    keep = (t != pad)[:, None]
+    nl, sm = nl * keep, sm * keep
+    eps_i = eps / (V - 1)
+    ref = (1 - eps - eps_i) * nl.sum() + eps_i * sm.sum()
+    if rows:
+        (ref * 0.5).backward()
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-4
+    assert abs(loss.item() - ref.item()) <= tol * max(1.0, abs(ref.item()))
+    assert abs(nll.item() - nl.sum().item()) <= tol * max(1.0, abs(nl.sum().item()))
+    if rows:
+        g = X.grad.float().cpu()
+        gr = torch.nan_to_num(xr.grad, nan=0.0)
+        assert (g - gr).abs().max().item() <= tol * max(1e-3, gr.abs().max().item()) + (1e-2 if dtype == torch.bfloat16 else 1e-6)
