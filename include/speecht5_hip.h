@@ -219,6 +219,16 @@ int st5_unfold_rows(const float* wav, void* out, int32_t B, int32_t S, int32_t k
 int st5_pad_time(const void* src, void* dst, int32_t B, int32_t T, int32_t C, int32_t pad_l, int32_t pad_r,
                  int dtype, void* stream);
 
+/* ---- log-mel front end of the input pipeline (data/speech_dataset.py:142-181 `logmelfilterbank`: librosa.stft
+ *      n_fft 1024 / hop 256 / periodic Hann / centred with reflect padding, |.|, 80 Slaney mel filters, log10 floor 1e-10).
+ *      The two matrix products (windowed DFT basis, mel filterbank) are st5_gemm calls in fp32; these are the pieces around them.
+ *      st5_stft_frames: out fp32 [B * L, n_fft], L = 1 + S / hop, out[(b,l), j] = wav[b, reflect(l*hop + j - n_fft/2)].
+ *      st5_stft_magnitude: reim fp32 [rows, 2*ldh] (real parts in columns [0,nbins), imaginary in [ldh, ldh+nbins)) ->
+ *      mag fp32 [rows, ldh] = sqrt(re^2 + im^2), columns >= nbins zero.  st5_log10_floor: y = log10(max(x, floor)). */
+int st5_stft_frames(const float* wav, float* out, int32_t B, int32_t S, int32_t n_fft, int32_t hop, void* stream);
+int st5_stft_magnitude(const float* reim, float* mag, int64_t rows, int32_t nbins, int32_t ldh, void* stream);
+int st5_log10_floor(const float* x, float* y, int64_t n, float floor_value, void* stream);
+
 /* ---- losses ---- */
 /* Row-wise (label-smoothed) cross entropy on logits [rows, ld] (dtype, first V cols valid).
  * loss_sum[0] += sum_r w_r * ((1-eps)*nll_r + eps/V... ) following speech_to_text_loss.py:93-110;

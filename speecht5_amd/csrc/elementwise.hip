@@ -281,6 +281,39 @@ __global__ void cross_entropy_kernel(const T* __restrict__ logits, const int32_t
   }
 }
 
+// ---- log-mel front end (speech_dataset.py:142-181): framing with librosa's centred reflect padding, |STFT|, log10 ----
+// out[(b, l), j] = wav[b, reflect(l * hop + j - n_fft / 2)], reflect(i) = -i below 0, 2 (S - 1) - i from S on
+__global__ void stft_frames_kernel(const float* __restrict__ wav, float* __restrict__ out, int S, int n_fft, int hop, int L,
+                                   long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % n_fft);
+    const long long row = i / n_fft;
+    const int l = (int)(row % L);
+    const long long b = row / L;
+    int t = l * hop + j - n_fft / 2;
+    t = t < 0 ? -t : t;
+    t = t >= S ? 2 * (S - 1) - t : t;
+    out[i] = wav[b * S + t];
+  }
+}
+// reim [rows, 2 * ldh]: real parts in columns [0, nbins), imaginary parts in [ldh, ldh + nbins) -> mag [rows, ldh] (pad 0)
+__global__ void stft_magnitude_kernel(const float* __restrict__ reim, float* __restrict__ mag, int nbins, int ldh, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % ldh);
+    const long long row = i / ldh;
+    float v = 0.f;
+    if (n < nbins) {
+      const float re = reim[row * 2 * ldh + n], im = reim[row * 2 * ldh + ldh + n];
+      v = sqrtf(re * re + im * im);
+    }
+    mag[i] = v;
+  }
+}
+__global__ void log10_floor_kernel(const float* __restrict__ x, float* __restrict__ y, float floor_, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = log10f(fmaxf(x[i], floor_));
+}
+
 float* g_scratch = nullptr;  // 2048-float device scratch for block partials (lazily allocated)
 float* scratch() {
   if (!g_scratch) { if (hipMalloc(&g_scratch, 2048 * sizeof(float)) != hipSuccess) return nullptr; }
@@ -506,6 +539,30 @@ extern "C" int st5_cross_entropy_rows(const void* logits, const int32_t* target,
   dim3 grid((unsigned)((rows + 3) / 4));
   DISPATCH(dtype, hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)logits, target, (float*)nullptr, (float*)nullptr, (bf16_t*)dlogits, (long long)rows, V, (long long)ld, label_smoothing, ignore_index, grad_scale, row_loss, row_nll),
            hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, dim3(256), 0, s, (const float*)logits, target, (float*)nullptr, (float*)nullptr, (float*)dlogits, (long long)rows, V, (long long)ld, label_smoothing, ignore_index, grad_scale, row_loss, row_nll));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+extern "C" int st5_stft_frames(const float* wav, float* out, int32_t B, int32_t S, int32_t n_fft, int32_t hop, void* stream) {
+  if (!wav || !out || B <= 0 || n_fft <= 0 || n_fft % 2 || hop <= 0 || S <= n_fft / 2) return ST5_ERR_ARG;
+  const int L = 1 + S / hop;
+  const long long total = (long long)B * L * n_fft;
+  hipLaunchKernelGGL(stft_frames_kernel, grid_for(total), dim3(256), 0, (hipStream_t)stream, wav, out, S, n_fft, hop, L, total);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_stft_magnitude(const float* reim, float* mag, int64_t rows, int32_t nbins, int32_t ldh, void* stream) {
+  if (!reim || !mag || rows < 0 || nbins <= 0 || ldh < nbins) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  const long long total = (long long)rows * ldh;
+  hipLaunchKernelGGL(stft_magnitude_kernel, grid_for(total), dim3(256), 0, (hipStream_t)stream, reim, mag, nbins, ldh, total);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_log10_floor(const float* x, float* y, int64_t n, float floor_value, void* stream) {
+  if (!x || !y || n < 0 || !(floor_value > 0.f)) return ST5_ERR_ARG;
+  if (n == 0) return ST5_OK;
+  hipLaunchKernelGGL(log10_floor_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, x, y, floor_value, (long long)n);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
