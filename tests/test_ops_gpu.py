@@ -492,3 +492,51 @@ def test_cross_entropy_sum_function(cuda, dtype, rows, V, eps):
         g = X.grad.float().cpu()
         gr = torch.nan_to_num(xr.grad, nan=0.0)
         assert (g - gr).abs().max().item() <= tol * max(1e-3, gr.abs().max().item()) + (1e-2 if dtype == torch.bfloat16 else 1e-6)
+
+
+@pytest.mark.parametrize("block", ["linear", "ffn"])
+def test_layernorm_backward_hands_dropped_gradient_to_the_linear_in_front(cuda, block, monkeypatch):
+    """Post-LN block  y = LN(x + drop(Linear(x)))  (transformer_layer.py:122-134): the LayerNorm backward kernel's second
+    output dX * mask replaces the dropout kernel of the Linear's backward.  Same seed with and without the hand-off must
+    give bit-identical gradients, and the hand-off must actually have been used."""
+    dt = torch.bfloat16
+    Fn.set_compute_dtype(dt)
+    try:
+        torch.manual_seed(11)
+        M, d, Fd = 300, 256, 512
+        x0 = torch.randn(M, d).to(dt).to(cuda)
+        lin = torch.nn.Linear(d, d).to(cuda)
+        fc1, fc2 = torch.nn.Linear(d, Fd).to(cuda), torch.nn.Linear(Fd, d).to(cuda)
+        lw, lb = torch.randn(d, device=cuda).requires_grad_(True), torch.randn(d, device=cuda).requires_grad_(True)
+        gout = torch.randn(M, d).to(dt).to(cuda)
+        params = [lw, lb] + list(lin.parameters()) + list(fc1.parameters()) + list(fc2.parameters())
+
+        def run():
+            Fn.manual_seed(99)
+            Fn.weight_cache.clear()
+            for p in params:
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            if block == "linear":
+                y = Fn.linear(x, lin.weight, lin.bias, residual=x, dropout_p=0.3)
+            else:
+                y = Fn.ffn(x, x, fc1, fc2, p_act=0.0, p_out=0.3)
+            out = Fn.layer_norm(y, lw, lb)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            return [x.grad.clone()] + [p.grad.clone() for p in params if p.grad is not None]
+
+        calls = []
+        orig = Fn._dropout
+        monkeypatch.setattr(Fn, "_dropout", lambda x, p, s: (calls.append(1), orig(x, p, s))[1])
+        with_handoff = run()
+        n_with = len(calls)
+        monkeypatch.setattr(Fn, "_tag_dropout_output", lambda *a: None)      # no tag -> LayerNorm emits no second output
+        without = run()
+        assert n_with == 0 and len(calls) == 1
+        assert len(with_handoff) == len(without) >= 4
+        for a, b in zip(with_handoff, without):
+            assert torch.equal(a, b)
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.weight_cache.clear()
