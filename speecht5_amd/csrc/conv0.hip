@@ -66,14 +66,16 @@ template <int KW>
 __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ wav, float* __restrict__ part, int S,
                                                             int L, int k, int stride, int nch) {
   extern __shared__ float seg[];
-  __shared__ float red[MAXMOM];
+  // one slot per wave and moment, summed in a fixed order below: LDS atomics here would make the GroupNorm statistics --
+  // and through bf16 rounding every activation after them -- depend on wave arrival order (run-to-run differences)
+  __shared__ float red[4][MAXMOM];
   const int b = blockIdx.y, ch = blockIdx.x, t0 = ch * TCH;
   const int nt = min(TCH, L - t0);
   stage_wav(seg, wav, b, S, t0, nt, k, stride);
   const int nm = nmom(k);
-  for (int i = threadIdx.x; i < nm; i += 256) red[i] = 0.f;
   __syncthreads();
   const int t = threadIdx.x;
+  const int wv = threadIdx.x >> 6;
   float x[KW];
 #pragma unroll
   for (int j = 0; j < KW; ++j) x[j] = (t < nt && j < k) ? seg[t * stride + j] : 0.f;
@@ -82,18 +84,19 @@ __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restr
   for (int j = 0; j < KW; ++j) {
     if (j < k) {
       const float s = wave_sum(x[j]);
-      if (lane == 0) atomicAdd(&red[j], s);
+      if (lane == 0) red[wv][j] = s;
 #pragma unroll
       for (int jp = j; jp < KW; ++jp) {
         if (jp < k) {
           const float r = wave_sum(x[j] * x[jp]);
-          if (lane == 0) atomicAdd(&red[ridx(k, j, jp)], r);
+          if (lane == 0) red[wv][ridx(k, j, jp)] = r;
         }
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nm; i += 256) part[((long long)b * nch + ch) * nm + i] = red[i];
+  for (int i = threadIdx.x; i < nm; i += 256)
+    part[((long long)b * nch + ch) * nm + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 // mom[b][nmom] (double) = sum over chunks
 __global__ __launch_bounds__(256) void conv0_moments_final_kernel(const float* __restrict__ part, double* __restrict__ mom,

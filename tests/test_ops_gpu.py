@@ -540,3 +540,31 @@ def test_layernorm_backward_hands_dropped_gradient_to_the_linear_in_front(cuda, 
     finally:
         Fn.set_compute_dtype(torch.float32)
         Fn.weight_cache.clear()
+
+
+def test_conv0_statistics_are_run_to_run_deterministic(cuda):
+    """The GroupNorm statistics of conv layer 0 feed every later activation through bf16 rounding, so they must not depend
+    on wave arrival order (a fixed-order reduction, no fp32 atomics): repeated launches, interleaved with other work that
+    shifts the timing, give bit-identical (mean, rstd) and outputs."""
+    torch.manual_seed(3)
+    B, S, C, k, stride = 4, 48000, 512, 10, 5
+    wav = (torch.randn(B, S) * 0.3).to(cuda)
+    w = (torch.randn(C, k) * math.sqrt(2.0 / k)).to(cuda)
+    g, b = (torch.rand(C) + 0.5).to(cuda), (torch.randn(C) * 0.1).to(cuda)
+    Lo = (S - k) // stride + 1
+    Ld = hip.lib()
+    ws = hip.workspace(Ld.st5_conv0_ws_bytes(B, S, C, k, stride), cuda)
+    first = None
+    for i in range(25):
+        if i % 3:
+            torch.randn(1 << (14 + i % 5), device=cuda).sum()      # unrelated kernels in between
+        out = torch.empty(B, Lo, C, dtype=torch.bfloat16, device=cuda)
+        stats = torch.empty(B, C, 2, device=cuda)
+        hip.check(Ld.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                           stats.data_ptr(), ws.data_ptr(), B, S, C, k, stride, 1e-5, hip.BF16, hip.stream()),
+                  "conv0 fwd")
+        torch.cuda.synchronize()
+        if first is None:
+            first = (stats.clone(), out.clone())
+        else:
+            assert torch.equal(stats, first[0]) and torch.equal(out, first[1]), f"launch {i} differs"
