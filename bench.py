@@ -160,7 +160,10 @@ def main():
     except Exception:
         traffic = None
     alg_bytes = hip.profiler.nt_bytes_per_launch() if hasattr(hip.profiler, "nt_bytes_per_launch") else None
-    roof = {"bound": "mfma", "kernel": f"gemm_nt_glds_kernel<{a.dtype}> (Linear / conv / attention-projection forward + data-gradient form)",
+    roof = {"bound": "mfma", "kernel": f"gemm_nt_glds_kernel<{a.dtype}> (Linear / conv / attention-projection forward + data-gradient form; "
+                      "the 7 conv feature-extractor launches of this form run on gemm_nt256_kernel)",
+            "note": "launch durations are measured inside the step, i.e. beside the weight-gradient stream's kernels "
+                    "(ST5_WGRAD_STREAM=0 gives the isolated rate, ~8 % higher)",
             "achieved": round(flops / secs / 1e12, 2) if secs > 0 else None, "peak": peak, "unit": "TFLOP/s",
             "frac": round(flops / secs / 1e12 / peak, 4) if secs > 0 else None, "traffic": traffic,
             "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)" if traffic else None,
