@@ -105,6 +105,11 @@ int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
                       void* dx_dropped /* optional 2nd output dx * dropout_mask(seed, row*cols + c): the gradient of the
                                           dropout-epilogue Linear in front of this LayerNorm (cols % 4 == 0) */,
                       float drop_p, uint64_t drop_seed, int dtype, void* stream);
+/* Batched dgamma / dbeta reductions: while enabled, st5_layernorm_bwd leaves its block partials in an internal arena and
+ * st5_layernorm_flush(stream) folds all pending LayerNorms' partials into their dgamma / dbeta with ONE launch (same stream
+ * as the st5_layernorm_bwd calls; the owner of the gradient buffers flushes wherever gradients must be complete). */
+int st5_layernorm_defer(int enabled, void* stream);
+int st5_layernorm_flush(void* stream);
 int64_t st5_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols);
 
 /* ---- attention probabilities (multihead_attention.py:343-386) ----

@@ -328,6 +328,46 @@ __global__ __launch_bounds__(1024) void ln_bwd_final_kernel(const float* __restr
   }
 }
 
+// Deferred form of the reduction above: while st5_layernorm_defer is on, every LayerNorm backward leaves its block partials
+// in an arena slot and ONE launch per flush folds the partials of all pending LayerNorms into their dgamma / dbeta (the
+// training step has ~86 LayerNorm backwards, each followed by a 7 us reduction launch).  Descriptors travel as a kernel
+// argument; a block finds its descriptor by its block range.
+constexpr int LNF_MAX = 48;
+struct LnFinalDesc { const float* part; float* dgamma; float* dbeta; int nblk, cols, blk0, pad; };
+struct LnFinalArgs { LnFinalDesc d[LNF_MAX]; int n; };
+__global__ __launch_bounds__(1024) void ln_bwd_final_multi_kernel(const LnFinalArgs a) {
+  __shared__ float red[16][64];
+  int k = 0;
+  while (k + 1 < a.n && (int)blockIdx.x >= a.d[k + 1].blk0) ++k;
+  const LnFinalDesc d = a.d[k];
+  const int cl = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int c = ((int)blockIdx.x - d.blk0) * 64 + cl;     // index into [2][cols]
+  float s = 0.f;
+  if (c < 2 * d.cols)
+    for (int b = j; b < d.nblk; b += 16) s += d.part[(long long)b * 2 * d.cols + c];
+  red[j][cl] = s;
+  __syncthreads();
+  if (j == 0 && c < 2 * d.cols) {
+    s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += red[q][cl];
+    if (c < d.cols) { if (d.dgamma) d.dgamma[c] += s; }
+    else if (d.dbeta) d.dbeta[c - d.cols] += s;
+  }
+}
+bool g_ln_defer = false;
+LnFinalArgs g_ln_pending;
+int g_ln_blocks = 0;
+float* g_ln_arena = nullptr;
+size_t g_ln_arena_bytes = 0, g_ln_arena_used = 0;
+int ln_flush(hipStream_t s) {
+  if (g_ln_pending.n == 0) return ST5_OK;
+  hipLaunchKernelGGL(ln_bwd_final_multi_kernel, dim3((unsigned)g_ln_blocks), dim3(1024), 0, s, g_ln_pending);
+  g_ln_pending.n = 0; g_ln_blocks = 0; g_ln_arena_used = 0;
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
 int ln_blocks(long long rows) {
   long long n = (rows + 4 * RPW - 1) / (4 * RPW);
   return (int)(n < LN_MAX_BLOCKS ? (n < 1 ? 1 : n) : LN_MAX_BLOCKS);
@@ -522,6 +562,32 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
     const int nb = ln_blocks(rows);
     const bool pg = dgamma || dbeta;
     const size_t shm = pg ? (size_t)8 * cols * sizeof(float) : 0;
+    bool deferred = false;
+    if (pg && g_ln_defer) {
+      // the same parameter twice in one batch (two micro-batches) would race inside the batched reduction: fold first
+      for (int j = 0; j < g_ln_pending.n; ++j)
+        if ((dgamma && g_ln_pending.d[j].dgamma == dgamma) || (dbeta && g_ln_pending.d[j].dbeta == dbeta)) {
+          const int rc = ln_flush(s); if (rc) return rc; break;
+        }
+      const size_t need = ((size_t)nb * 2 * cols * sizeof(float) + 255) & ~(size_t)255;
+      if (g_ln_pending.n == LNF_MAX || g_ln_arena_used + need > g_ln_arena_bytes) {
+        const int rc = ln_flush(s); if (rc) return rc;
+        if (need > g_ln_arena_bytes) {
+          if (g_ln_arena) (void)hipFree(g_ln_arena);   // synchronises with in-flight users
+          size_t want = size_t(128) << 20;
+          while (want < need * 4) want *= 2;
+          if (hipMalloc(&g_ln_arena, want) != hipSuccess) { g_ln_arena = nullptr; g_ln_arena_bytes = 0; return ST5_ERR_LAUNCH; }
+          g_ln_arena_bytes = want;
+        }
+      }
+      ws = reinterpret_cast<char*>(g_ln_arena) + g_ln_arena_used;
+      g_ln_arena_used += need;
+      LnFinalDesc& d = g_ln_pending.d[g_ln_pending.n++];
+      d.part = reinterpret_cast<const float*>(ws); d.dgamma = dgamma; d.dbeta = dbeta; d.nblk = nb; d.cols = cols;
+      d.blk0 = g_ln_blocks; d.pad = 0;
+      g_ln_blocks += (2 * cols + 63) / 64;
+      deferred = true;
+    }
 #define LBV(TT, NV_)                                                                                                    \
   do {                                                                                                                  \
     if (pg) hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, true>), dim3(nb), dim3(256), shm, s, (const TT*)dy, (const TT*)x, gamma, \
@@ -539,7 +605,7 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
     if (dtype == ST5_BF16) LBV_T(bf16_t); else LBV_T(float);
 #undef LBV_T
 #undef LBV
-    if (pg) hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((2 * cols + 63) / 64), dim3(1024), 0, s, (const float*)ws, dgamma, dbeta, nb, cols);
+    if (pg && !deferred) hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((2 * cols + 63) / 64), dim3(1024), 0, s, (const float*)ws, dgamma, dbeta, nb, cols);
     HIP_CHECK_LAUNCH();
     return ST5_OK;
   }
@@ -569,6 +635,15 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
   }
   return ST5_OK;
 }
+
+/* Deferred dgamma / dbeta reductions (see ln_bwd_final_multi_kernel).  While enabled, the parameter gradients of
+ * st5_layernorm_bwd (vector path) are complete only after st5_layernorm_flush() on the same stream; disabling flushes. */
+extern "C" int st5_layernorm_defer(int enabled, void* stream) {
+  if (!enabled && g_ln_defer) { const int rc = ln_flush(reinterpret_cast<hipStream_t>(stream)); if (rc) return rc; }
+  g_ln_defer = enabled != 0;
+  return ST5_OK;
+}
+extern "C" int st5_layernorm_flush(void* stream) { return ln_flush(reinterpret_cast<hipStream_t>(stream)); }
 
 // out[c] (+)= scale * sum_r x[r, c]; uses an internal static workspace-free two-stage path via `ws`
 // passed through the trailing part of `out`?  No: colsum allocates nothing -- the caller provides

@@ -93,6 +93,7 @@ class FlatGradDataParallel:
             # all-reduce, finish()), so the per-GEMM slab reductions can be deferred and folded in one launch
             from . import hip
             hip.check(hip.lib().st5_gemm_defer_splitk(1, hip.stream()), "st5_gemm_defer_splitk")
+            hip.check(hip.lib().st5_layernorm_defer(1, hip.stream()), "st5_layernorm_defer")   # same idea for LayerNorm dgamma/dbeta
             # weight-gradient GEMMs of the transformer layers on their own stream (functional.set_wgrad_stream): their
             # gradient buffers have no other writer (no tied weights inside a layer)
             if os.environ.get("ST5_WGRAD_STREAM", "1") == "1":
@@ -123,6 +124,7 @@ class FlatGradDataParallel:
         """Gradients complete on the current stream: batched split-K reductions folded, weight-gradient stream joined."""
         from . import hip
         if self.flat.is_cuda:
+            hip.check(hip.lib().st5_layernorm_flush(hip.stream()), "st5_layernorm_flush")
             if Fn.wgrad_stream() is not None:
                 Fn.join_wgrad_stream()   # the deferred reductions belong to the side stream: folded there, then joined
             else:
@@ -141,6 +143,7 @@ class FlatGradDataParallel:
         if self.flat.is_cuda:
             Fn.set_wgrad_stream(None)
             Fn.set_attention_stream(None)
+            hip.check(hip.lib().st5_layernorm_defer(0, hip.stream()), "st5_layernorm_defer")
             hip.check(hip.lib().st5_gemm_defer_splitk(0, hip.stream()), "st5_gemm_defer_splitk")
         Fn.set_layer_boundary_hook(None)
 

@@ -50,6 +50,8 @@ _SIGS = {
                                   c_float, c_int, c_void_p]),
     "st5_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int64, c_int32, c_void_p, c_float, c_uint64, c_int, c_void_p]),
+    "st5_layernorm_defer": (c_int, [c_int, c_void_p]),
+    "st5_layernorm_flush": (c_int, [c_void_p]),
     "st5_layernorm_bwd_ws_bytes": (c_int64, [c_int64, c_int32]),
     "st5_softmax_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                 c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, c_int, c_void_p]),

@@ -568,3 +568,40 @@ def test_conv0_statistics_are_run_to_run_deterministic(cuda):
             first = (stats.clone(), out.clone())
         else:
             assert torch.equal(stats, first[0]) and torch.equal(out, first[1]), f"launch {i} differs"
+
+
+def test_layernorm_deferred_parameter_gradients(cuda):
+    """st5_layernorm_defer / st5_layernorm_flush: block partials of several LayerNorm backwards folded by one launch, the
+    same parameter twice in a batch (two micro-batches) included -- equal to the immediate per-call reduction."""
+    torch.manual_seed(17)
+    L = hip.lib()
+    dt = torch.bfloat16
+    shapes = [(500, 768), (2100, 768), (64, 256), (500, 768)]      # the last one reuses the first one's parameters
+    xs = [dev(torch.randn(r, c), dt, cuda) for r, c in shapes]
+    dys = [dev(torch.randn(r, c), dt, cuda) for r, c in shapes]
+    gam = [torch.randn(c, device=cuda) for _, c in shapes]
+    means = [torch.randn(r, device=cuda) * 0.1 for r, _ in shapes]
+    rstds = [torch.rand(r, device=cuda) + 0.5 for r, _ in shapes]
+
+    def run(defer):
+        dG = [torch.zeros(c, device=cuda) for _, c in shapes[:3]]
+        dB = [torch.zeros(c, device=cuda) for _, c in shapes[:3]]
+        hip.check(L.st5_layernorm_defer(1 if defer else 0, hip.stream()), "defer")
+        try:
+            for i, (r, c) in enumerate(shapes):
+                p = 0 if i == 3 else i
+                dx = torch.empty_like(xs[i])
+                ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(r, c), cuda)
+                hip.check(L.st5_layernorm_bwd(dys[i].data_ptr(), xs[i].data_ptr(), gam[p].data_ptr(), means[i].data_ptr(),
+                                              rstds[i].data_ptr(), dx.data_ptr(), dG[p].data_ptr(), dB[p].data_ptr(), ws.data_ptr(),
+                                              r, c, None, 0.0, 0, hip.BF16, hip.stream()), "ln bwd")
+            hip.check(L.st5_layernorm_flush(hip.stream()), "flush")
+        finally:
+            hip.check(L.st5_layernorm_defer(0, hip.stream()), "defer off")
+        torch.cuda.synchronize()
+        return dG, dB
+
+    a, b = run(False), run(True)
+    for u, v in zip(a[0] + a[1], b[0] + b[1]):
+        assert torch.equal(u, v)
+    assert a[0][0].abs().max().item() > 0
