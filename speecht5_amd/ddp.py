@@ -93,7 +93,8 @@ class FlatGradDataParallel:
             # all-reduce, finish()), so the per-GEMM slab reductions can be deferred and folded in one launch
             from . import hip
             hip.check(hip.lib().st5_gemm_defer_splitk(1, hip.stream()), "st5_gemm_defer_splitk")
-            hip.check(hip.lib().st5_layernorm_defer(1, hip.stream()), "st5_layernorm_defer")   # same idea for LayerNorm dgamma/dbeta
+            if os.environ.get("ST5_LN_DEFER", "1") == "1":   # same idea for the LayerNorm dgamma/dbeta reductions
+                hip.check(hip.lib().st5_layernorm_defer(1, hip.stream()), "st5_layernorm_defer")
             # weight-gradient GEMMs of the transformer layers on their own stream (functional.set_wgrad_stream): their
             # gradient buffers have no other writer (no tied weights inside a layer)
             if os.environ.get("ST5_WGRAD_STREAM", "1") == "1":
