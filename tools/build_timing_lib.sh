@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds gpurun_out/libspeecht5_hip_timing.so: the library with -DGEMM_TIMING (s_memtime phase probes in the NT kernels).
+# Builds speecht5_amd/libspeecht5_hip_timing.so (git-ignored): the library with -DGEMM_TIMING (s_memtime phase probes in the NT kernels).
 # Use it with ST5_HIP_LIB=<path> python tools/gemm_timing.py
 set -e
 cd "$(dirname "$0")/../speecht5_amd/csrc"
