@@ -35,6 +35,29 @@ def test_product_filterbank_equals_oracle():
     assert np.allclose(a.sum(1) * (8000.0 / 512), 1.0, atol=0.05)
 
 
+def test_product_dft_basis_is_the_windowed_rfft():
+    """Host logic of features.LogMelFilterBank (no GPU): frames @ basis^T = [Re | Im] of rfft(frames * periodic Hann), the
+    padding columns of the basis / filterbank are zero, and basis + filterbank + log10 reproduce the oracle on CPU."""
+    from speecht5_amd.features import LogMelFilterBank
+    fb = LogMelFilterBank(torch.device("cpu"))
+    assert fb.basis.shape == (2 * 520, 1024) and fb.mel.shape == (80, 520)
+    rng = np.random.default_rng(0)
+    frames = rng.standard_normal((7, 1024))
+    reim = frames @ fb.basis.double().numpy().T
+    ref = np.fft.rfft(frames * O.hann_periodic(1024), axis=1)
+    assert np.abs(reim[:, :513] - ref.real).max() < 1e-4 and np.abs(reim[:, 520:520 + 513] - ref.imag).max() < 1e-4
+    assert np.all(reim[:, 513:520] == 0) and np.all(reim[:, 520 + 513:] == 0)
+    assert torch.all(fb.mel[:, 513:] == 0)
+    # the whole pipeline with numpy matmuls in place of st5_gemm
+    wav = (0.2 * rng.standard_normal(3000)).astype(np.float32)
+    x = np.pad(wav.astype(np.float64), (512, 512), mode="reflect")
+    fr = np.stack([x[i * 256:i * 256 + 1024] for i in range(1 + len(wav) // 256)])
+    ri = fr @ fb.basis.double().numpy().T
+    mag = np.sqrt(ri[:, :520] ** 2 + ri[:, 520:] ** 2)
+    out = np.log10(np.maximum(mag @ fb.mel.double().numpy().T, 1e-10))
+    assert np.abs(out - O.logmelfilterbank(wav)).max() < 1e-4
+
+
 @pytest.mark.gpu
 def test_gpu_logmel_matches_oracle_and_golden(cuda):
     from speecht5_amd.features import LogMelFilterBank
