@@ -115,8 +115,9 @@ def main():
 
     def step(i):
         ddp.zero_grad()
-        for s in micro:
-            task.train_step(s, model, crit, None, i, sync=False)
+        # --update-freq 2: gradients of the first micro-batch only accumulate (no_sync); the bucket all-reduces are
+        # launched from the backward of the LAST micro-batch, each bucket once, after its last local contribution
+        ddp.accumulate(micro, lambda s: task.train_step(s, model, crit, None, i, sync=False))
         ddp.finish()
         opt.step(grad_scale=1.0 / len(micro))
 

@@ -9,7 +9,13 @@
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
  *   - `dtype` is ST5_F32 (0) or ST5_BF16 (1): the element type of activations/weights;
  *     statistics, softmax, accumulators, biases, LayerNorm affine params and weight gradients are fp32;
- *   - return value 0 = ok, non-zero = ST5_ERR_* (argument / alignment / launch error).
+ *   - return value 0 = ok, non-zero = ST5_ERR_* (argument / alignment / launch error);
+ *   - threading / devices: the library is built for ONE process per GPU driven by ONE host thread (the reference's
+ *     execution model).  It keeps process-global mutable state -- the deferred split-K queue and
+ *     its slab arena (st5_gemm_defer_splitk / _flush_splitk; the arena is hipFree'd and re-allocated when it must
+ *     grow, which synchronises the device), per-stream split-K workspaces, the deferred LayerNorm reductions
+ *     (st5_layernorm_defer / _flush), the stream-fork event ring and the A/B switches (st5_gemm_set_*).  Calling it
+ *     from two host threads, or for two devices from one process, is NOT supported.
  */
 #ifndef SPEECHT5_HIP_H
 #define SPEECHT5_HIP_H
@@ -251,7 +257,8 @@ int st5_cross_entropy_rows(const void* logits, const int32_t* target, float* row
 
 /* ---- optimizer (fairseq `adam`: decoupled weight decay; README.md:107-115 flags) ----
  * One fused pass over the flat fp32 buffers: g' = g * grad_scale * min(1, max_norm / (sqrt(*gnorm_sq) * grad_scale));
- * m,v update; p = p*(1 - lr*wd) - lr/bc1 * m / (sqrt(v/bc2) + eps).  gnorm_sq is a DEVICE scalar (may be NULL). */
+ * m,v update; p = p*(1 - lr*wd) - lr*sqrt(bc2)/bc1 * m / (sqrt(v) + eps) (fairseq/optim/adam.py: eps is not bias-corrected;
+ * bc_i = 1 - beta_i^step).  gnorm_sq is a DEVICE scalar (may be NULL). */
 int st5_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
                   void* bf16_mirror /* optional bf16 [n]: receives the updated parameters in the compute dtype */, void* stream);

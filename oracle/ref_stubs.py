@@ -17,9 +17,11 @@ Two kinds of symbols are installed into `sys.modules`:
 * restatements of third-party pieces that are NOT under /root/reference
   (fairseq is an empty, un-pinned submodule: .gitmodules:1-3; espnet is an
   un-pinned pip dependency: SpeechT5/README.md:32).  Their published algorithms
-  are restated here following SURVEY.md Appendix A and cross-checked against the
-  independently written HuggingFace port where it covers them
-  (tests/test_oracle_vs_hf.py).
+  are restated here following SURVEY.md Appendix A; where the independently written
+  HuggingFace port covers a piece it was used as the cross-check (HiFi-GAN and the
+  log-mel front end have committed HF fixtures: tests/test_hifigan.py,
+  tests/test_logmel.py; the espnet / fairseq restatements below have no second
+  implementation in this image and are pinned only through the whole-model goldens).
 """
 import importlib.util
 import math

@@ -14,8 +14,6 @@ def _register():
     from . import criterions, speecht5, task  # noqa: F401
 
 
-try:
-    _register()
-except Exception as e:  # pragma: no cover  (torch missing etc.)
-    import warnings
-    warnings.warn(f"speecht5_amd registration failed: {e}")
+# Registration is the whole point of importing this package (`--user-dir`): a failure here must not be swallowed -- a job
+# would otherwise start with the task / arch / criterion names silently missing.
+_register()

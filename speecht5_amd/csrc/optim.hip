@@ -19,8 +19,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float c = max_norm / (norm + 1e-6f);
     coef *= c < 1.f ? c : 1.f;
   }
-  const float step = lr / bc1;
-  const float inv_bc2 = 1.f / sqrtf(bc2);
+  // fairseq/optim/adam.py: denom = sqrt(v) + eps (eps is NOT bias-corrected), step_size = lr * sqrt(bc2) / bc1
+  const float step = lr * sqrtf(bc2) / bc1;
   const long long nv = n / 4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       const float ge = gg[e] * coef;
       mm[e] = b1 * mm[e] + (1.f - b1) * ge;
       vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
-      const float denom = sqrtf(vv[e]) * inv_bc2 + eps;
+      const float denom = sqrtf(vv[e]) + eps;
       pp[e] = pp[e] * (1.f - lr * wd) - step * mm[e] / denom;
     }
     reinterpret_cast<f32x4*>(p)[i] = pp;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float mi = b1 * m[i] + (1.f - b1) * ge;
     const float vi = b2 * v[i] + (1.f - b2) * ge * ge;
     m[i] = mi; v[i] = vi;
-    p[i] = p[i] * (1.f - lr * wd) - step * mi / (sqrtf(vi) * inv_bc2 + eps);
+    p[i] = p[i] * (1.f - lr * wd) - step * mi / (sqrtf(vi) + eps);
     if (mirror) mirror[i] = (bf16_t)p[i];
   }
 }

@@ -16,6 +16,7 @@ the recipe needs --find-unused-parameters).  Same semantics here, re-designed fo
 xGMI note: the 8-GPU node is a full mesh of point-to-point links, so a ring all-reduce is bound
 by one link (~153 GB/s).  Buckets default to 64 MB so that several collectives are in flight during backward.
 """
+import contextlib
 import os
 
 import torch
@@ -25,6 +26,9 @@ from . import functional as Fn
 
 
 class _Trigger(torch.autograd.Function):
+    """Identity whose backward tells the owner that every gradient produced by the graph BEHIND this point (the layers
+    that run after it in the forward) is complete for this backward pass."""
+
     @staticmethod
     def forward(ctx, x, owner, bucket_id):
         ctx.owner, ctx.bucket_id = owner, bucket_id
@@ -45,24 +49,36 @@ class FlatGradDataParallel:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         # ST5_DDP_FORCE_COLLECTIVES=1 runs the bucketed async all-reduce path even in a 1-rank group (used to exercise the
         # RCCL stream / event plumbing on a single-GPU box; a 1-rank all-reduce leaves the data unchanged)
-        import os
         self.collectives = self.world > 1 or (os.environ.get("ST5_DDP_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
-        params, seen = [], set()
-        groups = bucket_groups if bucket_groups is not None else default_buckets(model)
-        self.module_bucket = {}
-        order = []
-        for bi, mods in enumerate(groups):
-            for m in mods:
-                self.module_bucket[id(m)] = bi
-                for p in _fusion_ordered_parameters(m):
-                    if id(p) not in seen and p.requires_grad:
-                        seen.add(id(p))
-                        order.append((bi, p))
+        groups = [g if isinstance(g, BucketGroup) else BucketGroup(list(g)) for g in
+                  (bucket_groups if bucket_groups is not None else default_buckets(model))]
         nb = len(groups)
-        for p in model.parameters():
-            if id(p) not in seen and p.requires_grad:
-                seen.add(id(p))
-                order.append((nb, p))
+        # a parameter belongs to bucket i only if every module that holds it lies inside group i: tied weights (the text
+        # embedding is shared by two pre-nets and a post-net) and everything outside the groups go to the final bucket,
+        # which only finish() reduces -- otherwise a late contribution could land in a bucket already handed to RCCL
+        sub_bucket = {}
+        for bi, g in enumerate(groups):
+            for m in g.modules:
+                for sub in m.modules():
+                    sub_bucket[id(sub)] = bi
+        owners = {}
+        for mod in model.modules():
+            for q in mod.parameters(recurse=False):
+                owners.setdefault(id(q), set()).add(sub_bucket.get(id(mod), nb))
+        self.module_bucket = {}
+        seen, order = set(), []
+        for bi, g in enumerate(groups):
+            for key in g.trigger_keys():
+                self.module_bucket[key] = bi
+            for m in g.modules:
+                for q in _fusion_ordered_parameters(m):
+                    if id(q) not in seen and q.requires_grad and owners.get(id(q), {nb}) == {bi}:
+                        seen.add(id(q))
+                        order.append((bi, q))
+        for q in model.parameters():
+            if id(q) not in seen and q.requires_grad:
+                seen.add(id(q))
+                order.append((nb, q))
         order.sort(key=lambda t: t[0])
         # matrices start on 64-element boundaries: 128-byte aligned rows in the bf16 parameter image (the GEMM loaders
         # fetch 128-byte row segments; 16-byte-only alignment made them straddle cache lines and cost ~10 % in the NT
@@ -86,7 +102,16 @@ class FlatGradDataParallel:
         self.buckets.append((start, total))
         self.params = [p for _, p in order]
         self.offsets = offs
-        self._launched = [None] * len(self.buckets)
+        # Gradient accumulation (--update-freq U): triggers only count during the LAST micro-batch of an update
+        # (`no_sync()` around the others), so a bucket is reduced once, after its last local contribution.
+        # Collective ORDER must be identical on every rank (RCCL matches collectives by issue order and the layer
+        # buckets all have the same size): buckets are launched strictly in index order -- bucket i goes out as soon as
+        # it AND every bucket before it has been reported ready -- and finish() launches the rest, again in index order.
+        # A rank that skipped a layer (LayerDrop, another modality) simply defers from that bucket on; it never reorders.
+        self._accumulating = False
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
+        self._works = []
         Fn.set_layer_boundary_hook(self._boundary)
         if dev.type == "cuda":
             # batched split-K reductions: this wrapper owns the points where gradients must be complete (bucket
@@ -115,8 +140,8 @@ class FlatGradDataParallel:
                 Fn.set_attention_stream(self._attn_side)
 
     # -- hooks -------------------------------------------------------------------------------------
-    def _boundary(self, x, module):
-        bi = self.module_bucket.get(id(module))
+    def _boundary(self, x, module, tag=None):
+        bi = self.module_bucket.get((id(module), tag))
         if bi is None or not self.collectives or not x.requires_grad:
             return x
         return _Trigger.apply(x, self, bi)
@@ -132,10 +157,43 @@ class FlatGradDataParallel:
                 hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")
 
     def _bucket_ready(self, bi):
-        if self._launched[bi] is None and self.collectives:
-            self._flush_splitk()   # the bucket's weight gradients may still be slabs awaiting their batched reduction
-            s, e = self.buckets[bi]
-            self._launched[bi] = dist.all_reduce(self.flat[s:e], group=self.pg, async_op=True)
+        """A layer trigger fired: bucket bi has received its last local contribution of this update."""
+        if not self.collectives or self._accumulating:
+            return
+        self._ready[bi] = True
+        self._launch_in_order(False)
+
+    def _launch_in_order(self, everything):
+        nb = len(self.buckets)
+        if self._next >= nb or not (everything or self._ready[self._next]):
+            return
+        # the buckets' weight gradients may still be slabs awaiting their batched reduction, or in flight on the
+        # weight-gradient stream: fold and join first, so that the collective (ordered after the current stream by the
+        # process group) only ever sees complete gradients
+        self._flush_splitk()
+        while self._next < nb and (everything or self._ready[self._next]):
+            s, e = self.buckets[self._next]
+            self._works.append(dist.all_reduce(self.flat[s:e], group=self.pg, async_op=True))
+            self._next += 1
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Wrap the forward+backward of every micro-batch of an update EXCEPT the last one (torch DDP's no_sync /
+        fairseq's accumulation, trainer semantics of --update-freq): gradients accumulate locally, nothing is reduced."""
+        old, self._accumulating = self._accumulating, True
+        try:
+            yield
+        finally:
+            self._accumulating = old
+
+    def accumulate(self, micro_batches, fn):
+        """fn(sample) = forward + backward of one micro-batch; runs all of them with the right sync mode."""
+        n = len(micro_batches)
+        out = []
+        for i, mb in enumerate(micro_batches):
+            with (self.no_sync() if i + 1 < n else contextlib.nullcontext()):
+                out.append(fn(mb))
+        return out
 
     # -- step API ----------------------------------------------------------------------------------
     def close(self):
@@ -148,21 +206,43 @@ class FlatGradDataParallel:
             hip.check(hip.lib().st5_gemm_defer_splitk(0, hip.stream()), "st5_gemm_defer_splitk")
         Fn.set_layer_boundary_hook(None)
 
+    def _reset_round(self):
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
+        self._works = []
+
     def zero_grad(self):
+        assert not self._works, "zero_grad() between backward and finish(): all-reduces are in flight"
         self.flat.zero_()
-        self._launched = [None] * len(self.buckets)
+        self._reset_round()
+
+    def check_grad_views(self):
+        """`param.grad` must still be the view of the flat buffer this wrapper installed: model.zero_grad() /
+        optimizer.zero_grad(set_to_none=True) drop it, after which the kernels would accumulate into fresh private tensors
+        and the all-reduce / optimizer would keep reading zeros.  A dropped view is re-installed; a foreign tensor raises."""
+        es = self.flat.element_size()
+        base = self.flat.data_ptr()
+        for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            if g is None:
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+            elif g.data_ptr() != base + o * es:
+                raise RuntimeError("a parameter's .grad no longer aliases FlatGradDataParallel.flat (was it replaced by "
+                                   "loss.backward() after zero_grad(set_to_none=True)?): use ddp.zero_grad()")
 
     def finish(self):
-        """Call after backward: reduce the remaining buckets, wait for all, average over ranks."""
+        """Call after the LAST micro-batch's backward: reduce the remaining buckets (index order), wait for all, average
+        over ranks."""
+        assert not self._accumulating, "finish() inside no_sync()"
+        self.check_grad_views()
         self._flush_splitk()
         if self.collectives:
-            for bi in range(len(self.buckets)):
-                self._bucket_ready(bi)
-            for w in self._launched:
+            self._launch_in_order(True)
+            for w in self._works:
                 w.wait()
             if self.world > 1:
                 self.flat.mul_(1.0 / self.world)
-        self._launched = [None] * len(self.buckets)
+        self._reset_round()
 
 
 def _fusion_ordered_parameters(module):
@@ -196,24 +276,43 @@ def _fusion_ordered_parameters(module):
     return out
 
 
+class BucketGroup:
+    """Modules whose parameters form one all-reduce bucket + the layer boundaries whose backward means "this bucket has
+    received its last contribution": `triggers` = [(module, tag)] as passed to functional.layer_boundary(x, module, tag);
+    default: the input boundary (tag None) of every module of the group."""
+
+    def __init__(self, modules, triggers=None):
+        self.modules = list(modules)
+        self.triggers = triggers
+
+    def trigger_keys(self):
+        if self.triggers is None:
+            return [(id(m), None) for m in self.modules]
+        return [(id(m), tag) for m, tag in self.triggers]
+
+
 def default_buckets(model):
-    """Backward-completion order of a T5TransformerModel: post-nets + NCE head + quantizer, decoder layers (last
-    first), decoder pre-nets, encoder layers (last first), encoder pre-nets.  The remaining parameters (layer-less
-    encoder/decoder members, tied embeddings, ...) fall into a final bucket reduced by finish()."""
+    """Backward-completion order of a T5TransformerModel:
+      0      decoder-side heads (mel / text post-nets)      ready when the gradient of the decoder output exists
+      1..Ld  decoder layers, last first                      ready at each layer's input boundary
+      Ld+1   encoder-side heads (HuBERT NCE head, quantizer) ready when the gradient of the encoder output is complete
+             (every decoder layer's cross-attention and both heads hang off that tensor)
+      ...    encoder layers, last first
+    Everything else (pre-nets, the tied text embedding, layer-less encoder / decoder members) falls into the final bucket,
+    which finish() reduces."""
     groups = []
-    head = [m for m in (getattr(model, n, None) for n in ("speech_decoder_postnet", "text_decoder_postnet", "hubert_layer",
-                                                            "quantizer")) if m is not None]
-    if head:
-        groups.append(head)
     dec = getattr(model, "decoder", None)
-    if dec is not None and hasattr(dec, "layers"):
-        groups += [[l] for l in reversed(list(dec.layers))]
-    pre = [m for m in (getattr(model, n, None) for n in ("speech_decoder_prenet", "text_decoder_prenet")) if m is not None]
-    if pre:
-        groups.append(pre)
     enc = getattr(model, "encoder", None)
+    head = [m for m in (getattr(model, n, None) for n in ("speech_decoder_postnet", "text_decoder_postnet")) if m is not None]
+    if head and dec is not None:
+        groups.append(BucketGroup(head, triggers=[(dec, "out")]))
+    if dec is not None and hasattr(dec, "layers"):
+        groups += [BucketGroup([l]) for l in reversed(list(dec.layers))]
+    ehead = [m for m in (getattr(model, n, None) for n in ("hubert_layer", "quantizer")) if m is not None]
+    if ehead and enc is not None:
+        groups.append(BucketGroup(ehead, triggers=[(enc, "out")]))
     if enc is not None and hasattr(enc, "layers"):
-        groups += [[l] for l in reversed(list(enc.layers))]
+        groups += [BucketGroup([l]) for l in reversed(list(enc.layers))]
     return groups
 
 

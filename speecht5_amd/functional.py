@@ -18,7 +18,7 @@ from . import hip
 from .hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH  # noqa: F401
 
 _S = SimpleNamespace(dtype=torch.float32, seed=0x5EED, counter=0, grad_hook=None, boundary_hook=None, side=None, side_raw=0,
-                     side_keep=[], attn_side=None, attn_side_raw=None)
+                     side_keep=[], side_gens=[], side_n=0, attn_side=None, attn_side_raw=None)
 
 
 def set_compute_dtype(dtype):
@@ -48,12 +48,13 @@ def set_grad_ready_hook(fn):
 
 
 def set_layer_boundary_hook(fn):
-    """fn(x, module) -> x, called by the layer mirrors at their input (see speecht5_amd/ddp.py)."""
+    """fn(x, module, tag) -> x, called by the layer mirrors at their input (tag None) and by the encoder / decoder stacks
+    at their output (tag "out"); see speecht5_amd/ddp.py."""
     _S.boundary_hook = fn
 
 
-def layer_boundary(x, module):
-    return x if _S.boundary_hook is None else _S.boundary_hook(x, module)
+def layer_boundary(x, module, tag=None):
+    return x if _S.boundary_hook is None else _S.boundary_hook(x, module, tag)
 
 
 def _ceil8(n):
@@ -383,7 +384,23 @@ def join_wgrad_stream():
     L = hip.lib()
     hip.check(L.st5_gemm_flush_splitk(_S.side_raw), "st5_gemm_flush_splitk")
     hip.check(L.st5_stream_fork(_S.side_raw, hip.stream()), "st5_stream_fork")
-    _S.side_keep.clear()
+    _S.side_keep = []
+    _S.side_gens = []
+
+
+def _side_hold(keep):
+    """Keep the tensors a side-stream GEMM reads alive until that GEMM has run.  Generations of 16 launches are closed by an
+    event on the side stream and dropped once the event has completed, so at most a few dozen gradient activations are
+    pinned at a time even when no bucket boundary joins the streams (one rank: the only join is in finish())."""
+    _S.side_keep.extend(keep)
+    _S.side_n += 1
+    if _S.side_n % 16 == 0:
+        ev = torch.cuda.Event()
+        ev.record(_S.side)
+        _S.side_gens.append((ev, _S.side_keep))
+        _S.side_keep = []
+        while _S.side_gens and _S.side_gens[0][0].query():
+            _S.side_gens.pop(0)
 
 
 def _wgrad_gemm(params, A, B, C, M, N, K, dt, asum, keep):
@@ -400,8 +417,8 @@ def _wgrad_gemm(params, A, B, C, M, N, K, dt, asum, keep):
             hip.gemm(A, B, C, M, N, K, dt, flags=flags, beta=1.0, asum=asum)
             return
     hip.check(hip.lib().st5_stream_fork(hip.stream(), _S.side_raw), "st5_stream_fork")
-    _S.side_keep.extend(keep)
     hip.gemm(A, B, C, M, N, K, dt, flags=flags | hip.DEFERRABLE, beta=1.0, asum=asum, on=_S.side)
+    _side_hold(keep)
 
 
 def _conv_wgrad(w, opA, opB, Cout, k, Cin, Kred, dt, keep):
@@ -413,9 +430,9 @@ def _conv_wgrad(w, opA, opB, Cout, k, Cin, Kred, dt, keep):
         grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))  # (glue: layout permute of a <= 3 MB tensor)
     if _S.side is not None and getattr(w, "_st5_side_ok", False):
         hip.check(hip.lib().st5_stream_fork(hip.stream(), _S.side_raw), "st5_stream_fork")
-        _S.side_keep.extend(keep)
         with torch.cuda.stream(_S.side):
             run()
+        _side_hold(keep)
     else:
         run()
 

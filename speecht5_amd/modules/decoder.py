@@ -73,6 +73,7 @@ class TransformerDecoder(FairseqIncrementalDecoder):
         inner_states = [x.view(B, T, C).transpose(0, 1)]
         for idx, layer in enumerate(self.layers):
             if self.training and self.decoder_layerdrop > 0 and float(torch.empty(1).uniform_()) <= self.decoder_layerdrop:
+                x = Fn.layer_boundary(x, layer)   # skipped layer: its (zero) gradient bucket still reports ready here
                 continue  # LayerDropModuleList semantics (torch RNG)
             want = bool(idx == alignment_layer or alignment_layer == -1)
             x, layer_attn = layer.forward_rows(x, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want)
@@ -86,6 +87,7 @@ class TransformerDecoder(FairseqIncrementalDecoder):
             attn = attn.mean(dim=0)
         if self.layer_norm is not None:
             x = self.layer_norm(x)
+        x = Fn.layer_boundary(x, self, "out")   # the post-nets' gradients are complete when this node's backward runs
         x = x.view(B, T, C)
         return x, {"attn": [attn if len(attn_list) <= 1 else attn_list], "inner_states": inner_states}
 

@@ -106,6 +106,8 @@ class TransformerEncoder(FairseqEncoder):
             with torch.no_grad() if frozen else contextlib.ExitStack():
                 if not self.training or (dropout_probability > self.encoder_layerdrop) or i == self.unb_enc_layer:
                     x = layer.forward_rows(x, B, T, padding_mask=encoder_padding_mask, pos_bias=pos_k)
+                else:   # LayerDrop: the layer's (zero) gradient bucket still reports ready at this point of backward
+                    x = Fn.layer_boundary(x, layer)
                 if i == self.unb_enc_layer:
                     d = x.view(B, T, C).transpose(0, 1)
                 if i == tgt_layer:
@@ -118,6 +120,7 @@ class TransformerEncoder(FairseqEncoder):
                 x = self.layer_norm(x)
             if r is not None:
                 x = r
+        x = Fn.layer_boundary(x, self, "out")   # everything that consumes the encoder output is behind this point
         return {
             "encoder_out": [x.view(B, T, C).transpose(0, 1)],  # T x B x C (view of batch-major rows)
             "encoder_padding_mask": [encoder_padding_mask],

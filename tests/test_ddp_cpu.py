@@ -1,8 +1,11 @@
-"""CPU, world_size 2 over gloo: the flat-gradient data-parallel layer gives every rank the mean gradient of the
-concatenated batch (N-rank result == 1-rank result), reduces parameters the local micro-batch never touched
-(zeros take part, as fairseq legacy_ddp + --find-unused-parameters), and launches buckets from the backward
-triggers.  The model here is a plain-torch stand-in with the same module layout hooks; the DDP code is the
-product's (speecht5_amd/ddp.py)."""
+"""CPU, world_size 2 over gloo: the flat-gradient data-parallel layer (speecht5_amd/ddp.py, product code) on a plain-torch
+stand-in model with the same layer-boundary hooks as the SpeechT5 mirrors.
+
+Checked (reference semantics: fairseq legacy_ddp + --find-unused-parameters + --update-freq, SpeechT5/README.md:86-88,103,
+tasks/speecht5.py:538,556): every rank ends with the MEAN over all W*U micro-batches of each micro-batch's gradient,
+bit-identical across ranks; parameters no local micro-batch touched take part (zeros); with two micro-batches per update
+(mixed "modalities") a bucket is reduced once, after its last contribution; ranks that skip different layers (LayerDrop)
+still issue their collectives in the same order; tied weights are reduced by finish() only."""
 import os
 
 import pytest
@@ -19,74 +22,145 @@ class Layer(nn.Module):
         super().__init__()
         self.fc = nn.Linear(d, d)
 
-    def forward(self, x):
+    def forward(self, x, skip=False):
         x = Fn.layer_boundary(x, self)
+        if skip:
+            return x
         return torch.tanh(self.fc(x))
 
 
 class Toy(nn.Module):
     def __init__(self, d=8):
         super().__init__()
+        self.emb = nn.Linear(d, d, bias=False)   # "tied embedding": used at the input AND by the head
         self.inp = nn.Linear(d, d)
         self.layers = nn.ModuleList([Layer(d) for _ in range(3)])
         self.unused = nn.Linear(d, d)       # never touched by any rank
-        self.rank1_only = nn.Linear(d, 1)   # touched by rank 1 only ("other modality")
+        self.rank1_only = nn.Linear(d, 1)   # touched by one "modality" only
         self.head = nn.Linear(d, 1)
+        self.tied_head = nn.Linear(d, d, bias=False)
+        self.tied_head.weight = self.emb.weight
 
-    def forward(self, x, use_extra):
-        x = self.inp(x)
-        for l in self.layers:
-            x = l(x)
-        y = self.head(x)
+    def forward(self, x, use_extra, skip=()):
+        x = self.inp(self.emb(x))
+        for i, l in enumerate(self.layers):
+            x = l(x, skip=i in skip)
+        x = Fn.layer_boundary(x, self, "out")
+        y = self.head(x) + self.tied_head(x).sum(-1, keepdim=True)
         if use_extra:
             y = y + self.rank1_only(x)
         return y
 
 
-def _worker(rank, world, port, ret):
+def _groups(model):
+    from speecht5_amd.ddp import BucketGroup
+    return [BucketGroup([model.head, model.rank1_only, model.tied_head], triggers=[(model, "out")])] + \
+           [BucketGroup([l]) for l in reversed(list(model.layers))]
+
+
+def _micro(X, rank, u, U):
+    i = (rank * U + u) * 4
+    return X[i:i + 4]
+
+
+def _worker(rank, world, port, ret, U, skips):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from speecht5_amd.ddp import FlatGradDataParallel
     torch.manual_seed(0)
     model = Toy()
+    ddp = FlatGradDataParallel(model, bucket_groups=_groups(model))
     launched = []
-    ddp = FlatGradDataParallel(model, bucket_groups=[[model.head, model.rank1_only]] + [[l] for l in reversed(list(model.layers))])
-    orig = ddp._bucket_ready
-    ddp._bucket_ready = lambda bi: (launched.append(bi), orig(bi))[1]
+    orig = dist.all_reduce
+
+    def spy(t, *a, **k):   # record the issue order of the collectives by (offset, length) inside the flat buffer
+        launched.append(((t.data_ptr() - ddp.flat.data_ptr()) // 4, t.numel()))
+        return orig(t, *a, **k)
+    dist.all_reduce = spy
     torch.manual_seed(1)
-    X = torch.randn(8, 8)
-    xb = X[rank * 4:(rank + 1) * 4]
+    X = torch.randn(4 * world * U, 8)
     ddp.zero_grad()
-    loss = model(xb, use_extra=(rank == 1)).pow(2).mean()
-    loss.backward()
-    triggered = list(launched)
+    during = []
+
+    def fwd_bwd(u):
+        # modality mix: micro-batch (rank + u) odd uses the extra head
+        model(_micro(X, rank, u, U), use_extra=((rank + u) % 2 == 1), skip=skips[rank][u]).pow(2).mean().backward()
+        during.append(len(launched))
+    ddp.accumulate(list(range(U)), fwd_bwd)
     ddp.finish()
-    ret[rank] = dict(flat=ddp.flat.clone(), triggered=triggered, nb=len(ddp.buckets),
-                     grads={n: p.grad.clone() for n, p in model.named_parameters()})
+    dist.all_reduce = orig
+    # model.zero_grad() drops the views: the wrapper must notice and re-install them
+    model.zero_grad(set_to_none=True)
+    ddp.check_grad_views()
+    views_ok = all(p.grad is not None and p.grad.data_ptr() == ddp.flat.data_ptr() + o * 4 for p, o in zip(ddp.params, ddp.offsets))
+    ret[rank] = dict(flat=ddp.flat.clone(), launched=launched, during=during, nb=len(ddp.buckets), buckets=list(ddp.buckets),
+                     names={n: o for (n, p), o in zip([(n, p) for n, p in model.named_parameters()], [None] * 99)},
+                     emb_off=ddp.offsets[[id(p) for p in ddp.params].index(id(model.emb.weight))],
+                     grads={n: p.grad.clone() for n, p in model.named_parameters()}, views_ok=views_ok)
     dist.destroy_process_group()
 
 
-def test_two_rank_mean_equals_single_process():
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
-    # single-process reference: mean over the two micro-batches of each micro-batch's loss gradient
+def _reference(world, U, skips):
     torch.manual_seed(0)
     model = Toy()
     torch.manual_seed(1)
-    X = torch.randn(8, 8)
+    X = torch.randn(4 * world * U, 8)
     tot = None
-    for r in range(2):
-        model.zero_grad()
-        model(X[r * 4:(r + 1) * 4], use_extra=(r == 1)).pow(2).mean().backward()
-        g = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
-        tot = g if tot is None else {n: tot[n] + g[n] for n in g}
-    ref = {n: v / 2 for n, v in tot.items()}
+    for r in range(world):
+        for u in range(U):
+            model.zero_grad()
+            model(_micro(X, r, u, U), use_extra=((r + u) % 2 == 1), skip=skips[r][u]).pow(2).mean().backward()
+            g = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+            tot = g if tot is None else {n: tot[n] + g[n] for n in g}
+    return {n: v / world for n, v in tot.items()}   # mean over ranks of the per-rank SUM over micro-batches
+
+
+def _run(U, skips):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() * 7 + U * 13 + len(str(skips))) % 2000
+    mp.spawn(_worker, args=(2, port, ret, U, skips), nprocs=2, join=True)
+    return ret, _reference(2, U, skips)
+
+
+def _check(ret, ref):
     for r in range(2):
         for n, v in ref.items():
-            assert torch.allclose(ret[r]["grads"][n], v, atol=1e-6), (r, n)
+            assert torch.allclose(ret[r]["grads"][n], v, atol=1e-6), (r, n, (ret[r]["grads"][n] - v).abs().max())
         assert float(ret[r]["grads"]["unused.weight"].abs().sum()) == 0.0
+        assert ret[r]["views_ok"]
     assert torch.equal(ret[0]["flat"], ret[1]["flat"])
-    # the layer triggers fired during backward for the layer buckets whose input needed a gradient
-    assert len(ret[0]["triggered"]) >= 2 and ret[0]["nb"] == 5
+    # same collectives in the same order on both ranks, each bucket exactly once, in index order
+    assert ret[0]["launched"] == ret[1]["launched"]
+    assert ret[0]["launched"] == [(s, e - s) for s, e in ret[0]["buckets"]]
+
+
+NOSKIP = [[(), ()], [(), ()]]
+
+
+def test_two_rank_mean_equals_single_process():
+    ret, ref = _run(1, NOSKIP)
+    _check(ret, ref)
+    # the head trigger and the layer triggers fired during backward: every bucket but the final one was launched before finish()
+    assert ret[0]["nb"] == 5 and ret[0]["during"][-1] == 4
+    # the tied weight lives in the final bucket (reduced by finish() only)
+    s, e = ret[0]["buckets"][-1]
+    assert s <= ret[0]["emb_off"] < e
+
+
+def test_two_micro_batches_per_update_mixed_modalities():
+    """--update-freq 2 (bench.py's step: speech then text micro-batch): nothing is reduced during the first backward,
+    buckets go out during the second, the result is the mean over ranks of the accumulated gradients."""
+    ret, ref = _run(2, NOSKIP)
+    _check(ret, ref)
+    for r in range(2):
+        assert ret[r]["during"][0] == 0, "a bucket was all-reduced before its last micro-batch"
+        assert ret[r]["during"][1] == 4
+
+
+def test_ranks_skipping_different_layers_keep_collective_order():
+    """LayerDrop draws differ per rank: rank 0 skips layer 1 in its last micro-batch, rank 1 skips layer 2.  A skipped layer
+    still reports its bucket; collectives stay in bucket order on both ranks and the mean is right."""
+    skips = [[(), (1,)], [(0,), (2,)]]
+    ret, ref = _run(2, skips)
+    _check(ret, ref)
