@@ -333,7 +333,7 @@ class SpeechT5Criterion(nn.Module):
                  use_masking=True, use_weighted_masking=False, loss_type="L1", bce_pos_weight=5.0, bce_loss_lambda=1.0,
                  use_guided_attn_loss=False, num_heads_applied_guided_attn=2, ce_weight=1.0, ctc_weight=0.0, hubert_weight=1.0,
                  dec_weight=1.0, bart_weight=1.0, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_weights=None, cfg=None,
-                 sync_logging=True, guided_attn_loss_lambda=1.0, guided_attn_loss_sigma=0.4):
+                 sync_logging=True, guided_attn_loss_lambda=1.0, guided_attn_loss_sigma=0.4, log_keys=None):
         super().__init__()
         self.speech_criterion = TexttoSpeechLoss(task, sentence_avg, use_masking, use_weighted_masking, loss_type, bce_pos_weight,
                                                  bce_loss_lambda, use_guided_attn_loss, guided_attn_loss_sigma, guided_attn_loss_lambda,
@@ -342,7 +342,7 @@ class SpeechT5Criterion(nn.Module):
                                                ce_weight, ctc_weight, sync_logging=sync_logging)
         self.text_pretrain_criterion = TextPretrainCriterion(task, sentence_avg, bart_weight, loss_weights, sync_logging=sync_logging)
         self.speech_pretrain_criterion = SpeechPretrainCriterion(task, sentence_avg, pred_masked_weight, pred_nomask_weight,
-                                                                 loss_weights, None, use_masking, use_weighted_masking, loss_type,
+                                                                 loss_weights, log_keys, use_masking, use_weighted_masking, loss_type,
                                                                  bce_pos_weight, hubert_weight, dec_weight, sync_logging=sync_logging)
 
     def forward(self, model, sample, reduce=True):

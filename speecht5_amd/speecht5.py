@@ -82,6 +82,12 @@ class T5TransformerModel(FairseqEncoderDecoderModel):
             self.apply(init_bert_params)
         self.args = args
 
+    @staticmethod
+    def add_args(parser):
+        """Model options, speecht5.py:117-614 of the reference (same names / dests / defaults: speecht5_amd/cli.py)."""
+        from . import cli
+        cli.declare(parser, cli.MODEL_OPTIONS)
+
     # ---- builders (speecht5.py:616-729) ----
     @classmethod
     def build_encoder(cls, args, dictionary=None, embed_tokens=None):
@@ -347,12 +353,84 @@ class T5TransformerModel(FairseqEncoderDecoderModel):
 
     # ---- checkpoint compatibility (speecht5.py:1022-1058): non-strict per-submodule load ----
     def load_state_dict(self, state_dict, strict=True, model_cfg=None, args=None):
+        """Never strict (as the reference): a checkpoint trained with another dictionary loses its dictionary-sized tensors
+        (text pre/post-nets, CTC projection: speecht5.py:1036-1051), every other tensor whose shape differs is dropped with
+        a warning, and each top-level module then takes what the checkpoint has for it."""
+        state_dict = dict(state_dict)
+        self.upgrade_state_dict_named(state_dict, "")
+        post = getattr(self, "text_decoder_postnet", None)
+        key = "text_decoder_postnet.output_projection.weight"
+        if post is not None and key in state_dict and state_dict[key].size(0) != post.output_projection.weight.size(0):
+            logger.warning(f"dictionary size differs (model {post.output_projection.weight.size(0)} vs checkpoint "
+                           f"{state_dict[key].size(0)}): dictionary-sized modules keep their initialisation")
+            for k in [k for k in state_dict if k.startswith(("encoder.proj", "text_encoder_prenet", "text_decoder_prenet",
+                                                             "text_decoder_postnet"))]:
+                state_dict.pop(k)
         own = self.state_dict()
         for k in list(state_dict.keys()):
             if k in own and own[k].shape != state_dict[k].shape:
                 logger.warning(f"dropping {k}: checkpoint shape {tuple(state_dict[k].shape)} != model {tuple(own[k].shape)}")
                 state_dict.pop(k)
         return super().load_state_dict(state_dict, strict=False)
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        """Old-checkpoint fixes of the fairseq lineage, applied to the keys in place: fused `in_proj_weight / in_proj_bias`
+        of attention blocks are split into q/k/v projections (multihead_attention.py:493-522); the numbered decoder layer
+        norms `layer_norms.{0,1,2}` get their names (decoder.py:290-300)."""
+        for k in list(state_dict.keys()):
+            if k.endswith("in_proj_weight") or k.endswith("in_proj_bias"):
+                base, kind = k.rsplit("in_proj_", 1)
+                w = state_dict.pop(k)
+                n = w.shape[0] // 3
+                for i, pn in enumerate(("q_proj", "k_proj", "v_proj")):
+                    state_dict[f"{base}{pn}.{kind}"] = w[i * n:(i + 1) * n]
+        names = {"0": "self_attn_layer_norm", "1": "encoder_attn_layer_norm", "2": "final_layer_norm"}
+        for k in list(state_dict.keys()):
+            if ".layer_norms." in k and k.startswith((name + "decoder.") if name else "decoder."):
+                head, tail = k.split(".layer_norms.", 1)
+                idx, rest = tail.split(".", 1)
+                if idx in names:
+                    state_dict[f"{head}.{names[idx]}.{rest}"] = state_dict.pop(k)
+        return state_dict
+
+    def prune_modules(self, modules_filter=None):
+        """Drop the sub-modules a fine-tuning task never uses (speecht5.py:1060-1110): `s2s`, `t2s`, `s2c`, `s3prl`."""
+        if modules_filter is None:
+            return
+
+        def drop(*names):
+            for n in names:
+                if n in self._modules:
+                    del self._modules[n]
+                    if n == "quantizer":
+                        self.use_codebook = False
+
+        def drop_decoder_stack():
+            for n in ("dropout_module", "layers", "layer_norm"):
+                if n in self.decoder._modules:
+                    del self.decoder._modules[n]
+
+        common = ("speech_encoder_postnet", "hubert_layer", "projection", "quantizer")
+        if modules_filter == "s2c":
+            pooling = getattr(self.args, "sid_pooling_layer", "decoder")
+            drop("text_encoder_prenet", "speech_decoder_postnet", "text_decoder_postnet", *common)
+            if pooling != "decoder-las":
+                drop("speech_decoder_prenet")
+            if pooling.startswith("encoder") or getattr(self.args, "sid_decoder_speaker", False):
+                drop_decoder_stack()
+                drop("text_decoder_prenet")
+        elif modules_filter == "s2s":
+            drop("speaker_decoder_postnet", "text_encoder_prenet", "text_decoder_prenet", "text_decoder_postnet", *common)
+        elif modules_filter == "t2s":
+            drop("speaker_decoder_postnet", "speech_encoder_prenet", "text_decoder_prenet", "text_decoder_postnet", *common)
+        elif modules_filter == "s3prl":
+            drop_decoder_stack()
+            drop("speaker_decoder_postnet", "text_decoder_prenet", "text_decoder_postnet", "speech_decoder_prenet",
+                 "speech_decoder_postnet", *common)
+        else:
+            raise ValueError(f"unknown modules filter {modules_filter!r}")
+        if getattr(self.encoder, "proj", None) is not None:
+            self.encoder.proj = None
 
 
 # ---- architectures (speecht5.py:1252-1447) ----

@@ -13,6 +13,27 @@ class _Dictionary(list):
     def __init__(self, symbols=(), extra=()):
         super().__init__(["<s>", "<pad>", "</s>", "<unk>"] + list(symbols) + list(extra))
 
+    @classmethod
+    def load(cls, path):
+        """fairseq dictionary file: one `<symbol> <count>` per line, in index order after the four specials."""
+        syms = []
+        with open(path, encoding="utf-8") as f:
+            for line in f:
+                line = line.rstrip("\n")
+                if line:
+                    syms.append(line.rsplit(" ", 1)[0] if " " in line else line)
+        return cls(syms)
+
+    def add_symbol(self, sym):
+        if sym in self:
+            return list.index(self, sym)
+        self.append(sym)
+        return len(self) - 1
+
+    def string(self, tokens, bpe_symbol=None, extra_symbols_to_ignore=()):
+        skip = {self.pad(), self.eos(), self.bos()} | set(extra_symbols_to_ignore)
+        return " ".join(self[int(t)] for t in tokens if int(t) not in skip)
+
     def pad(self):
         return 1
 
@@ -35,8 +56,58 @@ class SpeechT5Task:
         self.args = args
         self.dicts = dicts
         self.config = config
-        self.t5_task = getattr(args, "t5_task", "pretrain")
+        self.t5_task = getattr(args, "t5_task", None) or "pretrain"
+        # size filter of the data plane (tasks/speecht5.py:277-281)
+        msp, mtp = getattr(args, "max_speech_positions", 4000), getattr(args, "max_text_positions", 450)
+        self.max_pos = [msp * 256, mtp] if self.t5_task == "pretrain" else [msp * 256]
+        # <mask> and the CTC blank are appended to the text dictionary by the task (tasks/speecht5.py:283-287)
+        text = dicts.get("text") if isinstance(dicts, dict) else None
+        if text is not None and hasattr(text, "add_symbol"):
+            self.mask_idx = text.add_symbol("<mask>")
+            self.blank_symbol_idx = text.add_symbol("<ctc_blank>")
         self.blank_symbol = "<ctc_blank>"
+        self.seed = getattr(args, "seed", 1)
+
+    @staticmethod
+    def add_args(parser):
+        """Task options, tasks/speecht5.py:44-270 of the reference (speecht5_amd/cli.py holds the table)."""
+        from . import cli
+        cli.declare(parser, cli.TASK_OPTIONS)
+
+    @classmethod
+    def setup_task(cls, args, **kwargs):
+        """tasks/speecht5.py:298-318: dictionaries from `<data>/dict.txt` (text) and, for pre-training,
+        `<hubert-label-dir>/dict.<label>.txt` per label set."""
+        import os.path as op
+        dicts = {}
+        if args.t5_task == "pretrain":
+            if not hasattr(args, "shuffle_instance"):
+                args.shuffle_instance = False
+            dicts["hubert"] = [_Dictionary.load(f"{args.hubert_label_dir}/dict.{label}.txt") for label in args.hubert_labels]
+        dicts["text"] = _Dictionary.load(op.join(args.data, "dict.txt"))
+        return cls(args, dicts, None)
+
+    def build_criterion(self, args):
+        from . import cli
+        from .criterions import SpeechT5Criterion
+        return SpeechT5Criterion(self, **cli.criterion_kwargs(args))
+
+    def build_generator(self, models, args, seq_gen_cls=None, extra_gen_cls_kwargs=None):
+        """tasks/speecht5.py:599-613: the plug-in's own SequenceGenerator (joint CTC / attention scoring) with the task's
+        --ctc-weight; beam / length options come from the generation namespace like fairseq's build_generator reads them."""
+        from .sequence_generator import SequenceGenerator
+        kw = dict(ctc_weight=getattr(self.args, "ctc_weight", 0.0))
+        kw.update(extra_gen_cls_kwargs or {})
+        cls_ = seq_gen_cls or SequenceGenerator
+        return cls_(models, self.target_dictionary, beam_size=getattr(args, "beam", 5), max_len_a=getattr(args, "max_len_a", 0),
+                    max_len_b=getattr(args, "max_len_b", 200), min_len=getattr(args, "min_len", 1),
+                    normalize_scores=not getattr(args, "unnormalized", False), len_penalty=getattr(args, "lenpen", 1),
+                    unk_penalty=getattr(args, "unkpen", 0), temperature=getattr(args, "temperature", 1.0),
+                    no_repeat_ngram_size=getattr(args, "no_repeat_ngram_size", 0), **kw)
+
+    @property
+    def source_dictionary(self):
+        return None
 
     @classmethod
     def synthetic(cls, args, text_symbols=77, hubert_units=500):
@@ -51,10 +122,20 @@ class SpeechT5Task:
         return self.dicts["text"]
 
     def build_model(self, args):
+        """tasks/speecht5.py:581-597: 80-bin single-channel mel targets unless a data config says otherwise; label / sample
+        rates flow from the task options into the model namespace."""
         from .speecht5 import T5TransformerModel
-        args.label_rates = getattr(args, "label_rates", 50)
-        args.sample_rate = getattr(args, "sample_rate", 16000)
-        return T5TransformerModel.build_model(args, self)
+        cfg = self.config
+        args.input_feat_per_channel = getattr(cfg, "input_feat_per_channel", 80) if cfg is not None else 80
+        args.input_channels = getattr(cfg, "input_channels", 1) if cfg is not None else 1
+        if getattr(args, "speech_odim", None) is None:
+            args.speech_odim = args.input_feat_per_channel * args.input_channels
+        for k, d in (("label_rates", 50), ("sample_rate", 16000)):
+            v = getattr(self.args, k, None)
+            setattr(args, k, v if v is not None else getattr(args, k, d))
+        model = T5TransformerModel.build_model(args, self)
+        self.args.reduction_factor = args.reduction_factor
+        return model
 
     def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False, sync=True):
         model.train()
