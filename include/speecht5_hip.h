@@ -240,6 +240,30 @@ int st5_stft_frames(const float* wav, float* out, int32_t B, int32_t S, int32_t 
 int st5_stft_magnitude(const float* reim, float* mag, int64_t rows, int32_t nbins, int32_t ldh, void* stream);
 int st5_log10_floor(const float* x, float* y, int64_t n, float floor_value, void* stream);
 
+/* ---- BatchNorm1d + tanh + dropout (+ residual) on channels-last rows: the non-GEMM part of the mel post-net
+ *      (speech_decoder_postnet.py:39-51,65-70 = espnet Tacotron Postnet: 5 x [Conv1d k5 -> BatchNorm1d -> tanh -> dropout], the
+ *      last block without tanh; after = before + postnet(before)).  x fp32 [rows, C] = the convolution GEMM's fp32 output
+ *      (ST5_GEMM_OUT_F32), C % 4 == 0.  Training: batch statistics (fp64 partial sums), running_mean / running_var /
+ *      num_batches_tracked updated like torch.nn.BatchNorm1d (momentum blend, unbiased variance); eval: running statistics.
+ *      y = dropout(act((x - mean) * rstd * gamma + beta)) [+ residual], act in {ST5_ACT_NONE, ST5_ACT_TANH}; dropout element
+ *      counters = row * C + c.  y: `dtype` elements, or fp32 when y_f32 (the block's fp32 `after` output); residual: `dtype`
+ *      [rows, C].  Output row r goes to element offset (r / out_L) * out_bstride + (r % out_L) * C + out_off (out_L = 0: r * C)
+ *      and `halo` rows in front of / behind every out_L-row batch block are zeroed: the next convolution's time-padded
+ *      operand is written directly.  stats fp32 [2*C] (mean, rstd) is saved for the backward.  ws >= st5_batchnorm_ws_bytes(C). */
+int64_t st5_batchnorm_ws_bytes(int32_t C);
+int st5_batchnorm_act_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          int64_t* num_batches_tracked, float momentum, float eps, int32_t training, int32_t act,
+                          float dropout_p, uint64_t seed, const void* residual, void* y, int32_t y_f32, float* stats, void* ws,
+                          int64_t rows, int32_t C, int64_t out_L, int64_t out_bstride, int64_t out_off, int32_t halo, int dtype,
+                          void* stream);
+/* Backward: g = dropout_mask * dy * act'(.) with dy fp32 (the fp32 data gradient of the next convolution);
+ * dgamma += sum g*xhat, dbeta += sum g (either may be NULL); dx (dtype, mapped / haloed like the forward's y) =
+ * gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)) for batch statistics, gamma * rstd * g for running statistics. */
+int st5_batchnorm_act_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, float* dgamma,
+                          float* dbeta, int32_t training, int32_t act, float dropout_p, uint64_t seed, void* dx, void* ws,
+                          int64_t rows, int32_t C, int64_t out_L, int64_t out_bstride, int64_t out_off, int32_t halo, int dtype,
+                          void* stream);
+
 /* ---- losses ---- */
 /* Row-wise (label-smoothed) cross entropy on logits [rows, ld] (dtype, first V cols valid).
  * loss_sum[0] += sum_r w_r * ((1-eps)*nll_r + eps/V... ) following speech_to_text_loss.py:93-110;

@@ -1306,6 +1306,31 @@ def _conv_w_fwd(w, dtype):
     return weight_cache.get(("convw", dtype, id(w)), [w], build)
 
 
+def _conv_w_dgrad_k2(w, dtype):
+    """k = 2, stride 2 transposed convolution as ONE NT GEMM: B[j = jj*Cin + ci][k = co] = W[co, ci, jj], K-major ([2*Cin, Cout])."""
+    def build():
+        src = w.detach().permute(2, 1, 0).reshape(-1, w.shape[0]).contiguous()   # [k*Cin, Cout]
+        out = torch.empty(src.shape, dtype=dtype, device=w.device)
+        _cast_into(src, out)
+        return out
+    return weight_cache.get(("convw_d2", dtype, id(w)), [w], build)
+
+
+def _conv_w_even_odd_t(w, dtype):
+    """K-major (transposed) forms of _conv_w_even_odd for the NT kernels: even rows [Cin, 2*Cout] = [W2 | W0]^T, odd rows
+    [Cin, Cout] = W1^T."""
+    def build():
+        wd = w.detach()
+        ev = torch.cat([wd[:, :, 2], wd[:, :, 0]], 0).t().contiguous()   # [Cin, 2*Cout]
+        od = wd[:, :, 1].t().contiguous()                                # [Cin, Cout]
+        e = torch.empty(ev.shape, dtype=dtype, device=w.device)
+        o = torch.empty(od.shape, dtype=dtype, device=w.device)
+        _cast_into(ev, e)
+        _cast_into(od, o)
+        return e, o
+    return weight_cache.get(("convw_eo_t", dtype, id(w)), [w], build)
+
+
 def _conv_w_even_odd(w, dtype):
     """k=3, stride 2 transposed-conv weights: even rows use [W2; W0] ([2*Cout, Cin]), odd rows W1 ([Cout, Cin])."""
     def build():
@@ -1407,25 +1432,28 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
             flags_d = 0 if last else hip.DACT
             act_d = ACT_NONE if last else ACT_GELU
             Wk = _conv_w_fwd(w, dtype)
+            # the transposed-convolution weights are cached K-major, so these data gradients run on the LDS-DMA NT kernels
+            # (256^2 tile for the long layers) instead of the register-staged general kernel (125-160 vs 600+ TFLOP/s)
             if k == 2 and s == 2:
                 covered = 2 * Lo
-                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wk, k * Cin),
+                Wd = _conv_w_dgrad_k2(w, dtype)   # [2*Cin, Cout]
+                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wd, Cout),
                          hip.operand(nxt, 2 * Cin, off=noff, rpb=Lo, bstride=nbs), B * Lo, 2 * Cin, Cout, _dt(dtype),
                          P=hip.operand(P, 2 * Cin, rpb=Lo, bstride=Lin * Cin) if P is not None else None,
-                         act=act_d, flags=hip.B_KSTRIDED | flags_d)
+                         act=act_d, flags=flags_d)
             elif k == 3 and s == 2:
                 covered = 2 * Lo + 1
-                We, Wo = _conv_w_even_odd(w, dtype)
+                Wet, Wot = _conv_w_even_odd_t(w, dtype)
                 # even rows 2t' (t' = 0..Lo): [dpre[t'-1], dpre[t']] . [W2; W0]
-                hip.gemm(hip.operand(dpre, Cout, rpb=Lo + 1, bstride=(Lo + 2) * Cout), hip.operand(We, Cin),
+                hip.gemm(hip.operand(dpre, Cout, rpb=Lo + 1, bstride=(Lo + 2) * Cout), hip.operand(Wet, 2 * Cout),
                          hip.operand(nxt, 2 * Cin, off=noff, rpb=Lo + 1, bstride=nbs), B * (Lo + 1), Cin, 2 * Cout, _dt(dtype),
                          P=hip.operand(P, 2 * Cin, rpb=Lo + 1, bstride=Lin * Cin) if P is not None else None,
-                         act=act_d, flags=hip.B_KSTRIDED | flags_d)
+                         act=act_d, flags=flags_d)
                 # odd rows 2t'+1: dpre[t'] . W1
-                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wo, Cin),
+                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wot, Cout),
                          hip.operand(nxt, 2 * Cin, off=noff + Cin, rpb=Lo, bstride=nbs), B * Lo, Cin, Cout, _dt(dtype),
                          P=hip.operand(P, 2 * Cin, off=Cin, rpb=Lo, bstride=Lin * Cin) if P is not None else None,
-                         act=act_d, flags=hip.B_KSTRIDED | flags_d)
+                         act=act_d, flags=flags_d)
             else:
                 raise NotImplementedError(f"conv feature layer (k={k}, stride={s}) backward")
             if covered < Lin:  # trailing input rows no output window touches
@@ -1717,3 +1745,129 @@ class Conv1dSameFunction(torch.autograd.Function):
 
 def conv1d_same(x, w):
     return Conv1dSameFunction.apply(x.contiguous(), w)
+
+
+# -------------------------------------------------------------------------------------------------
+# Mel post-net (espnet Tacotron Postnet as used at speech_decoder_postnet.py:39-51,65-70):
+#   after = before + dropout(BN(conv_5( ... dropout(tanh(BN(conv_1(before)))) ... )))
+# Convolutions = implicit GEMMs handing over their fp32 accumulators; BatchNorm statistics / affine / tanh / dropout /
+# residual = st5_batchnorm_act_* (csrc/batchnorm.hip).  Everything between two convolutions -- activations AND gradients --
+# stays fp32; only the MFMA operands are rounded to the compute dtype.
+# -------------------------------------------------------------------------------------------------
+class PostnetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, before, cfg, bufs, *params):
+        """before [B, L, odim] (compute dtype); cfg = (training, dropout_p, [(eps, momentum)] per layer); bufs = per layer
+        (running_mean, running_var, num_batches_tracked); params = per layer (conv_weight [Cout,Cin,k], bn_weight, bn_bias).
+        Returns after fp32 [B, L, odim]."""
+        training, p_drop, bn_cfg = cfg
+        dtype = before.dtype
+        dev = before.device
+        B, Lx, odim = before.shape
+        n = len(params) // 3
+        L = hip.lib()
+        before = before.contiguous()
+        k0 = params[0].shape[2]
+        pad = (k0 - 1) // 2
+        xp = torch.empty(B, Lx + 2 * pad, odim, dtype=dtype, device=dev)
+        hip.check(L.st5_pad_time(before.data_ptr(), xp.data_ptr(), B, Lx, odim, pad, pad, _dt(dtype), hip.stream()), "st5_pad_time")
+        saved, seeds = [], []
+        after = None
+        for i in range(n):
+            w, gamma, beta = params[3 * i: 3 * i + 3]
+            rm, rv, nbt = bufs[i]
+            eps, mom = bn_cfg[i]
+            Cout, Cin, k = w.shape
+            assert (k - 1) // 2 == pad and Cout % 4 == 0
+            Wk = _conv_w_fwd(w, dtype)
+            x32 = torch.empty(B * Lx, Cout, dtype=torch.float32, device=dev)
+            hip.gemm(hip.operand(xp, Cin, rpb=Lx, bstride=(Lx + 2 * pad) * Cin), hip.operand(Wk, k * Cin), hip.operand(x32, Cout),
+                     B * Lx, Cout, k * Cin, _dt(dtype), flags=hip.OUT_F32)
+            stats = torch.empty(2 * Cout, dtype=torch.float32, device=dev)
+            ws = hip.workspace(L.st5_batchnorm_ws_bytes(Cout), dev)
+            last = i == n - 1
+            p = p_drop if training else 0.0
+            seed = next_seed() if p > 0 else 0
+            mom_eff = mom if mom is not None else 0.1
+            if last:
+                after = torch.empty(B, Lx, Cout, dtype=torch.float32, device=dev)
+                hip.check(L.st5_batchnorm_act_fwd(x32.data_ptr(), gamma.data_ptr(), beta.data_ptr(), hip.ptr(rm), hip.ptr(rv), hip.ptr(nbt),
+                                                  mom_eff, eps, 1 if training else 0, ACT_NONE, p, seed, before.data_ptr(), after.data_ptr(),
+                                                  1, stats.data_ptr(), ws.data_ptr(), B * Lx, Cout, 0, 0, 0, 0, _dt(dtype), hip.stream()),
+                          "st5_batchnorm_act_fwd")
+                nxt = None
+            else:
+                nxt = torch.empty(B, Lx + 2 * pad, Cout, dtype=dtype, device=dev)
+                hip.check(L.st5_batchnorm_act_fwd(x32.data_ptr(), gamma.data_ptr(), beta.data_ptr(), hip.ptr(rm), hip.ptr(rv), hip.ptr(nbt),
+                                                  mom_eff, eps, 1 if training else 0, ACT_TANH, p, seed, 0, nxt.data_ptr(), 0,
+                                                  stats.data_ptr(), ws.data_ptr(), B * Lx, Cout, Lx, (Lx + 2 * pad) * Cout, pad * Cout, pad,
+                                                  _dt(dtype), hip.stream()), "st5_batchnorm_act_fwd")
+            saved += [xp, x32, stats]
+            seeds.append((p, seed))
+            xp = nxt
+        ctx.save_for_backward(*saved)
+        ctx.meta = (params, training, seeds, B, Lx, pad, dtype)
+        return after
+
+    @staticmethod
+    def backward(ctx, d_after):
+        params, training, seeds, B, Lx, pad, dtype = ctx.meta
+        saved = ctx.saved_tensors
+        n = len(params) // 3
+        dev = d_after.device
+        L = hip.lib()
+        d_after = d_after.contiguous().float()
+        dy = d_after.view(B * Lx, -1)
+        d_before = None
+        for i in range(n - 1, -1, -1):
+            w, gamma, beta = params[3 * i: 3 * i + 3]
+            xp, x32, stats = saved[3 * i: 3 * i + 3]
+            Cout, Cin, k = w.shape
+            p, seed = seeds[i]
+            dxp = torch.empty(B, Lx + 2 * pad, Cout, dtype=dtype, device=dev)
+            ws = hip.workspace(L.st5_batchnorm_ws_bytes(Cout), dev)
+            gg = grad_buffer(gamma) if gamma.requires_grad else None
+            gb = grad_buffer(beta) if beta.requires_grad else None
+            hip.check(L.st5_batchnorm_act_bwd(x32.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), hip.ptr(gg),
+                                              hip.ptr(gb), 1 if training else 0, ACT_NONE if i == n - 1 else ACT_TANH, p, seed, dxp.data_ptr(),
+                                              ws.data_ptr(), B * Lx, Cout, Lx, (Lx + 2 * pad) * Cout, pad * Cout, pad, _dt(dtype), hip.stream()),
+                      "st5_batchnorm_act_bwd")
+            for q in (gamma, beta):
+                if q.requires_grad:
+                    _grad_done(q)
+            if w.requires_grad:
+                tmpw = torch.empty(Cout, k * Cin, dtype=torch.float32, device=dev)
+                hip.gemm(hip.operand(dxp, Cout, off=pad * Cout, rpb=Lx, bstride=(Lx + 2 * pad) * Cout),
+                         hip.operand(xp, Cin, rpb=Lx, bstride=(Lx + 2 * pad) * Cin), hip.operand(tmpw, k * Cin),
+                         Cout, k * Cin, B * Lx, _dt(dtype), flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
+                grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))   # (glue: layout permute of a <= 1.3 MB tensor)
+                _grad_done(w)
+            if i > 0 or ctx.needs_input_grad[0]:
+                def build(w=w, Cin=Cin, Cout=Cout, k=k):
+                    src = w.detach().flip(-1).permute(1, 2, 0).reshape(Cin, k * Cout).contiguous()  # [ci][jj][co]
+                    out = torch.empty(src.shape, dtype=dtype, device=dev)
+                    _cast_into(src, out)
+                    return out
+                Wd = weight_cache.get(("convw_d", dtype, id(w)), [w], build)
+                din = torch.empty(B * Lx, Cin, dtype=torch.float32, device=dev)
+                hip.gemm(hip.operand(dxp, Cout, rpb=Lx, bstride=(Lx + 2 * pad) * Cout), hip.operand(Wd, k * Cout), hip.operand(din, Cin),
+                         B * Lx, Cin, k * Cout, _dt(dtype), flags=hip.OUT_F32,
+                         R=hip.operand(d_after.view(B * Lx, -1), Cin) if i == 0 else None)
+                dy = din
+                if i == 0:
+                    d_before = din
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = (d_before if dtype == torch.float32 else to_compute(d_before)).view(B, Lx, -1)
+        return (gx, None, None) + (None,) * len(params)
+
+
+def postnet(before, blocks, training, dropout_p):
+    """blocks: the nn.Sequential blocks of espnet's Postnet (block[0] = Conv1d without bias, block[1] = BatchNorm1d)."""
+    params, bufs, cfg = [], [], []
+    for blk in blocks:
+        conv, bn = blk[0], blk[1]
+        params += [conv.weight, bn.weight, bn.bias]
+        bufs.append((bn.running_mean, bn.running_var, bn.num_batches_tracked))
+        cfg.append((float(bn.eps), bn.momentum))
+    return PostnetFunction.apply(before, (bool(training), float(dropout_p), cfg), bufs, *params)

@@ -4,7 +4,6 @@ import contextlib
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import functional as Fn
 
@@ -27,22 +26,11 @@ class Postnet(nn.Module):
             self.postnet.append(nn.Sequential(*mods))
 
     def forward(self, x):
-        """x [B, L, odim] channels-last (compute dtype).  Convolutions run on the implicit-GEMM kernel; the
-        BatchNorm statistics/affine and tanh on [B*L, C] (<1 % of the step) are still torch ops -- see DESIGN.md."""
-        n = len(self.postnet)
-        for i, blk in enumerate(self.postnet):
-            x = Fn.conv1d_same(x, blk[0].weight)
-            bn = blk[1]
-            B, L, C = x.shape
-            y = F.batch_norm(x.reshape(B * L, C).float(), bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                             bn.training, bn.momentum, bn.eps)
-            if bn.training and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
-            if i < n - 1:
-                y = torch.tanh(y)
-            x = y.to(x.dtype).view(B, L, C)
-            x = Fn.dropout(x, self.dropout_rate, self.training)
-        return x
+        """x = `before` [B, L, odim] channels-last (compute dtype) -> `after` = before + postnet(before), fp32 [B, L, odim].
+        Convolutions on the implicit-GEMM kernel (fp32 accumulators handed over), BatchNorm (batch statistics, running
+        statistics update) + tanh + dropout + the final residual on st5_batchnorm_act_* (functional.PostnetFunction)."""
+        training = self.postnet[0][1].training
+        return Fn.postnet(x, self.postnet, training, self.dropout_rate if self.training else 0.0)
 
 
 class SpeechDecoderPostnet(nn.Module):
@@ -68,10 +56,10 @@ class SpeechDecoderPostnet(nn.Module):
             before = both[..., :nf].reshape(B, -1, self.odim)
             logits = both[..., nf:].reshape(B, -1)
             if self.postnet is None:
-                after = before
+                after = Fn.as_float(before.contiguous())
             else:
-                after = Fn.add(before.contiguous(), self.postnet(before.contiguous()))
-        return Fn.as_float(before.contiguous()), Fn.as_float(after), Fn.as_float(logits.contiguous())
+                after = self.postnet(before.contiguous())   # fp32: before + post-net residual (fused into the last BatchNorm kernel)
+        return Fn.as_float(before.contiguous()), after, Fn.as_float(logits.contiguous())
 
     def set_num_updates(self, num_updates):
         self.num_updates = num_updates
