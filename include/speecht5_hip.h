@@ -142,16 +142,29 @@ int st5_flash_attn_fwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld,
                        int32_t S, int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal, int32_t lds, float scale,
                        float dropout_p, uint64_t seed, int dtype, void* stream);
 
-/* st5_flash_attn_fwd that also saves the relative-position bucket table it builds (qp_out [B*H, T, nb], dtype, =
- * scale*log2(e)*q.pe^T; NULL = do not save): the backward's `qp` input, so the caller needs no q.pe^T GEMM there. */
+/* Relative-position table of the fused kernels: QP[bh][q][row] (dtype) with row = st5_flash_attn_qp_row(nb) elements:
+ * second-generation kernels (default): [8 x QP[0] | scale*log2(e) * q.pe[b]^T, b = 0..nb-1 | 8 x QP[nb-1]] -- the replicated
+ * end chunks are what a clipped relative position reads, so clipping is a clamp of a 16-byte chunk index; first generation
+ * (st5_flash_attn_set_impl(1)): the plain nb values.  The kernels DMA per-tile windows of it into LDS.
+ * st5_flash_attn_qp_table builds it (the forward does this itself when given qp_out); the backward takes it as `qp`. */
+int32_t st5_flash_attn_qp_row(int32_t nb);
+int st5_flash_attn_qp_table(const void* q, int64_t q_ld, const void* pe, void* qp_out, int32_t B, int32_t H, int32_t T, int32_t nb,
+                            float scale, int dtype, void* stream);
+/* 2 (default): second-generation kernels (csrc/flash_attn2.hip: LDS-DMA staging, transpose reads, bias windows, two blocks per
+ * CU); 1: first generation (csrc/flash_attn.hip).  Same results bit for bit; A/B measurements and tests only. */
+int st5_flash_attn_set_impl(int impl);
+
+/* st5_flash_attn_fwd with the relative-position table workspace (qp_out [B*H, T, st5_flash_attn_qp_row(nb)], dtype; required by
+ * the second-generation kernels when pe != NULL -- without it the call runs the first-generation kernel, which keeps the table
+ * in LDS): built here, returned for the backward's `qp` input. */
 int st5_flash_attn_fwd_qp(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld, void* o,
                           int64_t o_ld, float* lse, const void* pe, const uint8_t* kpm, int32_t B, int32_t H, int32_t T,
                           int32_t S, int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal, int32_t lds, float scale,
                           float dropout_p, uint64_t seed, void* qp_out, int dtype, void* stream);
 
 /* Backward of st5_flash_attn_fwd: recomputes P from (q, k, bias, lse).  Writes dq/dk/dv (dtype, same row layouts as
- * q/k/v with their own leading dimensions); dvec fp32 [B*H*T] scratch (D = rowsum(dO*O)).  With pe: qp = scale*log2(e)*q.pe^T
- * [B*H, T, nb] (dtype, caller computes it with st5_gemm; the kernels evaluate exp2 in the log2 domain) and dqp [B*H, T, nb] receives the bucket gradients
+ * q/k/v with their own leading dimensions); dvec fp32 [B*H*T] scratch (D = rowsum(dO*O)).  With pe: qp = the relative-position table
+ * [B*H, T, st5_flash_attn_qp_row(nb)] (from st5_flash_attn_fwd_qp or st5_flash_attn_qp_table) and dqp [B*H, T, nb] (plain) receives the bucket gradients
  * (the caller folds dqp into dq and d(pe) with st5_gemm, exactly as for the unfused path). */
 int st5_flash_attn_bwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld, const void* o,
                        int64_t o_ld, const void* dout, int64_t do_ld, void* dq, int64_t dq_ld, void* dk, int64_t dk_ld, void* dv,

@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(256, BIAS ? 1 : 2) void flash_bwd_dkv_kernel(const 
 
 }  // namespace
 
-extern "C" int st5_flash_attn_fwd_qp(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
+extern "C" int st5_flash1_attn_fwd_qp(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
                                      void* o, int64_t o_ld, float* lse, const void* pe, const uint8_t* kpm, int32_t B, int32_t H,
                                      int32_t T, int32_t S, int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal,
                                      int32_t lds, float scale, float dropout_p, uint64_t seed, void* qp_out, int dtype,
@@ -1053,15 +1053,15 @@ extern "C" int st5_flash_attn_fwd_qp(const void* q, int64_t q_ld, const void* k,
   return ST5_OK;
 }
 
-extern "C" int st5_flash_attn_fwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
+extern "C" int st5_flash1_attn_fwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
                                   void* o, int64_t o_ld, float* lse, const void* pe, const uint8_t* kpm, int32_t B, int32_t H,
                                   int32_t T, int32_t S, int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal,
                                   int32_t lds, float scale, float dropout_p, uint64_t seed, int dtype, void* stream) {
-  return st5_flash_attn_fwd_qp(q, q_ld, k, k_ld, v, v_ld, o, o_ld, lse, pe, kpm, B, H, T, S, head_dim, nb, maxrel, causal, lds, scale,
+  return st5_flash1_attn_fwd_qp(q, q_ld, k, k_ld, v, v_ld, o, o_ld, lse, pe, kpm, B, H, T, S, head_dim, nb, maxrel, causal, lds, scale,
                                dropout_p, seed, nullptr, dtype, stream);
 }
 
-extern "C" int st5_flash_attn_bwd_2s(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
+extern "C" int st5_flash1_attn_bwd_2s(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
                                      const void* o, int64_t o_ld, const void* dout, int64_t do_ld, void* dq, int64_t dq_ld, void* dk,
                                      int64_t dk_ld, void* dv, int64_t dv_ld, const float* lse, float* dvec, const void* pe,
                                      const void* qp, void* dqp, const uint8_t* kpm, int32_t B, int32_t H, int32_t T, int32_t S,
@@ -1117,12 +1117,12 @@ extern "C" int st5_flash_attn_bwd_2s(const void* q, int64_t q_ld, const void* k,
   return ST5_OK;
 }
 
-extern "C" int st5_flash_attn_bwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
+extern "C" int st5_flash1_attn_bwd(const void* q, int64_t q_ld, const void* k, int64_t k_ld, const void* v, int64_t v_ld,
                                   const void* o, int64_t o_ld, const void* dout, int64_t do_ld, void* dq, int64_t dq_ld, void* dk,
                                   int64_t dk_ld, void* dv, int64_t dv_ld, const float* lse, float* dvec, const void* pe,
                                   const void* qp, void* dqp, const uint8_t* kpm, int32_t B, int32_t H, int32_t T, int32_t S,
                                   int32_t head_dim, int32_t nb, int32_t maxrel, int32_t causal, int32_t lds, float scale,
                                   float dropout_p, uint64_t seed, int dtype, void* stream) {
-  return st5_flash_attn_bwd_2s(q, q_ld, k, k_ld, v, v_ld, o, o_ld, dout, do_ld, dq, dq_ld, dk, dk_ld, dv, dv_ld, lse, dvec, pe, qp, dqp,
+  return st5_flash1_attn_bwd_2s(q, q_ld, k, k_ld, v, v_ld, o, o_ld, dout, do_ld, dq, dq_ld, dk, dk_ld, dv, dv_ld, lse, dvec, pe, qp, dqp,
                                kpm, B, H, T, S, head_dim, nb, maxrel, causal, lds, scale, dropout_p, seed, dtype, stream, nullptr);
 }

@@ -1047,18 +1047,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile_row, int off0, int of
   return u.v;
 }
 
-constexpr int TN_BK = 32;                 // k rows per pipeline stage
-constexpr int TN_NST = 4;                 // stages in the LDS ring
-constexpr int TN_OP_BYTES = TN_BK * 256;  // one operand, one stage: [32 k][128 m] bf16 = 8 KB
-constexpr int TN_ST_BYTES = 2 * TN_OP_BYTES;
-
-// Pipeline: k-stages of 32 rows in a 4-deep ring (64 KB: two blocks per CU), loads run THREE stages ahead with counted
-// vmcnt waits and one raw barrier per stage.  (The first version waited vmcnt(0) on a one-tile-ahead prefetch: with 0.25 us
-// of MFMA work per 64-row k-step against ~1.2 us of load latency every step exposed the latency -- 63 steps took 77 us
-// whatever M and N were, 60-250 TFLOP/s, half of hipBLASLt.)
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
   typedef bf16_t T;
-  constexpr int BK = TN_BK;
+  constexpr int BK = 64;
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -1074,13 +1065,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
   const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
 
-  // split-K range (in stages of TN_BK rows)
+  // split-K range
   const int nk_all = (p.K + BK - 1) / BK;
   const int per = (nk_all + gridDim.y - 1) / gridDim.y;
   const int kt0 = blockIdx.y * per;
   const int nk = (kt0 + per <= nk_all ? per : nk_all - kt0) > 0 ? (kt0 + per <= nk_all ? per : nk_all - kt0) : 0;
 
-  // LDS-DMA sources: wave-instruction i of this wave covers stage rows (i*4 + wave)*4 .. +3; lane l -> row + (l>>4),
+  // LDS-DMA sources: wave-instruction i of this wave covers tile rows (i*4 + wave)*4 .. +3; lane l -> row + (l>>4),
   // physical chunk l&15, logical chunk (l&15) ^ 4*(l>>4)
   const int lrow = lane >> 4;
   const int lchunk = (lane & 15) ^ (4 * lrow);
@@ -1089,15 +1080,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   const T* abase = Ap + m0 + lchunk * 8;
   const T* bbase = Bp + n0 + lchunk * 8;
   auto issue = [&](int kt, int buf) {
-    char* base = dsm + buf * TN_ST_BYTES + wave * 1024;
+    char* base = dsm + buf * 2 * TILE_BYTES + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int k = kt * BK + (i * 4 + wave) * 4 + lrow;
       const bool kin = k < p.K;
       const T* sa = (kin && a_col_ok) ? abase + (long long)k * p.A.ld : zero;
       const T* sb = (kin && b_col_ok) ? bbase + (long long)k * p.B.ld : zero;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)sa, (lds_ptr_t)(base + i * 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sb, (lds_ptr_t)(base + TN_OP_BYTES + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)sb, (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, 0);
     }
   };
 
@@ -1105,9 +1096,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
-#pragma unroll
-  for (int t = 0; t < TN_NST - 1; ++t)
-    if (t < nk) issue(kt0 + t, t);
+  if (nk > 0) issue(kt0, 0);
   // transpose-read addressing of this lane: group (g = m sub-block of 16, h = k half), i = l&15 -> j = i>>2 (k row), q = i&3
   const int g = (lane >> 4) & 1, h = lane >> 5, j = (lane & 15) >> 2, q = lane & 3;
   // byte offset inside a tile for (k = 8h + j [+4 for the second read] [+16 per k-step], m = mbase + 16g + 4q)
@@ -1124,21 +1113,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
 #pragma unroll
   for (int r = 0; r < 16; ++r) { sum0[r] = 0.f; sum1[r] = 0.f; }
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed when at most the loads of the stages behind it (4 per lane and stage) are outstanding
-    {
-      int ahead = nk - 1 - kt;
-      ahead = ahead < TN_NST - 2 ? ahead : TN_NST - 2;
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();   // publishes stage kt; every wave is done reading stage kt-1, whose buffer is refilled next
-    if (kt + TN_NST - 1 < nk) issue(kt0 + kt + TN_NST - 1, (kt + TN_NST - 1) % TN_NST);
-    const char* cur = dsm + (kt % TN_NST) * TN_ST_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt0 + kt + 1, (kt + 1) & 1);
+    const char* cur = dsm + (kt & 1) * 2 * TILE_BYTES;
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
+    for (int kg = 0; kg < 4; ++kg) {
       const char* ta = cur + kg * 16 * 256;
-      const char* tb = ta + TN_OP_BYTES;
+      const char* tb = ta + TILE_BYTES;
       const bf16x8 a0 = tr_frag(ta, oa0, oa0 + 4 * 256);
       const bf16x8 a1 = tr_frag(ta, oa1, oa1 + 4 * 256);
       const bf16x8 b0 = tr_frag(tb, ob0, ob0 + 4 * 256);
@@ -1179,7 +1161,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
 int launch_tn_glds(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, nsplit, p.batch), block(NTHREADS);
-  hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, block, (size_t)TN_NST * TN_ST_BYTES, s, p, c_vec_ok);
+  hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, block, (size_t)4 * TILE_BYTES, s, p, c_vec_ok);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

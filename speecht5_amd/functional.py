@@ -931,11 +931,12 @@ def _flash_fwd(q, k, v, B, H, T, S, hd, pe, maxrel, kpm, causal, p_drop, seed, s
     ctx = torch.empty(B * T, d, dtype=torch.bfloat16, device=dev)
     lse = torch.empty(B * H, T, dtype=torch.float32, device=dev)
     nb = pe.shape[0] if pe is not None else 0
-    qp = torch.empty(B * H, T, nb, dtype=torch.bfloat16, device=dev) if (save_qp and pe is not None) else None
+    # relative-position table workspace ([.., 8 | nb | 8] rows for the second-generation kernels); kept for the backward
+    qp = torch.empty(B * H, T, hip.lib().st5_flash_attn_qp_row(nb), dtype=torch.bfloat16, device=dev) if pe is not None else None
     hip.check(hip.lib().st5_flash_attn_fwd_qp(_eptr(q), q[1], _eptr(k), k[1], _eptr(v), v[1], ctx.data_ptr(), d, lse.data_ptr(),
                                               hip.ptr(pe), hip.ptr(kpm), B, H, T, S, hd, nb, maxrel, 1 if causal else 0, _ceil8(S),
                                               hd ** -0.5, p_drop, seed, hip.ptr(qp), hip.BF16, hip.stream()), "st5_flash_attn_fwd_qp")
-    return ctx, lse, qp
+    return ctx, lse, (qp if save_qp else None)
 
 
 def set_attention_stream(stream):
@@ -957,11 +958,10 @@ def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe
     qt, qld, qoff = q
     if pe is not None:
         nb = pe.shape[0]
-        if qp is None:
-            qp = torch.empty(BH, T, nb, dtype=dtype, device=dev)
-            # the kernels work in the log2 domain: qp = scale * log2(e) * q.pe^T
-            hip.gemm(hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd), hip.operand(pe, hd),
-                     hip.operand(qp, nb, zs0=H * T * nb, zs1=T * nb), T, nb, hd, hip.BF16, batch=BH, zdiv=H, alpha=alpha * _LOG2E)
+        if qp is None:   # the kernels work in the log2 domain: qp = scale * log2(e) * q.pe^T (+ replicated end chunks)
+            qp = torch.empty(BH, T, hip.lib().st5_flash_attn_qp_row(nb), dtype=dtype, device=dev)
+            hip.check(hip.lib().st5_flash_attn_qp_table(_eptr(q), q[1], pe.data_ptr(), qp.data_ptr(), B, H, T, nb, alpha, hip.BF16,
+                                                        hip.stream()), "st5_flash_attn_qp_table")
         dqp = torch.empty(BH, T, nb, dtype=dtype, device=dev)
     hip.check(hip.lib().st5_flash_attn_bwd_2s(_eptr(q), q[1], _eptr(k), k[1], _eptr(v), v[1], ctx.data_ptr(), d, dctx.data_ptr(), d,
                                               _eptr(dq), dq[1], _eptr(dk), dk[1], _eptr(dv), dv[1], lse.data_ptr(), dvec.data_ptr(),

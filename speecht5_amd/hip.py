@@ -71,6 +71,9 @@ _SIGS = {
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, c_float, c_float, c_uint64, c_int, c_void_p]),
+    "st5_flash_attn_set_impl": (c_int, [c_int]),
+    "st5_flash_attn_qp_row": (c_int32, [c_int32]),
+    "st5_flash_attn_qp_table": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_int, c_void_p]),
     "st5_conv0_gn_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                       c_int32, c_int32, c_int32, c_int32, c_float, c_int, c_void_p]),
     "st5_conv0_gn_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

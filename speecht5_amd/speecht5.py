@@ -342,7 +342,7 @@ class T5TransformerModel(FairseqEncoderDecoderModel):
                     continue
                 mel = torch.cat(outs, dim=0).unsqueeze(0)  # (1, L, odim)
                 if post.postnet is not None:
-                    mel = mel + Fn.as_float(post.postnet(Fn.as_compute(mel.contiguous())))
+                    mel = post.postnet(Fn.as_compute(mel.contiguous()))   # fp32: mel + post-net residual (fused in the last BatchNorm kernel)
                 mel = mel.squeeze(0)
                 probs = torch.cat(probs, dim=0)
                 attn = torch.cat(attns, dim=2)
