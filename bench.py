@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=8, help="speech clips (10 s) per GPU per step")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying a captured HIP graph")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,19 +127,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        step(i)
+    # One rank: the update is captured into a HIP graph after the warm-up steps and REPLAYED in the timed region (fresh dropout
+    # seeds / span masks / lr per replay: speecht5_amd/graph.py).  Several ranks: eager enqueue (RCCL collectives stay outside
+    # graphs here).  ST5_GRAPH=0 or --no-graph forces the eager path.
+    use_graph = world == 1 and not a.no_graph and os.environ.get("ST5_GRAPH", "1") == "1" and not dist.is_initialized()
+    counter = [0]
+
+    def one_update():
+        step(counter[0])
+
+    def advance():   # host-side state a replayed step does not touch: the update counter behind the quantizer temperature etc.
+        counter[0] += 1
+        model.set_num_updates(counter[0])
+
+    if use_graph:
+        from speecht5_amd.graph import StepGraph
+        sg = StepGraph(one_update, opt=opt, model=model, device=device, on_step=advance)
+        for i in range(max(a.warmup - 2, 1)):
+            step(i)
+        counter[0] = max(a.warmup - 2, 1) - 1
+        sg.record()
+        sg.record()
+        sg.capture()
+        run = sg.replay
+    else:
+        for i in range(a.warmup):
+            step(i)
+        run = lambda: step(a.warmup)
     barrier()
     hip.profiler.reset()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        # roofline leg: HIP events around every st5_gemm launch of the LAST timed step (recording them on all K steps
-        # costs ~10 % of the step in host time: two events per launch, ~750 launches per step)
-        hip.profiler.enabled = (i == a.steps - 1)
-        step(a.warmup + i)
+        # eager mode: HIP events around every st5_gemm launch of the LAST timed step (recording them on all K steps costs
+        # ~10 % of the step in host time: two events per launch, ~750 launches per step)
+        hip.profiler.enabled = (not use_graph) and (i == a.steps - 1)
+        run()
     barrier()
     dt = time.perf_counter() - t0
     hip.profiler.enabled = False
+    if use_graph:
+        # roofline leg of the graph mode: the replayed launches carry no events, so the SAME update is enqueued once more
+        # eagerly, outside the timed region, with HIP events around every st5_gemm launch (same kernels, shapes, streams)
+        hip.profiler.enabled = True
+        step(a.warmup)
+        torch.cuda.synchronize()
+        hip.profiler.enabled = False
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,6 +217,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "SpeechT5-Base pretrain step (speech 8x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
                                       "fwd+bwd+allreduce+clip+Adam, per GPU", "arch": "t5_transformer_base (12 enc + 6 dec, d=768)",
+                          "enqueue": "hip-graph replay" if use_graph else "eager",
                           "global_speech_batch": a.batch * world, "clip_seconds": 10, "parallelism": f"dp{world}",
                           "dropout": 0.1, "layerdrop": 0.0},
                "roofline": roof}

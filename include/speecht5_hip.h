@@ -299,6 +299,15 @@ int st5_cross_entropy_rows(const void* logits, const int32_t* target, float* row
 int st5_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
                   void* bf16_mirror /* optional bf16 [n]: receives the updated parameters in the compute dtype */, void* stream);
+/* The same with the learning rate and the step count read from DEVICE memory (hyper_dev = {lr, step} as two floats; NULL =
+ * the by-value arguments): the form a captured HIP graph replays -- its kernel arguments are frozen, the host rewrites the two
+ * floats before every replay. */
+int st5_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale, void* bf16_mirror,
+                      const float* hyper_dev, void* stream);
+/* Dropout seeds: every `seed` argument of this library may instead be a device pointer to the 64-bit seed, tagged with bit 63
+ * (seed = (1 << 63) | pointer): the kernels then read the seed from memory (csrc/common.h resolve_seed).  Used by captured HIP
+ * graphs, whose kernel arguments cannot change between replays. */
 /* Batched bf16 matrix transposes in one launch.  jobs_dev: device array of {int64 src_off, int64 dst_off, int32 rows,
  * int32 cols, int32 tile0, int32 pad} sorted by tile0 (first 64x64 tile index of the job), offsets in elements into
  * src_flat / dst_flat; ntiles = total tile count.  Used for the transposed weight copies of the data-gradient GEMMs

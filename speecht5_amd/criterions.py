@@ -173,7 +173,7 @@ class SpeechPretrainCriterion(nn.Module):
             log[f"loss_m_{i}"] = _item(l, s)
         if self.pred_masked_weight > 0:
             loss = loss + self.pred_masked_weight * sum(loss_m_list)
-            sample_size += targ_m_list[0].numel()
+            sample_size = sample_size + model.get_target_count(net_output, True)
         logp_u_list = model.get_logits(net_output, False)
         targ_u_list = model.get_targets(None, net_output, False)
         loss_u_list = []
@@ -183,7 +183,7 @@ class SpeechPretrainCriterion(nn.Module):
             log[f"loss_u_{i}"] = _item(l, s)
         if self.pred_nomask_weight > 0:
             loss = loss + self.pred_nomask_weight * sum(loss_u_list)
-            sample_size += targ_u_list[0].numel()
+            sample_size = sample_size + model.get_target_count(net_output, False)
         if self.loss_weights is not None:
             extra_losses, names = model.get_extra_losses(net_output)
             lw = self.loss_weights

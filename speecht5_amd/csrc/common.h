@@ -169,8 +169,16 @@ __device__ __forceinline__ unsigned int dropout_thresh(float p) { return (unsign
 // 32-bit key of a 64-element block.  The seed part (splitmix64 of the seed, folded) is wave-uniform and loop-invariant,
 // so it is computed once on the scalar unit; the per-block part is one xorshift-multiply mixer on full-rate 24-bit
 // multiplies (different constants from the per-pair mixer below).
+// A `seed` argument with bit 63 set is not a seed but a device POINTER (low 48 bits) to the 64-bit seed.  Host code hands out
+// such slots when a training step is captured into a HIP graph (speecht5_amd/graph.py): the kernel arguments stay constant
+// across replays while the host refreshes the slots' contents before every replay, so each replay draws fresh dropout masks.
+// The pointer derives from a kernel argument, i.e. it is wave-uniform: the load is one scalar load per wave.
+__device__ __forceinline__ unsigned long long resolve_seed(unsigned long long seed) {
+  if (seed >> 63) seed = *reinterpret_cast<const unsigned long long*>(seed & 0x0000FFFFFFFFFFFFull);
+  return seed;
+}
 __device__ __forceinline__ unsigned int drop_block_key(unsigned long long seed, unsigned long long block) {
-  const unsigned long long h = rng_hash64(seed, 0ull);
+  const unsigned long long h = rng_hash64(resolve_seed(seed), 0ull);
   unsigned int x = (unsigned int)block ^ (unsigned int)h ^ (unsigned int)(h >> 32) ^ __umul24((unsigned int)(block >> 32), 0x9E3779u);
   x ^= x >> 15; x = __umul24(x, 0x9E3779u);
   x ^= x >> 12; x = __umul24(x, 0x85EBCBu);

@@ -7,12 +7,20 @@
 #include "../../include/speecht5_hip.h"
 
 namespace {
+// hyper: optional device array {lr, step} that overrides the by-value lr / bias corrections (a captured HIP graph replays
+// constant kernel arguments; the host refreshes these two floats before every replay)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ mirror, long long n,
                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
                                                    float bc2, const float* __restrict__ gnorm_sq, float max_norm,
-                                                   float gscale) {
+                                                   float gscale, const float* __restrict__ hyper) {
+  if (hyper) {
+    lr = hyper[0];
+    const float t = hyper[1];
+    bc1 = 1.f - powf(b1, t);
+    bc2 = 1.f - powf(b2, t);
+  }
   float coef = gscale;
   if (gnorm_sq && max_norm > 0.f) {
     const float norm = sqrtf(gnorm_sq[0]) * gscale;
@@ -84,10 +92,21 @@ __global__ __launch_bounds__(256) void multi_transpose_kernel(const bf16_t* __re
 }
 }  // namespace
 
+extern "C" int st5_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
+                                 void* bf16_mirror, const float* hyper_dev, void* stream);
+
 extern "C" int st5_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int32_t step, const float* gnorm_sq,
                              float max_norm, float grad_scale, void* bf16_mirror, void* stream) {
-  if (!p || !g || !m || !v || n < 0 || step < 1) return ST5_ERR_ARG;
+  return st5_adam_step_dev(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq, max_norm, grad_scale, bf16_mirror, nullptr,
+                           stream);
+}
+
+extern "C" int st5_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
+                                 void* bf16_mirror, const float* hyper_dev, void* stream) {
+  if (!p || !g || !m || !v || n < 0 || (step < 1 && !hyper_dev)) return ST5_ERR_ARG;
   if (n == 0) return ST5_OK;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   long long blocks = (n / 4 + 255) / 256;
@@ -95,7 +114,7 @@ extern "C" int st5_adam_step(float* p, const float* g, float* m, float* v, int64
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)bf16_mirror,
                      (long long)n,
-                     lr, beta1, beta2, eps, weight_decay, bc1, bc2, gnorm_sq, max_norm, grad_scale);
+                     lr, beta1, beta2, eps, weight_decay, bc1, bc2, gnorm_sq, max_norm, grad_scale, hyper_dev);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

@@ -345,6 +345,21 @@ class FusedAdam:
         self.v = torch.zeros_like(self.pflat)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.t = 0
+        # {lr, step} in device memory: what the kernel reads when the step runs from a captured graph (graph.StepGraph), whose
+        # kernel arguments are frozen; refreshed from the host image before every replay
+        self.hyper_dev = None
+        self.hyper_host = None
+
+    def enable_device_hyper(self):
+        dev = self.pflat.device
+        self.hyper_dev = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+
+    def push_hyper(self):
+        """Host -> device copy of (lr, next step count); call before the step that will read it."""
+        self.hyper_host[0] = float(self.lr)
+        self.hyper_host[1] = float(self.t + 1)
+        self.hyper_dev.copy_(self.hyper_host, non_blocking=True)
 
     def backward(self, loss):
         loss.backward()
@@ -356,11 +371,11 @@ class FusedAdam:
         g = self.ddp.flat
         if self.clip > 0:
             hip.check(L.st5_sumsq(g.data_ptr(), self.gnorm_sq.data_ptr(), g.numel(), 1.0, 0, hip.F32, hip.stream()), "st5_sumsq")
-        hip.check(L.st5_adam_step(self.pflat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), g.numel(), self.lr,
-                                  self.betas[0], self.betas[1], self.eps, self.wd, self.t,
-                                  self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
-                                  self.wflat.data_ptr() if self.mirror is not None else 0, hip.stream()),
-                  "st5_adam_step")
+        hip.check(L.st5_adam_step_dev(self.pflat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), g.numel(), self.lr,
+                                      self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                      self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
+                                      self.wflat.data_ptr() if self.mirror is not None else 0, hip.ptr(self.hyper_dev), hip.stream()),
+                  "st5_adam_step_dev")
         # parameters changed in place through the flat view: invalidate the compute-dtype weight cache (entries that do
         # not come from the bf16 image: conv / fp32 / non-adjacent stacks) and refresh the transposed copies
         Fn.weight_cache.clear()

@@ -18,7 +18,7 @@ from . import hip
 from .hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH  # noqa: F401
 
 _S = SimpleNamespace(dtype=torch.float32, seed=0x5EED, counter=0, grad_hook=None, boundary_hook=None, side=None, side_raw=0,
-                     side_keep=[], side_gens=[], side_n=0, attn_side=None, attn_side_raw=None)
+                     side_keep=[], side_gens=[], side_n=0, attn_side=None, attn_side_raw=None, slots=None, force_static=False)
 
 
 def set_compute_dtype(dtype):
@@ -31,14 +31,102 @@ def compute_dtype():
 
 
 def manual_seed(seed):
-    _S.seed = int(seed) & 0xFFFFFFFF
+    _S.seed = int(seed) & 0x7FFFFFFF   # 31 bits: bit 63 of a kernel's seed argument tags a seed-slot pointer (next_seed)
     _S.counter = 0
 
 
 def next_seed():
-    """A fresh 64-bit dropout seed (host-side counter; the kernels hash (seed, element index))."""
+    """A fresh 64-bit dropout seed (host-side counter; the kernels hash (seed, element index)).  While a step is recorded /
+    captured for graph replay (speecht5_amd/graph.py) the return value is instead a tagged device pointer to a seed SLOT (bit
+    63 set, csrc/common.h resolve_seed); the slots are refilled before every replay with exactly the values the host
+    counter would have produced, so eager and replayed steps draw the same masks."""
+    if _S.slots is not None:
+        return _S.slots.take()
     _S.counter += 1
     return ((_S.seed << 32) | (_S.counter & 0xFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+
+
+class SeedSlots:
+    """Device array of 64-bit seeds + its pinned host image; slot k of a step holds the k-th next_seed() of that step."""
+
+    def __init__(self, n, device):
+        self.n = n
+        self.dev = torch.zeros(n, dtype=torch.int64, device=device)
+        self.host = torch.zeros(n, dtype=torch.int64).pin_memory()
+        self.k = 0          # slots handed out in the step being recorded / captured
+        self.used = 0       # slots one step uses (fixed after the recording step)
+
+    def take(self):
+        assert self.k < self.n, "seed slots exhausted: raise StepGraph(seed_slots=...)"
+        v = (1 << 63) | (self.dev.data_ptr() + 8 * self.k)
+        self.k += 1
+        return v
+
+    def begin_step(self):
+        """Fill the slots with the seeds the host counter yields for this step (same values as the eager path)."""
+        n = self.used if self.used else self.n
+        base = _S.counter
+        import numpy as np
+        vals = ((np.uint64(_S.seed) << np.uint64(32)) | ((np.arange(1, n + 1, dtype=np.uint64) + np.uint64(base)) & np.uint64(0xFFFFFFFF)))
+        self.host[:n] = torch.from_numpy(vals.astype(np.int64))
+        self.dev.copy_(self.host, non_blocking=True)
+        _S.counter += n
+        self.k = 0
+
+
+# Host-produced step inputs (random span masks, time-mix indices, ...): in eager mode a plain host->device copy; while a
+# step is RECORDED the tensor gets a persistent device buffer + pinned host image and the producer is remembered; while the
+# step is CAPTURED the buffer is returned as is (a captured graph must not copy from pageable host memory, and must read
+# the same addresses on every replay); before every REPLAY graph.StepGraph re-runs the producers in recording order and
+# refreshes the buffers.
+class HostStaging:
+    def __init__(self):
+        self.mode = None          # None | "record" | "capture"
+        self.entries = []         # [dev, pinned, producer]
+        self.i = 0
+
+    def begin_step(self, mode):
+        self.mode = mode
+        self.i = 0
+
+    def get(self, producer, device):
+        if self.mode is None:
+            return producer().to(device, non_blocking=True)
+        if self.mode == "record":
+            h = producer()
+            if self.i == len(self.entries):
+                self.entries.append([torch.empty(h.shape, dtype=h.dtype, device=device), torch.empty(h.shape, dtype=h.dtype).pin_memory(), producer])
+            e = self.entries[self.i]
+            assert e[1].shape == h.shape and e[1].dtype == h.dtype, "a staged step input changed shape between steps"
+            e[2] = producer
+            e[1].copy_(h)
+            e[0].copy_(e[1], non_blocking=True)
+            self.i += 1
+            return e[0]
+        e = self.entries[self.i]   # capture: contents were refreshed by refresh()
+        self.i += 1
+        return e[0]
+
+    def refresh(self):
+        for e in self.entries:
+            h = e[2]()
+            assert e[1].shape == h.shape
+            e[1].copy_(h)
+            e[0].copy_(e[1], non_blocking=True)
+
+
+staging = HostStaging()
+
+
+def stage_host(producer, device):
+    """Device copy of the CPU tensor `producer()` returns (see HostStaging)."""
+    return staging.get(producer, device)
+
+
+def static_shapes():
+    """True while a step is recorded / captured for graph replay: data-dependent shapes (boolean-index gathers) are replaced by
+    their fixed-shape forms (all rows + per-row weights)."""
+    return staging.mode is not None or _S.force_static
 
 
 def set_grad_ready_hook(fn):
@@ -394,6 +482,8 @@ def _side_hold(keep):
     pinned at a time even when no bucket boundary joins the streams (one rank: the only join is in finish())."""
     _S.side_keep.extend(keep)
     _S.side_n += 1
+    if staging.mode == "capture":
+        return   # (event queries are illegal during stream capture; the graph's private pool keeps the memory anyway)
     if _S.side_n % 16 == 0:
         ev = torch.cuda.Event()
         ev.record(_S.side)

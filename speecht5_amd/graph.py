@@ -1,0 +1,98 @@
+"""One optimizer update as a HIP graph (hipStreamBeginCapture through torch.cuda.CUDAGraph): the step's ~2000 kernel launches
+are enqueued once and replayed with a single call, which takes the host (36-48 ms of Python / ctypes enqueue per step, more
+than the GPU needs once the kernels are fast) off the critical path and removes the launch gaps between dependent kernels.
+
+What makes a training step replayable:
+  * dropout seeds live in device memory (functional.SeedSlots: a `seed` argument with bit 63 set is a pointer, csrc/common.h
+    resolve_seed), refilled before every replay with the values the eager path's host counter would have produced;
+  * host-produced step inputs (HuBERT span mask and code-book time-mix from the CPU RNGs, target index maps) go through
+    functional.stage_host: persistent device buffers + pinned host images, refreshed before every replay in recording order,
+    so the numpy / torch CPU random streams advance exactly as in eager mode;
+  * data-dependent shapes are replaced by fixed-shape forms while recording (functional.static_shapes(): the NCE head scores
+    every frame and passes selection masks; the sample size becomes a device scalar);
+  * the optimizer reads the learning rate and step count from device memory (FusedAdam.enable_device_hyper).
+Not supported in a captured step (asserted): LayerDrop (host-side control flow would be frozen), multi-rank collectives
+(the N > 1 path stays eager), host reads of device values."""
+import torch
+
+from . import functional as Fn
+
+
+class StepGraph:
+    def __init__(self, step_fn, opt=None, model=None, device=None, seed_slots=1024, on_step=None):
+        """step_fn(): one full update on the current stream -- zero_grad, forward/backward of every micro-batch, finish,
+        optimizer step -- without host synchronisation.  `opt`: the FusedAdam whose (lr, step) must follow the host."""
+        self.step_fn = step_fn
+        self.on_step = on_step   # host-side bookkeeping a replay skips (e.g. model.set_num_updates(n)): called before every step
+        self.opt = opt
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.graph = None
+        self.slots = Fn.SeedSlots(seed_slots, self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        if model is not None:
+            for m in model.modules():
+                assert getattr(m, "encoder_layerdrop", 0.0) in (0, 0.0) and getattr(m, "decoder_layerdrop", 0.0) in (0, 0.0), \
+                    "LayerDrop decisions are host control flow: not replayable"
+        if opt is not None and opt.hyper_dev is None:
+            opt.enable_device_hyper()
+
+    # -- one step in a given staging mode ------------------------------------------------------------------------------
+    def _run(self, mode):
+        Fn._S.slots = self.slots
+        Fn.staging.begin_step(mode)
+        try:
+            self.step_fn()
+        finally:
+            Fn._S.slots = None
+            Fn.staging.mode = None
+
+    def record(self):
+        """Eager step that allocates the static buffers and counts the seed slots (also the last warm-up step)."""
+        if self.on_step is not None:
+            self.on_step()
+        if self.opt is not None:
+            self.opt.push_hyper()
+        self.slots.begin_step()
+        self._run("record")
+        if not self.slots.used:
+            self.slots.used = self.slots.k
+            Fn._S.counter -= self.slots.n - self.slots.used   # begin_step() reserved all slots: give the unused ones back
+        else:
+            assert self.slots.k == self.slots.used, "the step's dropout call sequence changed"
+
+    def capture(self):
+        torch.cuda.synchronize(self.device)
+        self._pre_replay()
+        self.graph = torch.cuda.CUDAGraph()
+        t0 = self.opt.t if self.opt is not None else 0
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+            self._run("capture")
+        # the capture pass itself executed nothing: the host-side step counter it advanced is rolled back
+        if self.opt is not None:
+            self.opt.t = t0
+        assert self.slots.k == self.slots.used, "the captured step used a different number of dropout seeds than the recorded one"
+        self._pending = True   # buffers are already staged for the first replay
+
+    def _pre_replay(self):
+        if self.on_step is not None:
+            self.on_step()
+        self.slots.begin_step()
+        Fn.staging.refresh()
+        if self.opt is not None:
+            self.opt.push_hyper()
+
+    def replay(self):
+        if self._pending:
+            self._pending = False
+        else:
+            self._pre_replay()
+        self.graph.replay()
+        if self.opt is not None:
+            self.opt.t += 1
+
+    def __call__(self):
+        if self.graph is None:
+            self.record()
+            self.record()   # second recording step: confirms that the slot / staging sequence repeats
+            self.capture()
+        self.replay()

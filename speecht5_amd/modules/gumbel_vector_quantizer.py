@@ -38,7 +38,10 @@ class GumbelVectorQuantizer(nn.Module):
 
     def sample(self, logits):
         """Training-time hard Gumbel-softmax (straight-through); overridable for parity tests."""
-        return F.gumbel_softmax(logits.float(), tau=self.curr_temp, hard=True).type_as(logits)
+        tau = self.curr_temp
+        if Fn.static_shapes():   # the temperature decays with the update count: a replayed step reads it from device memory
+            tau = Fn.stage_host(lambda: torch.tensor([float(self.curr_temp)], dtype=torch.float32), logits.device)
+        return F.gumbel_softmax(logits.float(), tau=tau, hard=True).type_as(logits)
 
     def forward(self, x, produce_targets=False):
         result = {"num_vars": self.num_vars * self.groups}

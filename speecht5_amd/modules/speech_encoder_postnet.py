@@ -38,6 +38,8 @@ class SpeechEncoderPostnet(nn.Module):
     def forward(self, x, padding_mask, mask_indices, target_list):
         """x [B,T,C] (compute dtype).  Boolean-index gathers are torch glue, the projection is the HIP GEMM."""
         label_embs_list = self.label_embs_concat.split(self.num_classes, 0)
+        if Fn.static_shapes():
+            return self._forward_static(x, padding_mask, mask_indices, target_list, label_embs_list)
 
         host = getattr(mask_indices, "_st5_host", None)
 
@@ -69,3 +71,23 @@ class SpeechEncoderPostnet(nn.Module):
         else:
             logit_u_list = [None for _ in target_list]
         return {"logit_m_list": logit_m_list, "logit_u_list": logit_u_list, "padding_mask": padding_mask}
+
+    def _forward_static(self, x, padding_mask, mask_indices, target_list, label_embs_list):
+        """Fixed-shape form for recorded / replayed steps: the boolean-index gathers above have data-dependent sizes (the span
+        mask is redrawn every step), which a captured graph cannot hold.  Here EVERY frame is projected and scored; `sel_m` /
+        `sel_u` say which frames each loss runs over (the criterion turns them into ignored targets and into the sample
+        size).  Same per-frame logits, same sums."""
+        R = x.shape[0] * x.shape[1]
+        proj = Fn.linear(x.reshape(R, x.shape[-1]).contiguous(), self.final_proj.weight, self.final_proj.bias)
+        projs = proj.chunk(len(target_list), dim=-1) if self.untie_final_proj else [proj] * len(target_list)
+        logits = []
+        for i, (p, t) in enumerate(zip(projs, target_list)):
+            tg = t.reshape(-1)
+            emb = label_embs_list[i]
+            logits.append(self.compute_nce(Fn.as_float(p.contiguous()), emb[tg.long()], emb, tg))
+        valid = ~padding_mask
+        out = {"padding_mask": padding_mask,
+               "logit_m_list": [None] * len(target_list) if self.skip_masked else logits,
+               "logit_u_list": [None] * len(target_list) if self.skip_nomask else logits,
+               "sel_m": torch.logical_and(valid, mask_indices).reshape(-1), "sel_u": torch.logical_and(valid, ~mask_indices).reshape(-1)}
+        return out

@@ -127,7 +127,12 @@ class SpeechEncoderPrenet(nn.Module):
             targ_tsz = min([t.size(1) for t in target_list])
             if self.feat2tar_ratio * T > targ_tsz:
                 T = int(targ_tsz / self.feat2tar_ratio)
-        pm_host = padding_mask.cpu()
+        pm_host = getattr(padding_mask, "_st5_host", None)
+        if pm_host is None:
+            # one device->host read of the input padding mask, remembered on the tensor (a recorded / replayed step keeps the
+            # same sample tensors; the collater could hand over the host copy it already has the same way)
+            pm_host = padding_mask.cpu()
+            padding_mask._st5_host = pm_host
         extra = pm_host.size(1) % T
         pmh = pm_host[:, :-extra] if extra > 0 else pm_host
         frame_pad_host = pmh.view(pmh.size(0), T, -1).all(-1)  # == forward_padding_mask() on the host
@@ -150,6 +155,7 @@ class SpeechEncoderPrenet(nn.Module):
         if mask:
             if pre_mask is None and self.mask_prob > 0:
                 # (target-trimmed path: the frame padding mask depends on the trimmed feature length)
+                assert not Fn.static_shapes(), "graph capture needs the frame padding mask to follow from the input lengths"
                 fp_host = encoder_padding_mask.cpu()
                 pre_mask = self._sample_mask(x.size(0), x.size(1), fp_host, x.device)
             x, mask_indices = self.apply_hubert_mask(x, encoder_padding_mask, pre_mask)
@@ -178,7 +184,8 @@ class SpeechEncoderPrenet(nn.Module):
         if self.feat2tar_ratio * feat_tsz > targ_tsz:
             feat_tsz = int(targ_tsz / self.feat2tar_ratio)
             features = features[:, :feat_tsz].contiguous()
-        target_inds = (torch.arange(feat_tsz).float() * self.feat2tar_ratio).long().to(features.device, non_blocking=True)
+        ratio = self.feat2tar_ratio
+        target_inds = Fn.stage_host(lambda: (torch.arange(feat_tsz).float() * ratio).long(), features.device)
         target_list = [t.index_select(1, target_inds) for t in target_list]
         return features, target_list
 
@@ -194,11 +201,16 @@ class SpeechEncoderPrenet(nn.Module):
 
     def _sample_mask(self, B, T, frame_pad_host, device):
         """HuBERT span mask from the numpy RNG (speech_encoder_prenet.py:237-247) -> (device bool [B,T], host copies)."""
-        m = compute_mask_indices((B, T), frame_pad_host, self.mask_prob, self.hubert_mask_length, self.mask_selection,
-                                 self.mask_other, min_masks=2, no_overlap=self.no_mask_overlap, min_space=self.mask_min_space)
-        mt = torch.from_numpy(m)
-        dev = mt.to(device, non_blocking=True)
-        dev._st5_host = (mt, frame_pad_host)  # host copies: the NCE head derives its gather indices without a device sync
+        box = {}
+
+        def draw():
+            m = compute_mask_indices((B, T), frame_pad_host, self.mask_prob, self.hubert_mask_length, self.mask_selection,
+                                     self.mask_other, min_masks=2, no_overlap=self.no_mask_overlap, min_space=self.mask_min_space)
+            box["mt"] = torch.from_numpy(m)
+            return box["mt"]
+        dev = Fn.stage_host(draw, device)
+        if "mt" in box:   # host copies: the NCE head derives its gather indices without a device sync (eager mode)
+            dev._st5_host = (box["mt"], frame_pad_host)
         return dev
 
     def apply_hubert_mask(self, x, padding_mask, pre_mask=None):

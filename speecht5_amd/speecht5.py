@@ -172,8 +172,22 @@ class T5TransformerModel(FairseqEncoderDecoderModel):
 
     def get_targets(self, sample, net_output, is_masked=True):
         if "logit_m_list" in net_output:
+            sel = net_output.get("sel_m" if is_masked else "sel_u")
+            if sel is not None:
+                # fixed-shape form (recorded / replayed steps): logits of ALL frames; the frames outside the (un)masked set
+                # get the ignored target -1, the others class 0 as in the reference
+                return [(sel.long() - 1) for _ in self.get_logits(net_output, is_masked)]
             return [x.new_zeros(x.size(0), dtype=torch.long) for x in self.get_logits(net_output, is_masked)]
         return sample["target"]
+
+    def get_target_count(self, net_output, is_masked=True):
+        """Number of frames the (un)masked prediction loss runs over: the reference's `targ_list[0].numel()`
+        (speech_pretrain_criterion.py:117,127) -- a Python int, or a device scalar in the fixed-shape form."""
+        sel = net_output.get("sel_m" if is_masked else "sel_u")
+        if sel is not None:
+            return sel.sum().float()
+        lg = self.get_logits(net_output, is_masked)
+        return lg[0].size(0) if lg else 0
 
     def get_extra_losses(self, net_output):
         extra_losses, names = [], []
@@ -232,10 +246,13 @@ class T5TransformerModel(FairseqEncoderDecoderModel):
             enc_btc = encoder_output["encoder_out"][0].transpose(0, 1)
             q = self.quantizer(enc_btc)
             tlen = q["x"].size(1)
-            random_idx = torch.randperm(tlen)[:int(tlen * self.codebook_prob)]
-            q_w_host = torch.zeros(tlen)
-            q_w_host[random_idx] = 1.0
-            q_w = q_w_host.to(q["x"].device, non_blocking=True)  # built on the host: no device-side index_put / sync
+            n_mix = int(tlen * self.codebook_prob)
+
+            def draw_mix():   # built on the host: no device-side index_put / sync
+                w = torch.zeros(tlen)
+                w[torch.randperm(tlen)[:n_mix]] = 1.0
+                return w
+            q_w = Fn.stage_host(draw_mix, q["x"].device)
             # time-wise mix of quantised codes and encoder states (:870-877); fp32 torch arithmetic on [B,T,d]
             mixed = q_w.view(-1, 1) * q["x"] + (-q_w + 1).view(-1, 1) * Fn.as_float(enc_btc.contiguous())
             encoder_output["encoder_out"][0] = mixed.transpose(0, 1)

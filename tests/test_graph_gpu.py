@@ -1,0 +1,103 @@
+"""HIP-graph replay of a whole optimizer update (speecht5_amd/graph.py) against the eager path on the tiny model with dropout
+on: two micro-batches (speech + text, update-freq 2), gradient clipping, fused Adam.
+
+ * replayed steps == the same steps enqueued eagerly in the fixed-shape form, BIT FOR BIT (same kernels, same device-side seeds,
+   same staged span masks / time-mix draws, same lr / step count): parameters and Adam moments after 3 updates;
+ * the fixed-shape form (every frame scored, selection masks) == the reference-shaped form (boolean-index gathers) to fp32
+   round-off of the loss reductions."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import Task, load_golden, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cuda, dtype):
+    from argparse import Namespace
+    from speecht5_amd import functional as Fn
+    from speecht5_amd.criterions import SpeechT5Criterion
+    from speecht5_amd.ddp import FlatGradDataParallel, FusedAdam
+    from speecht5_amd.speecht5 import T5TransformerModel
+    from speecht5_amd.task import SpeechT5Task
+    m, fx_s = load_golden("tiny_speech_pretrain.pt")
+    _, fx_t = load_golden("tiny_text_pretrain.pt")
+    args = Namespace(**m["args"])
+    for k in ("dropout", "attention_dropout", "activation_dropout"):
+        setattr(args, k, 0.1)
+    args.dprenet_dropout_rate = 0.5
+    args.postnet_dropout_rate = 0.5
+    Fn.set_compute_dtype(dtype)
+    task = SpeechT5Task(args, Task().dicts)
+    model = T5TransformerModel.build_model(args, task)
+    torch.nn.Module.load_state_dict(model, m["state_dict"], strict=True)
+    model = model.to(cuda)
+    crit = SpeechT5Criterion(task, loss_weights=[10, 0.1], sync_logging=False)
+    ddp = FlatGradDataParallel(model)
+    opt = FusedAdam(ddp, lr=1e-3, clip_norm=1.0, weight_decay=0.01)
+    micro = [to_dev(fx_s["sample"], cuda), to_dev(fx_t["sample"], cuda)]
+    return Fn, task, model, crit, ddp, opt, micro
+
+
+def _run(cuda, dtype, mode, nsteps=3):
+    Fn, task, model, crit, ddp, opt, micro = _setup(cuda, dtype)
+    try:
+        Fn.manual_seed(99)
+        np.random.seed(5)
+        torch.manual_seed(5)
+        n = [0]
+
+        def step():
+            ddp.zero_grad()
+            ddp.accumulate(micro, lambda s: task.train_step(s, model, crit, None, n[0], sync=False))
+            ddp.finish()
+            opt.step(grad_scale=0.5)
+
+        def advance():   # host-side bookkeeping before every update (what a trainer does between steps)
+            n[0] += 1
+            model.set_num_updates(n[0])
+            opt.lr = 1e-3 * (1 + 0.1 * n[0])          # a schedule: the replayed step must follow the host's learning rate
+
+        if mode == "graph":
+            from speecht5_amd.graph import StepGraph
+            sg = StepGraph(step, opt=opt, model=model, device=cuda, on_step=advance)
+            sg.record(); sg.record(); sg.capture()
+            for _ in range(nsteps - 2):
+                sg.replay()
+        else:
+            Fn._S.force_static = mode == "static"
+            for _ in range(nsteps):
+                advance()
+                step()
+        torch.cuda.synchronize()
+        return opt.pflat.clone(), opt.m.clone(), opt.v.clone(), opt.t
+    finally:
+        Fn._S.force_static = False
+        ddp.close()
+        Fn.bf16_mirror.__init__()
+        Fn.weight_cache.clear()
+        Fn.set_layer_boundary_hook(None)
+        Fn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_graph_replay_equals_eager_fixed_shape_bitwise(cuda, dtype):
+    pg, mg, vg, tg = _run(cuda, dtype, "graph", 4)
+    ps, ms, vs, ts = _run(cuda, dtype, "static", 4)
+    assert tg == ts == 4
+    assert torch.isfinite(pg).all()
+    for a, b, name in ((pg, ps, "parameters"), (mg, ms, "first moment"), (vg, vs, "second moment")):
+        if not torch.equal(a, b):
+            d = (a - b).abs()
+            raise AssertionError(f"{name}: {int((d > 0).sum())} of {d.numel()} differ, max {float(d.max()):.3e}")
+    assert float((pg - _run(cuda, dtype, "static", 1)[0]).abs().max()) > 0   # the updates did something
+
+
+def test_fixed_shape_form_equals_reference_shaped_form(cuda):
+    ps, ms, vs, _ = _run(cuda, torch.float32, "static", 2)
+    pe, me, ve, _ = _run(cuda, torch.float32, "eager", 2)
+    assert (ps - pe).abs().max().item() <= 5e-6, (ps - pe).abs().max().item()   # two updates of ~1e-3 each
+    assert (ms - me).abs().max().item() <= 1e-4 * me.abs().max().item()
