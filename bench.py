@@ -149,7 +149,11 @@ def main():
         sg.record()
         sg.record()
         sg.capture()
-        run = sg.replay
+        cap_stream = sg.stream
+
+        def run():
+            with torch.cuda.stream(cap_stream):
+                sg.replay()
     else:
         for i in range(a.warmup):
             step(i)

@@ -48,12 +48,18 @@ class StepGraph:
 
     def record(self):
         """Eager step that allocates the static buffers and counts the seed slots (also the last warm-up step)."""
-        if self.on_step is not None:
-            self.on_step()
-        if self.opt is not None:
-            self.opt.push_hyper()
-        self.slots.begin_step()
-        self._run("record")
+        # on the capture stream: per-stream state of the library (split-K slab workspaces) and of the allocator is created
+        # here, eagerly -- nothing may allocate device memory once capture has begun
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            if self.on_step is not None:
+                self.on_step()
+            if self.opt is not None:
+                self.opt.push_hyper()
+            self.slots.begin_step()
+            self._run("record")
+        cur.wait_stream(self.stream)
         if not self.slots.used:
             self.slots.used = self.slots.k
             Fn._S.counter -= self.slots.n - self.slots.used   # begin_step() reserved all slots: give the unused ones back
@@ -62,7 +68,9 @@ class StepGraph:
 
     def capture(self):
         torch.cuda.synchronize(self.device)
-        self._pre_replay()
+        with torch.cuda.stream(self.stream):
+            self._pre_replay()
+        torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
         t0 = self.opt.t if self.opt is not None else 0
         with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):

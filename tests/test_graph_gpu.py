@@ -84,16 +84,23 @@ def _run(cuda, dtype, mode, nsteps=3):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_graph_replay_equals_eager_fixed_shape_bitwise(cuda, dtype):
+def test_graph_replay_equals_eager_fixed_shape(cuda, dtype):
+    """4 updates replayed vs enqueued eagerly.  Not bitwise: a few reductions use fp32 atomics (bias-gradient column of the
+    weight-gradient GEMM, embedding scatter), so two EAGER runs differ from each other by the same ~1e-6 (printed)."""
     pg, mg, vg, tg = _run(cuda, dtype, "graph", 4)
     ps, ms, vs, ts = _run(cuda, dtype, "static", 4)
+    ps2 = _run(cuda, dtype, "static", 4)[0]
+    p1 = _run(cuda, dtype, "static", 1)[0]
     assert tg == ts == 4
     assert torch.isfinite(pg).all()
+    upd = float((ps - p1).abs().max())
+    noise = float((ps - ps2).abs().max())
+    print(f"{dtype}: 3 further updates moved parameters by up to {upd:.3e}; eager vs eager {noise:.3e}; graph vs eager {float((pg - ps).abs().max()):.3e}")
+    assert upd > 1e-3                                   # the updates did something
+    tol = max(10 * noise, 2e-6) if dtype == torch.float32 else max(10 * noise, 2e-4)
     for a, b, name in ((pg, ps, "parameters"), (mg, ms, "first moment"), (vg, vs, "second moment")):
-        if not torch.equal(a, b):
-            d = (a - b).abs()
-            raise AssertionError(f"{name}: {int((d > 0).sum())} of {d.numel()} differ, max {float(d.max()):.3e}")
-    assert float((pg - _run(cuda, dtype, "static", 1)[0]).abs().max()) > 0   # the updates did something
+        d = float((a - b).abs().max())
+        assert d <= tol * max(1.0, float(b.abs().max())), f"{name}: max difference {d:.3e} (tolerance {tol:.1e})"
 
 
 def test_fixed_shape_form_equals_reference_shaped_form(cuda):
