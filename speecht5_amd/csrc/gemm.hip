@@ -592,16 +592,25 @@ float* arena_take(size_t bytes) {
 
 // split-K slab workspace, one per stream (the weight-gradient stream runs split-K GEMMs beside the main stream's)
 struct SlabWs { hipStream_t stream; float* ptr; size_t bytes; };
-SlabWs g_slabs[4] = {};
-int g_nslabs = 0;
+constexpr int SLAB_STREAMS = 8;
+SlabWs g_slabs[SLAB_STREAMS] = {};
+int g_nslabs = 0, g_slab_victim = 0;
 float* slab_workspace(size_t bytes, hipStream_t stream) {
   SlabWs* w = nullptr;
   for (int i = 0; i < g_nslabs; ++i)
     if (g_slabs[i].stream == stream) w = &g_slabs[i];
   if (!w) {
-    if (g_nslabs == 4) return nullptr;
-    w = &g_slabs[g_nslabs++];
-    w->stream = stream; w->ptr = nullptr; w->bytes = 0;
+    if (g_nslabs < SLAB_STREAMS) {
+      w = &g_slabs[g_nslabs++];
+      w->ptr = nullptr; w->bytes = 0;
+    } else {
+      // table full (streams come and go over a process's life): hand the oldest entry's allocation to the new stream.  The
+      // previous owner's work may still be in flight, so drain the device once; this happens on stream churn only.
+      w = &g_slabs[g_slab_victim];
+      g_slab_victim = (g_slab_victim + 1) % SLAB_STREAMS;
+      if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    }
+    w->stream = stream;
   }
   if (bytes > w->bytes) {
     if (w->ptr) (void)hipFree(w->ptr);  // synchronises with in-flight users
@@ -1079,7 +1088,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   const T* const zero = reinterpret_cast<const T*>(g_zero_page) + (lane & 15) * 8;
   const T* abase = Ap + m0 + lchunk * 8;
   const T* bbase = Bp + n0 + lchunk * 8;
-  auto issue = [&](int kt, int buf) {
+  // Source pointers advance by a per-lane constant stride (64 k-rows; 0 for the lanes that read the zero page because their
+  // 16-byte column chunk lies past M / N), so a k-step issues its 8 LDS-DMA loads with two adds each.  (The first version
+  // recomputed base + k * ld per load: 64-bit multiplies and two exec-masked branches per load, ~150 VALU instructions in
+  // front of every k-step's MFMAs -- the kernel ran at 0.25 PFLOP/s where the same tiling does 0.5 in the NT form.)  Only a
+  // final partial k-tile (K % 64 != 0) takes the per-row bounds-checked path.
+  const T* ap[4];
+  const T* bp[4];
+  const long long astep = a_col_ok ? (long long)BK * p.A.ld : 0, bstep = b_col_ok ? (long long)BK * p.B.ld : 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long k = (long long)kt0 * BK + (i * 4 + wave) * 4 + lrow;
+    ap[i] = a_col_ok ? abase + k * p.A.ld : zero;
+    bp[i] = b_col_ok ? bbase + k * p.B.ld : zero;
+  }
+  auto issue_fast = [&](int buf) {
+    char* base = dsm + buf * 2 * TILE_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)ap[i], (lds_ptr_t)(base + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)bp[i], (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, 0);
+      ap[i] += astep; bp[i] += bstep;
+    }
+  };
+  auto issue_tail = [&](int kt, int buf) {   // k-tile that crosses K: rows past K read the zero page
     char* base = dsm + buf * 2 * TILE_BYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1090,6 +1122,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)sa, (lds_ptr_t)(base + i * 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)sb, (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, 0);
     }
+  };
+  auto issue = [&](int kt, int buf) {
+    if ((kt + 1) * BK <= p.K) issue_fast(buf); else issue_tail(kt, buf);
   };
 
   f32x16 acc00, acc01, acc10, acc11;
