@@ -305,6 +305,16 @@ int st5_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 int st5_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale, void* bf16_mirror,
                       const float* hyper_dev, void* stream);
+/* ---- CTC prefix scoring for joint CTC / attention beam search (sequence_generator.py:273-418 calls espnet's
+ * CTCPrefixScore per hypothesis on the host; in-tree copy Speech2C/speech2c/models/modules/ctc_prefix_score.py:10-112) ----
+ * x: fp32 CTC log-posteriors [T, V] of ONE utterance (device).  A state is r[T][2] fp32 = log r_t^n, log r_t^b of a prefix.
+ * st5_ctc_initial_state: the state of the empty prefix (:27-39).
+ * st5_ctc_prefix_score: for nh hypotheses with states r_prev[nh][T][2], last label last[nh] and out_len labels after <sos>,
+ * and nc candidate next labels per hypothesis cs[nh][nc] (int64): log_psi[nh][nc] = log prefix probability of each extension
+ * (eos: probability that the prefix ends; blank: logzero = -1e10), r_new[nh][nc][T][2] = the extensions' states. */
+int st5_ctc_initial_state(const float* x, int32_t T, int32_t V, int32_t blank, float* r, void* stream);
+int st5_ctc_prefix_score(const float* x, int32_t T, int32_t V, int32_t blank, int32_t eos, const float* r_prev, const int64_t* last,
+                         int32_t out_len, const int64_t* cs, int32_t nh, int32_t nc, float* log_psi, float* r_new, void* stream);
 /* Dropout seeds: every `seed` argument of this library may instead be a device pointer to the 64-bit seed, tagged with bit 63
  * (seed = (1 << 63) | pointer): the kernels then read the seed from memory (csrc/common.h resolve_seed).  Used by captured HIP
  * graphs, whose kernel arguments cannot change between replays. */

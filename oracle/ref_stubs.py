@@ -528,3 +528,90 @@ def load_reference_models():
             sys.modules[name] = m
     import importlib
     return importlib.import_module("speecht5.models.speecht5")
+
+
+# ---- generation-side stubs: fairseq.search.BeamSearch / fairseq.ngram_repeat_block.NGramRepeatBlock are not in the snapshot.
+# Restated from fairseq's published algorithm (fairseq/search.py BeamSearch.step; fairseq/ngram_repeat_block.py, Python path):
+# only what SpeechT5/speecht5/sequence_generator.py:122-125,476-488 calls.
+class BeamSearch(nn.Module):
+    def __init__(self, tgt_dict):
+        super().__init__()
+        self.pad, self.unk, self.eos = tgt_dict.pad(), tgt_dict.unk(), tgt_dict.eos()
+        self.vocab_size = len(tgt_dict)
+        self.src_lengths = torch.tensor(-1)
+        self.supports_constraints = False
+        self.stop_on_max_len = False
+
+    def init_constraints(self, batch_constraints, beam_size):
+        pass
+
+    def prune_sentences(self, batch_idxs):
+        pass
+
+    def update_constraints(self, active_hypos):
+        pass
+
+    def step(self, step, lprobs, scores, prev_output_tokens=None, original_batch_idxs=None):
+        bsz, beam_size, vocab_size = lprobs.size()
+        if step == 0:
+            # at the first step all hypotheses are equally likely, so use only the first beam
+            lprobs = lprobs[:, ::beam_size, :].contiguous()
+        else:
+            assert scores is not None
+            lprobs = lprobs + scores[:, :, step - 1].unsqueeze(-1)
+        top_prediction = torch.topk(
+            lprobs.view(bsz, -1),
+            k=min(beam_size * 2, lprobs.view(bsz, -1).size(1) - 1),  # -1 so we never select pad
+        )
+        scores_buf = top_prediction[0]
+        indices_buf = top_prediction[1]
+        beams_buf = torch.div(indices_buf, vocab_size, rounding_mode="trunc")
+        indices_buf = indices_buf.fmod(vocab_size)
+        return scores_buf, indices_buf, beams_buf
+
+
+class NGramRepeatBlock(nn.Module):
+    def __init__(self, no_repeat_ngram_size, use_extension=True):
+        super().__init__()
+        self.no_repeat_ngram_size = no_repeat_ngram_size
+
+    def forward(self, tokens, lprobs, bsz, beam_size, step):
+        n = self.no_repeat_ngram_size
+        banned_tokens = [[] for _ in range(bsz * beam_size)]
+        if step + 2 - n >= 0:
+            cpu_tokens = tokens.cpu()
+            gen_ngrams = [{} for _ in range(bsz * beam_size)]
+            for bbsz_idx in range(bsz * beam_size):
+                gen_tokens = cpu_tokens[bbsz_idx].tolist()
+                for ngram in zip(*[gen_tokens[i:] for i in range(n)]):
+                    key = ",".join(str(x) for x in ngram[:-1])
+                    gen_ngrams[bbsz_idx][key] = gen_ngrams[bbsz_idx].get(key, []) + [ngram[-1]]
+            for bbsz_idx in range(bsz * beam_size):
+                key = ",".join(str(x) for x in cpu_tokens[bbsz_idx, step + 2 - n: step + 1].tolist())
+                banned_tokens[bbsz_idx] = gen_ngrams[bbsz_idx].get(key, [])
+        for bbsz_idx in range(bsz * beam_size):
+            lprobs[bbsz_idx][torch.tensor(banned_tokens[bbsz_idx], dtype=torch.int64)] = torch.tensor(-math.inf).to(lprobs)
+        return lprobs
+
+
+def load_reference_generator():
+    """Import the verbatim SpeechT5/speecht5/sequence_generator.py: fairseq.search / ngram_repeat_block from the restatements above,
+    espnet's CTCPrefixScore from the snapshot's own copy (Speech2C/speech2c/models/modules/ctc_prefix_score.py)."""
+    import importlib
+    import importlib.util
+    load_reference_models()
+    fs = sys.modules["fairseq"]
+    search = types.ModuleType("fairseq.search")
+    search.BeamSearch = BeamSearch
+    sys.modules["fairseq.search"] = search
+    fs.search = search
+    ng = types.ModuleType("fairseq.ngram_repeat_block")
+    ng.NGramRepeatBlock = NGramRepeatBlock
+    sys.modules["fairseq.ngram_repeat_block"] = ng
+    sys.modules["fairseq.data"].data_utils = sys.modules["fairseq.data.data_utils"]
+    spec = importlib.util.spec_from_file_location(
+        "espnet.nets.ctc_prefix_score", f"{REFERENCE_ROOT}/Speech2C/speech2c/models/modules/ctc_prefix_score.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sys.modules["espnet.nets.ctc_prefix_score"] = mod
+    return importlib.import_module("speecht5.sequence_generator")

@@ -112,6 +112,9 @@ _SIGS = {
                               c_int32, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "st5_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                   c_int32, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "st5_ctc_initial_state": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "st5_ctc_prefix_score": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32,
+                                     c_void_p, c_void_p, c_void_p]),
     "st5_multi_transpose_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "st5_batchnorm_ws_bytes": (c_int64, [c_int32]),
     "st5_batchnorm_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int32, c_int32,

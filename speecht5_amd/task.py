@@ -47,7 +47,11 @@ class _Dictionary(list):
         return 3
 
     def index(self, sym):
-        return list.index(self, sym)
+        """fairseq Dictionary.index: the symbol's id, <unk> for a symbol the table does not hold."""
+        try:
+            return list.index(self, sym)
+        except ValueError:
+            return self.unk()
 
 
 @register_task("speecht5")

@@ -26,7 +26,10 @@ class Dictionary(list):
         return 3
 
     def index(self, sym):
-        return list.index(self, sym)
+        try:
+            return list.index(self, sym)
+        except ValueError:   # fairseq Dictionary.index: unknown symbol -> <unk>
+            return self.unk()
 
 
 class Task:
