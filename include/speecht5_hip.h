@@ -234,6 +234,10 @@ int st5_embed_rows(const float* table, const int32_t* tok, const float* pos, con
 /* dtable[tok[r],:] += scale * dy[r,:]  (fp32 atomics) */
 int st5_embed_rows_bwd(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, float scale,
                        int dtype, void* stream);
+/* The same, bit-reproducible: one block per (table row, 256-column chunk) adds that row's tokens in token order (no atomics).
+ * Tokens outside [0, vocab) contribute nothing.  Cost grows with vocab * rows id reads (L2-resident). */
+int st5_embed_rows_bwd_det(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, int32_t vocab, float scale,
+                           int dtype, void* stream);
 /* zero-padded copy: dst [B, pad_l + T + pad_r, C] <- src [B, T, C] */
 /* out[(b,t), j] = wav[b, t*stride + j] (j < k), 0 (k <= j < kpad); out is [B*L, kpad] (dtype), L = (S-k)/stride + 1.
  * Turns the Cin = 1 first convolution of the extractor_mode=layer_norm feature extractor

@@ -199,6 +199,26 @@ __global__ void embed_rows_bwd_kernel(const T* __restrict__ dy, const int32_t* _
   for (int c = threadIdx.x & 63; c < cols; c += 64)
     atomicAdd(&trow[c], scale * Elem<T>::to_f(dy[row * cols + c]));
 }
+// Deterministic form: block (v, column chunk) walks every token in order and adds the rows whose id is v -- one writer per
+// table element, fixed summation order, so a training step is bit-reproducible (the atomic form above is not: fp32 atomics
+// commit in arrival order).  Every wave reads the same 64 ids and ballots the matches; ids stay L2-resident.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_rows_bwd_det_kernel(const T* __restrict__ dy, const int32_t* __restrict__ tok,
+                                                                 float* __restrict__ dtable, long long rows, int cols, float scale) {
+  const int v = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const bool live = c < cols;
+  float acc = 0.f;
+  for (long long t0 = 0; t0 < rows; t0 += 64) {
+    const long long t = t0 + lane;
+    unsigned long long m = __ballot(t < rows && tok[t] == v);
+    while (m) {
+      const int j = __builtin_ctzll(m);
+      m &= m - 1;
+      if (live) acc += Elem<T>::to_f(dy[(t0 + j) * cols + c]);
+    }
+  }
+  if (live && acc != 0.f) dtable[(long long)v * cols + c] += scale * acc;
+}
 template <typename T>
 __global__ void pad_time_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int Tn, int C, int pad_l,
                                 int pad_r) {
@@ -493,6 +513,17 @@ extern "C" int st5_embed_rows_bwd(const void* dy, const int32_t* tok, float* dta
   dim3 grid((unsigned)((rows + 3) / 4));
   DISPATCH(dtype, hipLaunchKernelGGL(embed_rows_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, tok, dtable, (long long)rows, cols, scale),
            hipLaunchKernelGGL(embed_rows_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, tok, dtable, (long long)rows, cols, scale));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_embed_rows_bwd_det(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, int32_t vocab,
+                                      float scale, int dtype, void* stream) {
+  if (!dy || !tok || !dtable || rows < 0 || cols <= 0 || vocab <= 0) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)vocab, (unsigned)((cols + 255) / 256));
+  DISPATCH(dtype, hipLaunchKernelGGL(embed_rows_bwd_det_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, tok, dtable, (long long)rows, cols, scale),
+           hipLaunchKernelGGL(embed_rows_bwd_det_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, tok, dtable, (long long)rows, cols, scale));
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

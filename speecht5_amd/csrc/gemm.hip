@@ -317,7 +317,7 @@ __device__ __forceinline__ void epilogue_rows(const EpiArgs& ea, const float* st
 }
 
 
-// Fast epilogue of a wave's 64x64 tile for the common layout (every C-class operand dense-row: rpb == 0, 16-byte
+// Fast epilogue of a wave's 64x64 tile for the common layout (every C-class operand 16-byte
 // aligned, N % 8 == 0 so a lane's 8 columns are all valid or all out of range).  Both 32-row halves are staged through the
 // wave-private LDS slab; the per-lane constants (bias, column offsets) are loaded once, the uniform feature tests are
 // per 8-vector, and the four row passes of a half are unrolled so their LDS reads / global loads overlap.
@@ -365,14 +365,19 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
       for (int k = 0; k < 2; ++k) {
         const int gm = mbase + h * 32 + (pp * 2 + k) * 8 + rsub;
         if (gm < ea.M && col_ok) {
+          // row -> (block q, row rm inside the block) when the C-class operands are split every `rpb` rows
+          // (convolution layouts: per-utterance halo rows); every operand has its own row / block stride
+          long long q = 0, rm = gm;
+          if (ea.rpb) { q = gm / ea.rpb; rm = gm - q * ea.rpb; }
+          const long long c_off = q * ea.c_bs + rm * ea.c_ld;
           float rv[8], pv[8], ov[8];
-          if (Rb) load8f<OUT>(Rb + (long long)gm * ea.r_ld, rv);
-          if (ea.dact) load8f<T>(Pb + (long long)gm * ea.p_ld, pv);
-          if (ea.beta != 0.f) load8f<OUT>(Cb + (long long)gm * ea.c_ld, ov);
+          if (Rb) load8f<OUT>(Rb + q * ea.r_bs + rm * ea.r_ld, rv);
+          if (ea.dact) load8f<T>(Pb + q * ea.p_bs + rm * ea.p_ld, pv);
+          if (ea.beta != 0.f) load8f<OUT>(Cb + c_off, ov);
           float x[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = fmaf(v[k][e], ea.alpha, bias8[e]);
-          if (Qb) store8f<T>(Qb + (long long)gm * ea.q_ld, x);
+          if (Qb) store8f<T>(Qb + q * ea.q_bs + rm * ea.q_ld, x);
           if (ea.dact) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] *= act_grad_f<FASTACT>(ea.act, pv[e]);
@@ -394,7 +399,7 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = fmaf(ea.beta, ov[e], x[e]);
           }
-          store8f<OUT>(Cb + (long long)gm * ea.c_ld, x);
+          store8f<OUT>(Cb + c_off, x);
         }
       }
     }
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const st5_gemm_params
   ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
   ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
   ea.atomic = 0;
-  ea.fast = c_vec_ok && (p.N % 8 == 0) && !p.C.rpb;
+  ea.fast = c_vec_ok && (p.N % 8 == 0);
   if (gridDim.y > 1) {  // split-K: each split writes its own fp32 slab (p.C describes slab 0, slabs are M*N apart)
     ea.C = reinterpret_cast<float*>(ea.C) + (long long)blockIdx.y * p.M * p.N;
   }
@@ -765,7 +770,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
   ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
   ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
   ea.atomic = 0;
-  ea.fast = c_vec_ok && (p.N % 8 == 0) && !p.C.rpb;
+  ea.fast = c_vec_ok && (p.N % 8 == 0);
   ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
   ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
   {
@@ -962,7 +967,7 @@ __global__ __launch_bounds__(NT2) void gemm_nt256_kernel(const st5_gemm_params p
   ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
   ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
   ea.atomic = 0;
-  ea.fast = c_vec_ok && (p.N % 8 == 0) && !p.C.rpb;
+  ea.fast = c_vec_ok && (p.N % 8 == 0);
   ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
   ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
   {
@@ -1093,14 +1098,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   // recomputed base + k * ld per load: 64-bit multiplies and two exec-masked branches per load, ~150 VALU instructions in
   // front of every k-step's MFMAs -- the kernel ran at 0.25 PFLOP/s where the same tiling does 0.5 in the NT form.)  Only a
   // final partial k-tile (K % 64 != 0) takes the per-row bounds-checked path.
+  // Row split (rpb > 0: k-row r lives at (r / rpb) * bstride + (r % rpb) * ld -- the convolution weight gradients read the
+  // haloed per-utterance activation layouts): each source keeps its row-in-block counter; stepping 64 rows wraps at most
+  // once (the host requires rpb >= 64) and adds the block jump.  rpb == 0 behaves as one endless block.
   const T* ap[4];
   const T* bp[4];
+  int ta[4], tb[4];
+  const int rpa = p.A.rpb ? p.A.rpb : 0x7fffffff, rpbb = p.B.rpb ? p.B.rpb : 0x7fffffff;
   const long long astep = a_col_ok ? (long long)BK * p.A.ld : 0, bstep = b_col_ok ? (long long)BK * p.B.ld : 0;
+  const long long awrap = (a_col_ok && p.A.rpb) ? p.A.bstride - (long long)p.A.rpb * p.A.ld : 0;
+  const long long bwrap = (b_col_ok && p.B.rpb) ? p.B.bstride - (long long)p.B.rpb * p.B.ld : 0;
+  auto row_off = [](long long k, int rpb, long long ld, long long bs) {
+    if (!rpb) return k * ld;
+    const long long q = k / rpb;
+    return q * bs + (k - q * rpb) * ld;
+  };
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long long k = (long long)kt0 * BK + (i * 4 + wave) * 4 + lrow;
-    ap[i] = a_col_ok ? abase + k * p.A.ld : zero;
-    bp[i] = b_col_ok ? bbase + k * p.B.ld : zero;
+    ap[i] = a_col_ok ? abase + row_off(k, p.A.rpb, p.A.ld, p.A.bstride) : zero;
+    bp[i] = b_col_ok ? bbase + row_off(k, p.B.rpb, p.B.ld, p.B.bstride) : zero;
+    ta[i] = p.A.rpb ? (int)(k % p.A.rpb) : 0;
+    tb[i] = p.B.rpb ? (int)(k % p.B.rpb) : 0;
   }
   auto issue_fast = [&](int buf) {
     char* base = dsm + buf * 2 * TILE_BYTES + wave * 1024;
@@ -1108,7 +1127,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
     for (int i = 0; i < 4; ++i) {
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)ap[i], (lds_ptr_t)(base + i * 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)bp[i], (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, 0);
-      ap[i] += astep; bp[i] += bstep;
+      ta[i] += BK; tb[i] += BK;
+      const bool wa = ta[i] >= rpa, wb = tb[i] >= rpbb;
+      ta[i] -= wa ? rpa : 0; tb[i] -= wb ? rpbb : 0;
+      ap[i] += astep + (wa ? awrap : 0); bp[i] += bstep + (wb ? bwrap : 0);
     }
   };
   auto issue_tail = [&](int kt, int buf) {   // k-tile that crosses K: rows past K read the zero page
@@ -1117,8 +1139,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
     for (int i = 0; i < 4; ++i) {
       const int k = kt * BK + (i * 4 + wave) * 4 + lrow;
       const bool kin = k < p.K;
-      const T* sa = (kin && a_col_ok) ? abase + (long long)k * p.A.ld : zero;
-      const T* sb = (kin && b_col_ok) ? bbase + (long long)k * p.B.ld : zero;
+      const T* sa = (kin && a_col_ok) ? abase + row_off(k, p.A.rpb, p.A.ld, p.A.bstride) : zero;
+      const T* sb = (kin && b_col_ok) ? bbase + row_off(k, p.B.rpb, p.B.ld, p.B.bstride) : zero;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)sa, (lds_ptr_t)(base + i * 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)sb, (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, 0);
     }
@@ -1175,7 +1197,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
   ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
   ea.atomic = 0;
-  ea.fast = c_vec_ok && (p.N % 8 == 0) && !p.C.rpb;
+  ea.fast = c_vec_ok && (p.N % 8 == 0);
   if (gridDim.y > 1) ea.C = reinterpret_cast<float*>(ea.C) + (long long)blockIdx.y * p.M * p.N;
   ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
   ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
@@ -1201,12 +1223,13 @@ int launch_tn_glds(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream
   return ST5_OK;
 }
 
-// operands the TN LDS-DMA kernel can take: bf16, both k-strided and dense (no row split / k segments), 16-byte
+// operands the TN LDS-DMA kernel can take: bf16, both k-strided (row split allowed, no k segments), 16-byte
 // chunks along the contiguous index fully inside or outside the matrix
 bool tn_glds_ok(const st5_gemm_params& p, int dtype) {
   if (dtype != ST5_BF16) return false;
   if (!(p.flags & ST5_GEMM_A_KSTRIDED) || !(p.flags & ST5_GEMM_B_KSTRIDED)) return false;
-  if (p.A.rpb || p.B.rpb || p.A.seg || p.B.seg) return false;
+  if (p.A.seg || p.B.seg) return false;
+  if ((p.A.rpb && (p.A.rpb < 64 || p.A.bstride % 8)) || (p.B.rpb && (p.B.rpb < 64 || p.B.bstride % 8))) return false;
   if (p.M % 8 || p.N % 8 || p.A.ld % 8 || p.B.ld % 8 || p.A.zs0 % 8 || p.A.zs1 % 8 || p.B.zs0 % 8 || p.B.zs1 % 8) return false;
   return aligned(p.A.ptr, 16) && aligned(p.B.ptr, 16);
 }

@@ -7,20 +7,18 @@
 #include "../../include/speecht5_hip.h"
 
 namespace {
-// hyper: optional device array {lr, step} that overrides the by-value lr / bias corrections (a captured HIP graph replays
+// hyper: optional device array {lr, step} that overrides the by-value lr / step count (a captured HIP graph replays
 // constant kernel arguments; the host refreshes these two floats before every replay)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ mirror, long long n,
-                                                   float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                   float bc2, const float* __restrict__ gnorm_sq, float max_norm,
+                                                   float lr, float b1, float b2, float eps, float wd, float t,
+                                                   const float* __restrict__ gnorm_sq, float max_norm,
                                                    float gscale, const float* __restrict__ hyper) {
-  if (hyper) {
-    lr = hyper[0];
-    const float t = hyper[1];
-    bc1 = 1.f - powf(b1, t);
-    bc2 = 1.f - powf(b2, t);
-  }
+  if (hyper) { lr = hyper[0]; t = hyper[1]; }
+  // bias corrections from the step count ON THE DEVICE in both forms: the by-value (eager) and the device-hyper (graph replay)
+  // updates are then the same arithmetic, bit for bit (host pow() and device powf() differ in the last place for some t)
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   float coef = gscale;
   if (gnorm_sq && max_norm > 0.f) {
     const float norm = sqrtf(gnorm_sq[0]) * gscale;
@@ -108,13 +106,12 @@ extern "C" int st5_adam_step_dev(float* p, const float* g, float* m, float* v, i
                                  void* bf16_mirror, const float* hyper_dev, void* stream) {
   if (!p || !g || !m || !v || n < 0 || (step < 1 && !hyper_dev)) return ST5_ERR_ARG;
   if (n == 0) return ST5_OK;
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)bf16_mirror,
                      (long long)n,
-                     lr, beta1, beta2, eps, weight_decay, bc1, bc2, gnorm_sq, max_norm, grad_scale, hyper_dev);
+                     lr, beta1, beta2, eps, weight_decay, (float)step, gnorm_sq, max_norm, grad_scale, hyper_dev);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

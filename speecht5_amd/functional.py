@@ -1035,7 +1035,8 @@ def set_attention_stream(stream):
     _S.attn_side_raw = stream.cuda_stream if stream is not None else None
 
 
-def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe, maxrel, kpm, causal, p_drop, seed, qp=None):
+def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe, maxrel, kpm, causal, p_drop, seed, qp=None,
+               pe_t=None):
     """Writes dq/dk/dv slices; returns dPE (fp32) or None."""
     dev = dctx.device
     dtype = torch.bfloat16
@@ -1061,10 +1062,14 @@ def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe
     if pe is None:
         return None
     dqt, dqld, dqoff = dq
-    # dQ += alpha * dQP . PE
-    hip.gemm(hip.operand(dqp, nb, zs0=H * T * nb, zs1=T * nb), hip.operand(pe, hd),
-             hip.operand(dqt, dqld, off=dqoff, zs0=T * dqld, zs1=hd), T, hd, nb, hip.BF16, batch=BH, zdiv=H,
-             flags=hip.B_KSTRIDED, alpha=alpha, beta=1.0)
+    # dQ += alpha * dQP . PE  (NT form on the LDS-DMA kernel when the caller made the K-major copy PE^T [hd, nb])
+    if pe_t is not None:
+        hip.gemm(hip.operand(dqp, nb, zs0=H * T * nb, zs1=T * nb), hip.operand(pe_t, nb),
+                 hip.operand(dqt, dqld, off=dqoff, zs0=T * dqld, zs1=hd), T, hd, nb, hip.BF16, batch=BH, zdiv=H, alpha=alpha, beta=1.0)
+    else:
+        hip.gemm(hip.operand(dqp, nb, zs0=H * T * nb, zs1=T * nb), hip.operand(pe, hd),
+                 hip.operand(dqt, dqld, off=dqoff, zs0=T * dqld, zs1=hd), T, hd, nb, hip.BF16, batch=BH, zdiv=H,
+                 flags=hip.B_KSTRIDED, alpha=alpha, beta=1.0)
     if not want_dpe:
         return None
     part = torch.empty(BH, nb, hd, dtype=torch.float32, device=dev)
@@ -1085,7 +1090,7 @@ class SelfAttentionFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx_, qkv, pe, kpm, cfg):
-        B, H, T, hd, maxrel, causal, p_drop = cfg
+        B, H, T, hd, maxrel, causal, p_drop = cfg[:7]
         d = H * hd
         seed = next_seed() if p_drop > 0 else 0
         if _can_flash(qkv.dtype, hd, False):
@@ -1102,14 +1107,16 @@ class SelfAttentionFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx_, dctx):
-        (B, H, T, hd, maxrel, causal, p_drop), seed, flash = ctx_.meta
+        cfg, seed, flash = ctx_.meta
+        B, H, T, hd, maxrel, causal, p_drop = cfg[:7]
+        pe_t = cfg[7] if len(cfg) > 7 else None
         d = H * hd
         if flash:
             qkv, ctx, lse, pe, kpm, qp = ctx_.saved_tensors
             dqkv = torch.empty_like(qkv)
             dpe = _flash_bwd(dctx.contiguous(), ctx, lse, (qkv, 3 * d, 0), (qkv, 3 * d, d), (qkv, 3 * d, 2 * d), (dqkv, 3 * d, 0),
                              (dqkv, 3 * d, d), (dqkv, 3 * d, 2 * d), B, H, T, T, hd, pe, pe is not None and ctx_.needs_input_grad[1],
-                             maxrel, kpm, causal, p_drop, seed, qp=qp)
+                             maxrel, kpm, causal, p_drop, seed, qp=qp, pe_t=pe_t)
             if dpe is not None and pe.dtype != torch.float32:
                 dpe = to_compute(dpe)
             return dqkv, dpe, None, None
@@ -1348,8 +1355,9 @@ class EmbedRowsFunction(torch.autograd.Function):
         if table.requires_grad:
             dy = dy.contiguous()
             g = grad_buffer(table)
-            hip.check(hip.lib().st5_embed_rows_bwd(dy.data_ptr(), tok.data_ptr(), g.data_ptr(), tok.numel(), table.shape[1],
-                                                   emb_scale, _dt(dy), hip.stream()), "st5_embed_rows_bwd")
+            # (the deterministic form: the atomic one made two runs of the same step differ in the last bits of this gradient)
+            hip.check(hip.lib().st5_embed_rows_bwd_det(dy.data_ptr(), tok.data_ptr(), g.data_ptr(), tok.numel(), table.shape[1],
+                                                       table.shape[0], emb_scale, _dt(dy), hip.stream()), "st5_embed_rows_bwd_det")
             _grad_done(table)
         return None, None, None, None, None, None, None
 

@@ -99,6 +99,7 @@ _SIGS = {
     "st5_embed_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
                                c_int, c_void_p]),
     "st5_embed_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_int, c_void_p]),
+    "st5_embed_rows_bwd_det": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_int, c_void_p]),
     "st5_unfold_rows": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "st5_pad_time": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "st5_stft_frames": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -18,6 +18,14 @@ class RelPosKeys:
     def __init__(self, table, maxlen):
         self.table = table      # [2*maxlen, head_dim] in the compute dtype (differentiable)
         self.maxlen = maxlen
+        self._t = None
+
+    def transposed(self):
+        """[head_dim, 2*maxlen] constant copy, made once per forward and shared by every layer that uses this table: the
+        attention backward's dQ += dQP . PE then runs as an NT-form GEMM on the LDS-DMA kernel (K-major B operand)."""
+        if self._t is None:
+            self._t = self.table.detach().t().contiguous()
+        return self._t
 
 
 def _is_causal_mask(attn_mask):
@@ -73,10 +81,12 @@ class MultiheadAttention(nn.Module, IncrementalState):
         if kv is None:
             qkv = Fn.linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight],
                             [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], relay_in=relay)
-            pe, maxrel = None, 0
+            pe, maxrel, pe_t = None, 0, None
             if position_bias is not None and self.has_relative_attention_bias:
                 pe, maxrel = position_bias.table, position_bias.maxlen
-            ctx = Fn.SelfAttentionFunction.apply(qkv, pe, kpm, (B, H, T, hd, maxrel, causal, p))
+                if torch.is_grad_enabled() and qkv.requires_grad:
+                    pe_t = position_bias.transposed()
+            ctx = Fn.SelfAttentionFunction.apply(qkv, pe, kpm, (B, H, T, hd, maxrel, causal, p, pe_t))
         else:
             q = Fn.linear(x, self.q_proj.weight, self.q_proj.bias, relay_in=relay)
             kvp = Fn.linear(kv, [self.k_proj.weight, self.v_proj.weight], [self.k_proj.bias, self.v_proj.bias])

@@ -605,3 +605,43 @@ def test_layernorm_deferred_parameter_gradients(cuda):
     for u, v in zip(a[0] + a[1], b[0] + b[1]):
         assert torch.equal(u, v)
     assert a[0][0].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("k,stride,L", [(3, 2, 401), (2, 2, 300)])
+def test_conv_weight_gradient_and_data_gradient_with_row_split_operands(cuda, k, stride, L):
+    """The haloed per-utterance layouts of the convolution backward (operands split every `rpb` rows):
+    weight gradient = TN-form GEMM on the LDS-DMA kernel with row-split k-strided operands and split-K; data gradient with the
+    act' epilogue writing a row-split output (vectorised epilogue path).  Against fp32 autograd of the same convolution."""
+    torch.manual_seed(5)
+    dtype = torch.bfloat16
+    B, Cin, Cout = 3, 64, 128
+    Lo = (L - k) // stride + 1
+    x = torch.randn(B, L, Cin)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    dy = torch.randn(B, Lo, Cout)
+    xr, wr, dyr = rt(x, dtype).requires_grad_(True), rt(w, dtype).requires_grad_(True), rt(dy, dtype)
+    y = F.conv1d(xr.transpose(1, 2), wr, stride=stride).transpose(1, 2)
+    y.backward(dyr)
+    # ---- weight gradient: dW[co, j*Cin + ci] = sum_{b,t} dY[b,t,co] * X[b, t*s + j, ci]; dY kept with one halo row per side
+    dpre = torch.zeros(B, Lo + 2, Cout, dtype=dtype, device=cuda)
+    dpre[:, 1:-1] = dy.to(dtype)
+    X = dev(x, dtype, cuda)
+    gw = torch.zeros(Cout, k * Cin, device=cuda)
+    hip.gemm(hip.operand(dpre, Cout, off=Cout, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(X, stride * Cin, rpb=Lo, bstride=L * Cin),
+             hip.operand(gw, k * Cin), Cout, k * Cin, B * Lo, hip.BF16, flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
+    ref_w = wr.grad.permute(0, 2, 1).reshape(Cout, k * Cin)
+    close(gw, ref_w, dtype, what="conv weight gradient (row-split TN)")
+    if k != 2:
+        return
+    # ---- data gradient (k = 2, stride 2: one NT GEMM) times gelu'(P), written into a haloed [B, L + 2, Cin] buffer
+    P = torch.randn(B, L, Cin)
+    Wd = dev(w.permute(2, 1, 0).reshape(k * Cin, Cout), dtype, cuda)            # [k*Cin, Cout]
+    nxt = torch.zeros(B, L + 2, Cin, dtype=dtype, device=cuda)
+    Pd = dev(P, dtype, cuda)
+    hip.gemm(hip.operand(dpre, Cout, off=Cout, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wd, Cout),
+             hip.operand(nxt, 2 * Cin, off=Cin, rpb=Lo, bstride=(L + 2) * Cin), B * Lo, 2 * Cin, Cout, hip.BF16,
+             P=hip.operand(Pd, 2 * Cin, rpb=Lo, bstride=L * Cin), act=hip.ACT_GELU, flags=hip.DACT)
+    Pr = rt(P, dtype).requires_grad_(True)
+    F.gelu(Pr).backward(xr.grad)                         # gelu'(P) * dX
+    close(nxt[:, 1:-1][:, :2 * Lo], Pr.grad[:, :2 * Lo], dtype, what="conv data gradient * gelu' (row-split epilogue)")
+    assert float(nxt[:, 0].abs().max()) == 0 and float(nxt[:, -1].abs().max()) == 0   # halo rows untouched
