@@ -50,9 +50,12 @@ def build(device, compute_dtype):
     return args, task, model, crit
 
 
-def cpu_baseline(model, args, seconds=10.0):
-    """The CPU oracle (oracle/speecht5_oracle.py: fp32 restatement of the reference path) on the host cores:
-    one 10 s clip, speech_pretrain forward + loss + backward, timed once after a short warm-up clip."""
+PMC_TRAFFIC_FILE = "r2_pmc_traffic.json"   # written by tools/pmc_traffic.sh
+
+
+def cpu_baseline(model, args, seconds=4.0, runs=5):
+    """The CPU oracle (oracle/speecht5_oracle.py: fp32 restatement of the reference path) on the host cores: one clip,
+    speech_pretrain forward + loss + backward; median of `runs` timed iterations after 2 warm-ups."""
     from oracle import speecht5_oracle as O
     from speecht5_amd.synthetic import speech_pretrain_sample
     from types import SimpleNamespace
@@ -64,6 +67,8 @@ def cpu_baseline(model, args, seconds=10.0):
         T = int(secs * 50) - 1
         mask = torch.zeros(1, T, dtype=torch.bool)
         mask[:, : int(0.6 * T)] = True
+        for v in sd.values():
+            v.grad = None
         t0 = time.perf_counter()
         out = O.forward_speech_pretrain(sd, cfg, s, mask_indices=mask, mix_idx=torch.arange(0, T, 2)[: T // 2], gumbel_noise=None)
         loss, ss, _ = O.speech_pretrain_loss(out, s, cfg, loss_weights=(10, 0.1))
@@ -71,16 +76,19 @@ def cpu_baseline(model, args, seconds=10.0):
         return time.perf_counter() - t0
 
     run(1.0)
-    t = run(seconds)
+    run(1.0)
+    ts = sorted(run(seconds) for _ in range(runs))
+    t = ts[len(ts) // 2]
     return {"value": round(seconds / t, 4), "unit": "audio-sec/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 x {seconds:g} s clip, speech_pretrain fwd+bwd (fp32 CPU oracle), {t:.1f} s wall"}
+            "sample": f"1 x {seconds:g} s clip, speech_pretrain fwd+bwd (fp32 CPU oracle): median of {runs} runs after 2 warm-ups, "
+                      f"{t:.2f} s per run (min {ts[0]:.2f}, max {ts[-1]:.2f})"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=8, help="speech clips (10 s) per GPU per step")
@@ -188,23 +196,30 @@ def main():
     peak = BF16_DENSE_PEAK_TFLOPS if a.dtype == "bf16" else 157.3
     # measured HBM bytes per launch of the same kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
     # (tools/pmc_traffic.sh), summary committed under profiles/ (the counters cannot be read from inside the process)
-    traffic = None
+    traffic, traffic_src = None, None
     try:
         import json as _json
-        pm = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")))
-        for kname, v in pm["kernels"].items():
-            if "gemm_nt_glds_kernel" in kname and a.dtype == "bf16":
-                traffic = v["hbm_corrected_bytes_per_launch"]
+        here = os.path.dirname(os.path.abspath(__file__))
+        pm = _json.load(open(os.path.join(here, "profiles", PMC_TRAFFIC_FILE)))
+        # only a summary measured on THIS kernel source counts (the file records the hash of csrc/gemm.hip it was taken on)
+        import hashlib
+        cur = hashlib.sha1(open(os.path.join(here, "speecht5_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:12]
+        if pm.get("gemm_hip_sha1") == cur and a.dtype == "bf16":
+            for kname, v in pm["kernels"].items():
+                if "gemm_nt_glds_kernel" in kname:
+                    traffic = v["hbm_corrected_bytes_per_launch"]
+                    traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes/launch; gemm.hip {cur})"
     except Exception:
         traffic = None
     alg_bytes = hip.profiler.nt_bytes_per_launch() if hasattr(hip.profiler, "nt_bytes_per_launch") else None
-    roof = {"bound": "mfma", "kernel": f"gemm_nt_glds_kernel<{a.dtype}> (Linear / conv / attention-projection forward + data-gradient form; "
-                      "the 7 conv feature-extractor launches of this form run on gemm_nt256_kernel)",
+    roof = {"bound": "mfma", "kernel": f"NT-form st5_gemm launches <{a.dtype}>: gemm_nt_glds_kernel (128x128 tiles: Linear / attention-projection "
+                      "forward and data-gradient GEMMs) + gemm_nt256_kernel (256x256 tiles: the long conv feature-extractor GEMMs); "
+                      "`traffic` is per launch of gemm_nt_glds_kernel",
             "note": "launch durations are measured inside the step, i.e. beside the weight-gradient stream's kernels "
                     "(ST5_WGRAD_STREAM=0 gives the isolated rate, ~8 % higher)",
             "achieved": round(flops / secs / 1e12, 2) if secs > 0 else None, "peak": peak, "unit": "TFLOP/s",
             "frac": round(flops / secs / 1e12 / peak, 4) if secs > 0 else None, "traffic": traffic,
-            "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)" if traffic else None,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes,
             "launches_per_step": n, "sampled_steps": 1, "avg_launch_us": round(secs / max(n, 1) * 1e6, 2),
             "all_variants": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None,

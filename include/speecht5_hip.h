@@ -234,10 +234,20 @@ int st5_embed_rows(const float* table, const int32_t* tok, const float* pos, con
 /* dtable[tok[r],:] += scale * dy[r,:]  (fp32 atomics) */
 int st5_embed_rows_bwd(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, float scale,
                        int dtype, void* stream);
-/* The same, bit-reproducible: one block per (table row, 256-column chunk) adds that row's tokens in token order (no atomics).
- * Tokens outside [0, vocab) contribute nothing.  Cost grows with vocab * rows id reads (L2-resident). */
+/* The same, bit-reproducible (no atomics): the rows are rank-sorted by (table row, position) and every table row is summed in
+ * position order by one block.  Tokens outside [0, vocab) contribute nothing.  The sort is quadratic in `rows` (one micro-batch
+ * of tokens / frames: ~10 us for 8k rows); rows <= 2^22.  Uses one internal workspace: calls must be stream-ordered. */
 int st5_embed_rows_bwd_det(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, int32_t vocab, float scale,
                            int dtype, void* stream);
+/* ... with a per-row weight: row r is scaled by row_w[(r / rw_div) % rw_mod] (NULL = 1). */
+int st5_embed_rows_bwd_det_w(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, int32_t vocab, float scale,
+                             const float* row_w, int32_t rw_div, int32_t rw_mod, int dtype, void* stream);
+/* dst[a, b, c] (+)= src[off + a*sa + b*sb + c*sc]  (src fp32, dst `dtype`, element strides, may be negative): one-pass weight
+ * re-layout + cast for the implicit-GEMM convolutions, and re-laid-out accumulation of their weight gradients. */
+int st5_gather3(const float* src, void* dst, int32_t A, int32_t B, int32_t C, int64_t sa, int64_t sb, int64_t sc, int64_t off,
+                int32_t accumulate, int dtype, void* stream);
+/* x[b, t, :] = 0 for t < head and for t >= tail_start (x [B, Tp, C]): halo rows + rows no output window covers, one launch. */
+int st5_zero_time_edges(void* x, int32_t B, int32_t Tp, int32_t C, int32_t head, int32_t tail_start, int dtype, void* stream);
 /* zero-padded copy: dst [B, pad_l + T + pad_r, C] <- src [B, T, C] */
 /* out[(b,t), j] = wav[b, t*stride + j] (j < k), 0 (k <= j < kpad); out is [B*L, kpad] (dtype), L = (S-k)/stride + 1.
  * Turns the Cin = 1 first convolution of the extractor_mode=layer_norm feature extractor
@@ -309,6 +319,45 @@ int st5_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 int st5_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale, void* bf16_mirror,
                       const float* hyper_dev, void* stream);
+/* ---- speech-decoder criterion (Tacotron2Loss with masking, text_to_speech_loss.py:263-345 + the label / length fix-ups of
+ * :186-204) as one reduction + one gradient pass.  All tensors fp32 on the device; ys [B, >=L, C] and labels [B, >=L] with
+ * their own batch strides (elements); olens int64 [B] (device) = the UNTRIMMED target lengths, r = reduction factor:
+ * valid frames are t < olens - olens % r, the stop label of the last valid frame is 1.
+ * fwd: out4 = {l1, mse, bce, n_frames}.   bwd: gradients of g_l1 * l1 + g_mse * mse + g_bce * bce (device scalars, NULL = 0)
+ * w.r.t. after / before / logits (each may be NULL). */
+int64_t st5_tacotron_loss_ws_bytes(void);
+int st5_tacotron_loss_fwd(const float* after, const float* before, const float* logits, const float* ys, int64_t ys_bstride,
+                          const float* labels, int64_t labels_bstride, const int64_t* olens, int32_t B, int32_t L, int32_t C, int32_t r,
+                          float pos_weight, float* out4, void* ws, void* stream);
+int st5_tacotron_loss_bwd(const float* after, const float* before, const float* logits, const float* ys, int64_t ys_bstride,
+                          const float* labels, int64_t labels_bstride, const int64_t* olens, int32_t B, int32_t L, int32_t C, int32_t r,
+                          float pos_weight, const float* out4, const float* g_l1, const float* g_mse, const float* g_bce, float* d_after,
+                          float* d_before, float* d_logits, void* stream);
+/* ---- Gumbel vector quantizer + time-wise code / encoder-state mix (speecht5.py:95-107, 858-882; csrc/vq.hip) ----
+ * logits, gumbel [N, G*V] fp32 (V <= 128); vars [G*V, Dg] fp32; enc / out [N, G*Dg] (dtype); mix_w [T] fp32 or NULL (rows are
+ * (b, t) with t = n % T); tau by value or from tau_dev.  training = 0: hard arg-max of the logits, no noise.
+ * fwd: out, idx [N, G] (code-book ROW g*V + v), avg [G][st5_vq_vpad()] (mean softmax, kept for bwd), perp2 = {code_perplexity,
+ * prob_perplexity}.  bwd: dlogits [N, G*V] from dsel [N][dsel_ld >= G*vpad] (= dOut . vars_g^T per group, the caller's GEMM; NULL =
+ * no code path), the upstream gradient of prob_perplexity (device scalar, NULL = 0); denc = (1 - w) dOut (NULL = skip). */
+int64_t st5_vq_ws_bytes(void);
+int32_t st5_vq_vpad(void);
+int st5_vq_fwd(const float* logits, const float* gumbel, const float* vars, const void* enc, const float* mix_w, float tau, const float* tau_dev,
+               int32_t training, void* out, int32_t* idx, float* avg, float* perp2, void* ws, int32_t N, int32_t G, int32_t V, int32_t Dg,
+               int32_t T, int dtype, void* stream);
+int st5_vq_bwd(const float* logits, const float* gumbel, const float* dsel, int32_t dsel_ld, const float* avg, const float* g_prob_perp,
+               const void* dout, const float* mix_w, float tau, const float* tau_dev, int32_t training, float* dlogits, void* denc, int32_t N,
+               int32_t G, int32_t V, int32_t Dg, int32_t T, int dtype, void* stream);
+/* ---- HuBERT NCE head (speech_encoder_postnet.py:56-76), fp32 (csrc/nce.hip) ----
+ * st5_norm_rows: y[r] = x[r] / max(|x[r]|, 1e-8) (x in `dtype`, y fp32), inv[r] = 1 / max(|x[r]|, 1e-8); st5_norm_rows_bwd: its
+ * gradient dx (`dtype`; accumulate != 0: dx += ...).  st5_canon_rows: canon[c] = smallest c' whose row equals row c exactly.
+ * st5_nce_logits: logits[s] = [sim[s, t_s], sim[s, :]] / temp with -inf where canon[c] == canon[t_s]; st5_nce_logits_bwd: dsim. */
+int st5_norm_rows(const void* x, float* y, float* inv, int64_t rows, int32_t cols, int dtype, void* stream);
+int st5_norm_rows_bwd(const float* y, const float* inv, const float* dy, void* dx, int64_t rows, int32_t cols, int32_t accumulate, int dtype,
+                      void* stream);
+int st5_canon_rows(const float* e, int32_t* canon, int32_t V, int32_t D, void* stream);
+int st5_nce_logits(const float* sim, const int32_t* target, const int32_t* canon, float* logits, int64_t S, int32_t V, float temp, void* stream);
+int st5_nce_logits_bwd(const float* dlogits, const int32_t* target, const int32_t* canon, float* dsim, int64_t S, int32_t V, float temp,
+                       void* stream);
 /* ---- CTC prefix scoring for joint CTC / attention beam search (sequence_generator.py:273-418 calls espnet's
  * CTCPrefixScore per hypothesis on the host; in-tree copy Speech2C/speech2c/models/modules/ctc_prefix_score.py:10-112) ----
  * x: fp32 CTC log-posteriors [T, V] of ONE utterance (device).  A state is r[T][2] fp32 = log r_t^n, log r_t^b of a prefix.

@@ -109,17 +109,24 @@ class TexttoSpeechLoss(nn.Module):
         labels, ys = sample["labels"], sample["dec_target"]
         olens, ilens = sample["dec_target_lengths"], sample["src_lengths"]
         r = model.reduction_factor
-        if r > 1:
-            olens_in = torch.div(torch.as_tensor(olens), r, rounding_mode="floor")
-            olens = torch.as_tensor(olens) - torch.as_tensor(olens) % r
-            # the collater pads to the longest utterance, so max(olens) = padded length rounded down to r (no host sync)
-            max_olen = ys.shape[1] - ys.shape[1] % r
-            ys = ys[:, :max_olen]
-            labels = labels[:, :max_olen]
-            labels = torch.scatter(labels, 1, (olens.to(labels.device) - 1).unsqueeze(1), 1.0)
+        fused = (after_outs.is_cuda and after_outs.dtype == before_outs.dtype == logits.dtype == ys.dtype == labels.dtype == torch.float32
+                 and after_outs.shape[1] == ys.shape[1] - ys.shape[1] % r and ys.is_contiguous() and labels.is_contiguous())
+        if fused:
+            # one reduction pass + one gradient pass (csrc/losses.hip); the length trim / stop-label fix-up below happen inside
+            olens_in = torch.div(torch.as_tensor(olens), r, rounding_mode="floor") if (r > 1 and self.use_guided_attn_loss) else olens
+            l1, l2, bce = Fn.tacotron_loss(after_outs, before_outs, logits, ys, labels, torch.as_tensor(olens), r, self.criterion.bce_pos_weight)
         else:
-            olens_in = olens
-        l1, l2, bce = self.criterion(after_outs, before_outs, logits, ys, labels, olens)
+            if r > 1:
+                olens_in = torch.div(torch.as_tensor(olens), r, rounding_mode="floor")
+                olens = torch.as_tensor(olens) - torch.as_tensor(olens) % r
+                # the collater pads to the longest utterance, so max(olens) = padded length rounded down to r (no host sync)
+                max_olen = ys.shape[1] - ys.shape[1] % r
+                ys = ys[:, :max_olen]
+                labels = labels[:, :max_olen]
+                labels = torch.scatter(labels, 1, (olens.to(labels.device) - 1).unsqueeze(1), 1.0)
+            else:
+                olens_in = olens
+            l1, l2, bce = self.criterion(after_outs, before_outs, logits, ys, labels, olens)
         if self.loss_type == "L1":
             loss = l1 + self.bce_loss_lambda * bce if self.bce_loss_lambda > 0.0 else l1
         elif self.loss_type == "L2":

@@ -139,7 +139,15 @@ __global__ void masked_fill_rows_kernel(T* __restrict__ x, const uint8_t* __rest
   for (int c = threadIdx.x & 63; c < cols; c += 64) x[row * cols + c] = Elem<T>::from_f(v[c]);
 }
 // dv[c] += sum_{masked rows} dx[r,c]; dx[r,:] = 0 for masked rows.  grid (column blocks of 256, row splits):
-// each thread owns one column and strides over rows; block partials go to dv with fp32 atomics.
+// each thread owns one column and strides over rows; block partials go to part[blockIdx.y][c] and a second kernel adds them
+// to dv in order (fp32 atomics here made the mask-embedding gradient differ from run to run in the last bits).
+__global__ void masked_fill_final_kernel(const float* __restrict__ part, float* __restrict__ dv, int ny, int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int y = 0; y < ny; ++y) s += part[(long long)y * cols + c];
+  dv[c] += s;
+}
 template <typename T>
 __global__ void masked_fill_rows_bwd_kernel(T* __restrict__ dx, const uint8_t* __restrict__ mask,
                                             float* __restrict__ dv, long long rows, int cols) {
@@ -152,7 +160,7 @@ __global__ void masked_fill_rows_bwd_kernel(T* __restrict__ dx, const uint8_t* _
       dx[r * cols + c] = Elem<T>::from_f(0.f);
     }
   }
-  if (dv && s != 0.f) unsafeAtomicAdd(dv + c, s);
+  if (dv) dv[(long long)blockIdx.y * cols + c] = s;   // (dv = the partial buffer here)
 }
 template <typename T>
 __global__ void add_table_rows_kernel(const T* __restrict__ x, const float* __restrict__ table,
@@ -199,25 +207,129 @@ __global__ void embed_rows_bwd_kernel(const T* __restrict__ dy, const int32_t* _
   for (int c = threadIdx.x & 63; c < cols; c += 64)
     atomicAdd(&trow[c], scale * Elem<T>::to_f(dy[row * cols + c]));
 }
-// Deterministic form: block (v, column chunk) walks every token in order and adds the rows whose id is v -- one writer per
-// table element, fixed summation order, so a training step is bit-reproducible (the atomic form above is not: fp32 atomics
-// commit in arrival order).  Every wave reads the same 64 ids and ballots the matches; ids stay L2-resident.
-template <typename T>
-__global__ __launch_bounds__(256) void embed_rows_bwd_det_kernel(const T* __restrict__ dy, const int32_t* __restrict__ tok,
-                                                                 float* __restrict__ dtable, long long rows, int cols, float scale) {
-  const int v = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x, lane = threadIdx.x & 63;
-  const bool live = c < cols;
-  float acc = 0.f;
-  for (long long t0 = 0; t0 < rows; t0 += 64) {
-    const long long t = t0 + lane;
-    unsigned long long m = __ballot(t < rows && tok[t] == v);
-    while (m) {
-      const int j = __builtin_ctzll(m);
-      m &= m - 1;
-      if (live) acc += Elem<T>::to_f(dy[(t0 + j) * cols + c]);
+// Deterministic form (no atomics; a training step is then bit-reproducible, the atomic form above is not: fp32 atomics commit
+// in arrival order).  Two kernels: (1) rank sort of the rows by (table row, position): every thread counts the rows that sort
+// before its own -- N^2 / 64 wave-steps on ids staged through LDS, ~10 us for 8k rows; (2) segmented sums over the sorted
+// order: the block in whose range a run of equal ids STARTS adds the whole run in position order and is the table row's only
+// writer.
+constexpr int RS_CHUNK = 2048;
+// block = 64 rows x 4 parts: part p counts inside its quarter of every staged chunk, the four counts are added at the end
+__global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t* __restrict__ tok, int32_t* __restrict__ order, int n) {
+  __shared__ int32_t ids[RS_CHUNK];
+  __shared__ int cnt[4][64];
+  const int tl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tl;
+  const int my = t < n ? tok[t] : 0x7fffffff;
+  int rank = 0;
+  for (int base = 0; base < n; base += RS_CHUNK) {
+    const int m = n - base < RS_CHUNK ? n - base : RS_CHUNK;
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += 256) ids[i] = tok[base + i];
+    __syncthreads();
+    const int lo = part * (RS_CHUNK / 4), hi = lo + RS_CHUNK / 4 < m ? lo + RS_CHUNK / 4 : m;
+    if (base + hi <= t) {                        // the whole piece lies before t: ties count
+      for (int i = lo; i < hi; ++i) rank += ids[i] <= my;
+    } else if (base + lo > t) {                  // the whole piece lies after t: ties do not count
+      for (int i = lo; i < hi; ++i) rank += ids[i] < my;
+    } else {
+      for (int i = lo; i < hi; ++i) rank += ids[i] < my || (ids[i] == my && base + i < t);
     }
   }
-  if (live && acc != 0.f) dtable[(long long)v * cols + c] += scale * acc;
+  cnt[part][tl] = rank;
+  __syncthreads();
+  if (part == 0 && t < n) order[cnt[0][tl] + cnt[1][tl] + cnt[2][tl] + cnt[3][tl]] = t;
+}
+constexpr int SEG_R = 16;  // sorted entries per block (run STARTS inside the range belong to the block)
+// grid (ceil(rows / SEG_R), ceil(cols / 64)); lane = one table column of the block's 64-column slab, wave w adds the run's
+// entries w, w + 4, w + 8, ... (a FIXED interleaving, so the result does not depend on timing), 16 independent loads in flight;
+// the four wave sums are combined in wave order.  A run is walked in chunks of 256 sorted entries whose row indices the block
+// loads together (a frequent token is a run of thousands of rows for one block: latency, not bandwidth, is what it costs).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_rows_bwd_det_kernel(const T* __restrict__ dy, const int32_t* __restrict__ tok,
+                                                                 const int32_t* __restrict__ order, float* __restrict__ dtable,
+                                                                 long long rows, int cols, int vocab, float scale,
+                                                                 const float* __restrict__ rw, int rw_div, int rw_mod) {
+  __shared__ int sh_r[256];
+  __shared__ float sh_w[256];
+  __shared__ float sh_p[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.y * 64 + lane;
+  const bool live = c < cols;
+  __shared__ int sh_id[SEG_R + 1];   // ids of sorted entries s0 - 1 .. s0 + SEG_R - 1 (fetched together: two dependent loads, not 2 x SEG_R)
+  const long long s0 = (long long)blockIdx.x * SEG_R;
+  const long long s1 = s0 + SEG_R < rows ? s0 + SEG_R : rows;
+  if (tid <= SEG_R) {
+    const long long e = s0 - 1 + tid;
+    sh_id[tid] = (e >= 0 && e < rows) ? tok[order[e]] : (int)0x80000000;
+  }
+  __syncthreads();
+  for (long long s = s0; s < s1; ++s) {
+    const int v = sh_id[s - s0 + 1];
+    if (s > 0 && sh_id[s - s0] == v) continue;          // not a run start (block-uniform)
+    if (v < 0 || v >= vocab) continue;
+    float acc = 0.f;
+    for (long long base = s;; base += 256) {
+      const long long i = base + tid;
+      int r = -1;
+      if (i < rows) { const int o = order[i]; if (tok[o] == v) r = o; }
+      __syncthreads();
+      sh_r[tid] = r;
+      sh_w[tid] = (r >= 0 && rw) ? rw[(r / rw_div) % rw_mod] : 1.f;
+      __syncthreads();
+      // the run's entries are a prefix of the chunk (sorted order); this wave takes entries wave, wave + 4, ...
+#pragma unroll 1
+      for (int k0 = 0; k0 < 256; k0 += 64) {
+        if (sh_r[k0] < 0) break;
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int k = k0 + u * 4 + wave;
+          const int rr = sh_r[k];
+          x[u] = (rr >= 0 && live) ? sh_w[k] * Elem<T>::to_f(dy[(long long)rr * cols + c]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += x[u];   // (entries past the run's end add exact zeros)
+      }
+      if (sh_r[255] < 0) break;                    // the run ended inside this chunk (block-uniform)
+    }
+    __syncthreads();
+    sh_p[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && live) {
+      const float t = ((sh_p[0][lane] + sh_p[1][lane]) + sh_p[2][lane]) + sh_p[3][lane];
+      if (t != 0.f) dtable[(long long)v * cols + c] += scale * t;
+    }
+  }
+}
+
+// x[b, t, :] = 0 for t < head or t >= tail_start  (x [B, Tp, C]): the halo / uncovered rows of the convolution-gradient buffers
+template <typename T>
+__global__ __launch_bounds__(256) void zero_time_edges_kernel(T* __restrict__ x, int B, int Tp, int C, int head, int tail_start) {
+  const int nedge = head + (Tp - tail_start);
+  const long long nrow = (long long)B * nedge;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrow) return;
+  const int b = (int)(row / nedge), e = (int)(row % nedge);
+  const int t = e < head ? e : tail_start + (e - head);
+  T* d = x + ((long long)b * Tp + t) * C;
+  const T zero = Elem<T>::from_f(0.f);
+  for (int c = threadIdx.x & 63; c < C; c += 64) d[c] = zero;
+}
+
+// dst[a, b, c] (+)= src[off + a*sa + b*sb + c*sc]: the weight re-layouts of the implicit-GEMM convolutions (permutes, tap
+// flips -- negative strides -- and the cast to the compute dtype) and the re-laid-out accumulation of their weight gradients
+// in one pass each (torch needs permute().contiguous() + a cast, or a strided add_).
+template <typename T>
+__global__ __launch_bounds__(256) void gather3_kernel(const float* __restrict__ src, T* __restrict__ dst, int A, int B, int C, long long sa,
+                                                      long long sb, long long sc, long long off, int accumulate) {
+  const long long n = (long long)A * B * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long ab = i / C;
+    const int b = (int)(ab % B), a = (int)(ab / B);
+    const float v = src[off + a * sa + b * sb + c * sc];
+    dst[i] = Elem<T>::from_f(accumulate ? Elem<T>::to_f(dst[i]) + v : v);
+  }
 }
 template <typename T>
 __global__ void pad_time_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int Tn, int C, int pad_l,
@@ -467,8 +579,22 @@ extern "C" int st5_masked_fill_rows_bwd(void* dx, const uint8_t* mask, float* dv
   hipStream_t s = (hipStream_t)stream;
   const unsigned ny = (unsigned)(rows < 256 ? rows : 256);
   dim3 grid((unsigned)((cols + 255) / 256), ny);
-  DISPATCH(dtype, hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)dx, mask, dv, (long long)rows, cols),
-           hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<float>, grid, dim3(256), 0, s, (float*)dx, mask, dv, (long long)rows, cols));
+  float* part = nullptr;
+  if (dv) {   // grow-only partial buffer [256][cols] (first use / growth happens outside stream capture)
+    static float* g_part = nullptr;
+    static size_t g_part_n = 0;
+    const size_t want = (size_t)256 * cols;
+    if (want > g_part_n) {
+      if (g_part) (void)hipFree(g_part);
+      g_part = nullptr; g_part_n = 0;
+      if (hipMalloc(&g_part, want * sizeof(float)) != hipSuccess) return ST5_ERR_LAUNCH;
+      g_part_n = want;
+    }
+    part = g_part;
+  }
+  DISPATCH(dtype, hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)dx, mask, part, (long long)rows, cols),
+           hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<float>, grid, dim3(256), 0, s, (float*)dx, mask, part, (long long)rows, cols));
+  if (dv) hipLaunchKernelGGL(masked_fill_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, part, dv, (int)ny, cols);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -516,14 +642,50 @@ extern "C" int st5_embed_rows_bwd(const void* dy, const int32_t* tok, float* dta
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
+int32_t* g_order = nullptr;   // sorted-order workspace of the deterministic row scatter (grow-only)
+long long g_order_n = 0;
+extern "C" int st5_embed_rows_bwd_det_w(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, int32_t vocab,
+                                        float scale, const float* row_w, int32_t rw_div, int32_t rw_mod, int dtype, void* stream) {
+  if (!dy || !tok || !dtable || rows < 0 || cols <= 0 || vocab <= 0 || (row_w && (rw_div <= 0 || rw_mod <= 0))) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  if (rows > (1ll << 22)) return ST5_ERR_ARG;   // the rank sort is quadratic: meant for token / frame counts of one micro-batch
+  hipStream_t s = (hipStream_t)stream;
+  if (rows > g_order_n) {   // (first use / growth: outside stream capture, like every other workspace of this library)
+    if (g_order) (void)hipFree(g_order);
+    g_order = nullptr;
+    const long long want = rows < 65536 ? 65536 : rows;
+    if (hipMalloc(&g_order, want * sizeof(int32_t)) != hipSuccess) { g_order_n = 0; return ST5_ERR_LAUNCH; }
+    g_order_n = want;
+  }
+  hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, tok, g_order, (int)rows);
+  dim3 grid((unsigned)((rows + SEG_R - 1) / SEG_R), (unsigned)((cols + 63) / 64));
+  DISPATCH(dtype, hipLaunchKernelGGL(embed_rows_bwd_det_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, tok, g_order, dtable, (long long)rows, cols, vocab, scale, row_w, rw_div, rw_mod),
+           hipLaunchKernelGGL(embed_rows_bwd_det_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, tok, g_order, dtable, (long long)rows, cols, vocab, scale, row_w, rw_div, rw_mod));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
 extern "C" int st5_embed_rows_bwd_det(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, int32_t vocab,
                                       float scale, int dtype, void* stream) {
-  if (!dy || !tok || !dtable || rows < 0 || cols <= 0 || vocab <= 0) return ST5_ERR_ARG;
-  if (rows == 0) return ST5_OK;
+  return st5_embed_rows_bwd_det_w(dy, tok, dtable, rows, cols, vocab, scale, nullptr, 1, 1, dtype, stream);
+}
+extern "C" int st5_zero_time_edges(void* x, int32_t B, int32_t Tp, int32_t C, int32_t head, int32_t tail_start, int dtype, void* stream) {
+  if (!x || B <= 0 || Tp <= 0 || C <= 0 || head < 0 || tail_start < head || tail_start > Tp) return ST5_ERR_ARG;
+  const long long nrow = (long long)B * (head + Tp - tail_start);
+  if (nrow == 0) return ST5_OK;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)vocab, (unsigned)((cols + 255) / 256));
-  DISPATCH(dtype, hipLaunchKernelGGL(embed_rows_bwd_det_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, tok, dtable, (long long)rows, cols, scale),
-           hipLaunchKernelGGL(embed_rows_bwd_det_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, tok, dtable, (long long)rows, cols, scale));
+  dim3 grid((unsigned)((nrow + 3) / 4));
+  DISPATCH(dtype, hipLaunchKernelGGL(zero_time_edges_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)x, B, Tp, C, head, tail_start),
+           hipLaunchKernelGGL(zero_time_edges_kernel<float>, grid, dim3(256), 0, s, (float*)x, B, Tp, C, head, tail_start));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_gather3(const float* src, void* dst, int32_t A, int32_t B, int32_t C, int64_t sa, int64_t sb, int64_t sc, int64_t off,
+                           int32_t accumulate, int dtype, void* stream) {
+  if (!src || !dst || A <= 0 || B <= 0 || C <= 0) return ST5_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)A * B * C;
+  DISPATCH(dtype, hipLaunchKernelGGL(gather3_kernel<bf16_t>, grid_for(n), dim3(256), 0, s, src, (bf16_t*)dst, A, B, C, (long long)sa, (long long)sb, (long long)sc, (long long)off, accumulate),
+           hipLaunchKernelGGL(gather3_kernel<float>, grid_for(n), dim3(256), 0, s, src, (float*)dst, A, B, C, (long long)sa, (long long)sb, (long long)sc, (long long)off, accumulate));
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

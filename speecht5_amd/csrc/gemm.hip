@@ -196,16 +196,24 @@ template <> __device__ __forceinline__ bf16x8 ones_frag<bf16_t>() {
 }
 template <> __device__ __forceinline__ f32x4 ones_frag<float>() { f32x4 o = {1.f, 1.f, 1.f, 1.f}; return o; }
 
-// asum[m] += row sums held in column 0 of the two 32x32 "A x ones" accumulators of a wave (rows mbase .. mbase+63)
-__device__ __forceinline__ void flush_asum(float* asum, const f32x16& s0, const f32x16& s1, int mbase, int M, int lane) {
+// Row sums held in column 0 of the two 32x32 "A x ones" accumulators of a wave (rows mbase .. mbase+63).  Exactly one wave
+// of the grid owns a given row (first tile column, wave column 0), so no atomics: without split-K the sums are added to
+// asum[] in place; with split-K every split STORES its partial column behind the slabs (part = slabs + nsplit*M*N + split*M)
+// and the slab-reduce kernel adds the splits in order -- the bias gradient is then bit-reproducible like the rest of the step.
+__device__ __forceinline__ void flush_asum(float* dst, bool accumulate, const f32x16& s0, const f32x16& s1, int mbase, int M, int lane) {
   if ((lane & 31) != 0) return;
   const int hi = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-    if (mbase + row < M) unsafeAtomicAdd(asum + mbase + row, s0[r]);
-    if (mbase + 32 + row < M) unsafeAtomicAdd(asum + mbase + 32 + row, s1[r]);
+    if (mbase + row < M) dst[mbase + row] = accumulate ? dst[mbase + row] + s0[r] : s0[r];
+    if (mbase + 32 + row < M) dst[mbase + 32 + row] = accumulate ? dst[mbase + 32 + row] + s1[r] : s1[r];
   }
+}
+__device__ __forceinline__ float* asum_target(const st5_gemm_params& p, bool& accumulate) {
+  accumulate = gridDim.y == 1;
+  if (accumulate) return p.asum;
+  return reinterpret_cast<float*>(const_cast<void*>(p.C.ptr)) + (long long)gridDim.y * p.M * p.N + (long long)blockIdx.y * p.M;
 }
 
 // predicated (static-index) tail accessors: arrays stay in registers
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const st5_gemm_params
     if (kt + 1 < nk) { la.store(nxt); lb.store(nxt + TILE_BYTES); }
     __syncthreads();
   }
-  if (do_asum) flush_asum(p.asum, sum0, sum1, m0 + wr * 64, p.M, lane);
+  if (do_asum) { bool acc_; float* dst_ = asum_target(p, acc_); flush_asum(dst_, acc_, sum0, sum1, m0 + wr * 64, p.M, lane); }
 
   // ------------------------------ epilogue ------------------------------
   EpiArgs ea;
@@ -527,9 +535,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const st5_gemm_params
 // C[m, n] = beta * C[m, n] + sum_s slab[s][m][n]   (slabs dense [M, N] fp32; C fp32 with row mapping)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C,
                                                             int nsplit, int M, int N, long long ldc, int rpb,
-                                                            long long bstride, float beta) {
+                                                            long long bstride, float beta, float* __restrict__ asum) {
   const long long nv = (long long)M * N / 4;  // N % 4 == 0 guaranteed by the host
   const long long slab = (long long)M * N;
+  if (asum) {   // bias-gradient column: the splits' partial columns sit behind the slabs
+    const float* part = slabs + (long long)nsplit * slab;
+    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {
+      float a = part[m];
+      for (int s2 = 1; s2 < nsplit; ++s2) a += part[(long long)s2 * M + m];
+      asum[m] += a;
+    }
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
     const long long e0 = i * 4;
     const int m = (int)(e0 / N), n = (int)(e0 % N);
@@ -554,7 +570,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // not launched one by one; their descriptors queue up (each GEMM keeps its slabs alive in a bump arena) and
 // st5_gemm_flush_splitk() folds all of them into their outputs with ONE launch (up to MR_MAX per launch).
 constexpr int MR_MAX = 48;
-struct MrDesc { const float* slabs; float* C; long long ldc; int nsplit, M, N; float beta; int blk0; int pad; };
+struct MrDesc { const float* slabs; float* C; float* asum; long long ldc; int nsplit, M, N; float beta; int blk0; int pad; };
 struct MrArgs { MrDesc d[MR_MAX]; int n; };
 __global__ __launch_bounds__(256) void splitk_multi_reduce_kernel(const MrArgs a) {
   int j = 0;
@@ -562,6 +578,14 @@ __global__ __launch_bounds__(256) void splitk_multi_reduce_kernel(const MrArgs a
   const MrDesc d = a.d[j];
   const int nblk = (j + 1 < a.n ? a.d[j + 1].blk0 : (int)gridDim.x) - d.blk0;
   const long long nv = (long long)d.M * d.N / 4, slab = (long long)d.M * d.N;
+  if (d.asum) {
+    const float* part = d.slabs + (long long)d.nsplit * slab;
+    for (long long m = (long long)(blockIdx.x - d.blk0) * 256 + threadIdx.x; m < d.M; m += (long long)nblk * 256) {
+      float a = part[m];
+      for (int s2 = 1; s2 < d.nsplit; ++s2) a += part[(long long)s2 * d.M + m];
+      d.asum[m] += a;
+    }
+  }
   for (long long i = (long long)(blockIdx.x - d.blk0) * 256 + threadIdx.x; i < nv; i += (long long)nblk * 256) {
     const long long e0 = i * 4;
     const int m = (int)(e0 / d.N), n = (int)(e0 % d.N);
@@ -1187,7 +1211,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
     }
   }
   __syncthreads();
-  if (do_asum) flush_asum(p.asum, sum0, sum1, m0 + wr * 64, p.M, lane);
+  if (do_asum) { bool acc_; float* dst_ = asum_target(p, acc_); flush_asum(dst_, acc_, sum0, sum1, m0 + wr * 64, p.M, lane); }
 
   EpiArgs ea;
   ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
@@ -1293,7 +1317,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
     }
   }
   if (nsplit > 1 && g_defer && (p.flags & ST5_GEMM_DEFERRABLE) && !p.C.rpb && p.C.ld % 4 == 0) {
-    const size_t need = (size_t)nsplit * p.M * p.N * sizeof(float);
+    const size_t need = ((size_t)nsplit * p.M * p.N + (p.asum ? (size_t)nsplit * p.M : 0)) * sizeof(float);
     // the same output twice in one batch (tied weights) would race inside the batched reduction: fold what is pending first
     for (int j = 0; j < g_pending.n; ++j)
       if (g_pending.d[j].C == p.C.ptr) { const int rc = flush_pending(s); if (rc) return rc; break; }
@@ -1318,7 +1342,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
                    : dtype == ST5_BF16 ? launch<bf16_t>(q, 1, nsplit, s) : launch<float>(q, 1, nsplit, s);
     if (rc) return rc;
     MrDesc& d = g_pending.d[g_pending.n++];
-    d.slabs = slabs; d.C = reinterpret_cast<float*>(const_cast<void*>(p.C.ptr)); d.ldc = p.C.ld; d.nsplit = nsplit;
+    d.slabs = slabs; d.C = reinterpret_cast<float*>(const_cast<void*>(p.C.ptr)); d.asum = p.asum; d.ldc = p.C.ld; d.nsplit = nsplit;
     d.M = p.M; d.N = p.N; d.beta = p.beta; d.blk0 = g_pending_blocks; d.pad = 0;
     long long blocks = ((long long)p.M * p.N / 4 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
@@ -1326,7 +1350,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
     return ST5_OK;
   }
   if (nsplit > 1) {
-    float* slabs = slab_workspace((size_t)nsplit * p.M * p.N * sizeof(float), s);
+    float* slabs = slab_workspace(((size_t)nsplit * p.M * p.N + (p.asum ? (size_t)nsplit * p.M : 0)) * sizeof(float), s);
     if (!slabs) return ST5_ERR_LAUNCH;
     st5_gemm_params q = p;
     q.C.ptr = slabs; q.C.ld = p.N; q.C.rpb = 0; q.C.bstride = 0; q.C.zs0 = q.C.zs1 = 0; q.beta = 0.f;
@@ -1337,7 +1361,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs,
                        reinterpret_cast<float*>(const_cast<void*>(p.C.ptr)), nsplit, p.M, p.N, (long long)p.C.ld, p.C.rpb,
-                       (long long)p.C.bstride, p.beta);
+                       (long long)p.C.bstride, p.beta, p.asum);
     HIP_CHECK_LAUNCH();
     return ST5_OK;
   }

@@ -422,53 +422,6 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
     part[(long long)blockIdx.y * cols + blockIdx.x * 256 + c] = s;
   }
 }
-// single-launch variant: block partials go straight into out[] with fp32 atomics (cols x nsplit atomics in total)
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void colreduce_atomic_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                               const float* __restrict__ mean,
-                                                               const float* __restrict__ rstd, float* __restrict__ out,
-                                                               long long rows, int cols, long long ld, float scale) {
-  __shared__ float red[8][256 + 8];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c0 = blockIdx.x * 256 + tx * 8;
-  const bool vec = (ld % 8) == 0 && c0 + 8 <= cols;
-  float acc[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  if (c0 < cols) {
-    for (long long r = (long long)blockIdx.y * 8 + ty; r < rows; r += (long long)gridDim.y * 8) {
-      float a[8], b[8];
-      if (vec) load8f<T>(x + r * ld + c0, a);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = (c0 + e < cols) ? Elem<T>::to_f(x[r * ld + c0 + e]) : 0.f;
-      }
-      if (MODE == 1) {
-        if (vec) load8f<T>(dy + r * ld + c0, b);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) b[e] = (c0 + e < cols) ? Elem<T>::to_f(dy[r * ld + c0 + e]) : 0.f;
-        }
-        const float mu = mean[r], rs = rstd[r];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += b[e] * (a[e] - mu) * rs;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += a[e];
-      }
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = acc[e];
-  __syncthreads();
-  const int c = threadIdx.x;
-  if (blockIdx.x * 256 + c < cols) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += red[j][c];
-    unsafeAtomicAdd(out + blockIdx.x * 256 + c, s * scale);
-  }
-}
 __global__ void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nsplit, int cols,
                                        float scale, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -491,15 +444,12 @@ int colreduce(const void* x, const void* dy, const float* mean, const float* rst
               long long rows, int cols, long long ld, float scale, int accumulate, hipStream_t s) {
   const int ns = nsplit_for(rows);
   dim3 grid((cols + 255) / 256, ns);
-  if (accumulate) {  // += : one launch, block partials combined with fp32 atomics
-    hipLaunchKernelGGL((colreduce_atomic_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, mean, rstd,
-                       out, rows, cols, ld, scale);
-  } else {
-    hipLaunchKernelGGL((colreduce_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, mean, rstd, ws,
-                       rows, cols, ld);
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, ws, out, ns, cols, scale,
-                       accumulate);
-  }
+  // two stages in both forms (block partials -> ordered final sum; `accumulate` adds to out[] there): the single-launch
+  // variant with fp32 atomics made bias gradients depend on the order in which blocks retire
+  hipLaunchKernelGGL((colreduce_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, mean, rstd, ws,
+                     rows, cols, ld);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, ws, out, ns, cols, scale,
+                     accumulate);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

@@ -179,6 +179,15 @@ class _WeightCache:
 weight_cache = _WeightCache()
 
 
+def _gather3(src, dst, dims, strides, off=0, accumulate=False):
+    """dst[a, b, c] (+)= src.flat[off + a*sa + b*sb + c*sc]: one-pass re-layout (+ cast to dst's dtype) of an fp32 tensor."""
+    A, B, C = dims
+    assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst.numel() == A * B * C
+    hip.check(hip.lib().st5_gather3(src.data_ptr(), dst.data_ptr(), A, B, C, strides[0], strides[1], strides[2], off,
+                                    1 if accumulate else 0, _dt(dst), hip.stream()), "st5_gather3")
+    return dst
+
+
 def _cast_into(src, dst, transpose=False):
     """dst (compute dtype) <- src (fp32 [rows, cols]); transpose writes dst[c, r]."""
     rows, cols = src.shape
@@ -517,7 +526,7 @@ def _conv_wgrad(w, opA, opB, Cout, k, Cin, Kred, dt, keep):
     def run():
         tmpw = torch.empty(Cout, k * Cin, dtype=torch.float32, device=w.device)
         hip.gemm(opA, opB, hip.operand(tmpw, k * Cin), Cout, k * Cin, Kred, dt, flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
-        grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))  # (glue: layout permute of a <= 3 MB tensor)
+        _gather3(tmpw, grad_buffer(w), (Cout, Cin, k), (k * Cin, 1, Cin), accumulate=True)   # grad[co, ci, j] += tmpw[co, j, ci]
     if _S.side is not None and getattr(w, "_st5_side_ok", False):
         hip.check(hip.lib().st5_stream_fork(hip.stream(), _S.side_raw), "st5_stream_fork")
         with torch.cuda.stream(_S.side):
@@ -841,6 +850,50 @@ def cross_entropy_sum(logits, target, label_smoothing=0.0, ignore_index=None):
                                          ignore_index)
 
 
+class TacotronLossFunction(torch.autograd.Function):
+    """(l1, mse, bce) of Tacotron2Loss with masking in one reduction pass (csrc/losses.hip); the gradient pass produces
+    d_after / d_before / d_logits from the three upstream scalar gradients without leaving the device."""
+
+    @staticmethod
+    def forward(ctx, after, before, logits, ys, labels, olens, r, pos_weight):
+        B, L, C = after.shape
+        after, before, logits = after.contiguous(), before.contiguous(), logits.contiguous()
+        assert after.dtype == before.dtype == logits.dtype == ys.dtype == labels.dtype == torch.float32
+        assert ys.stride(2) == 1 and ys.stride(1) == C and labels.stride(1) == 1 and ys.shape[1] >= L and labels.shape[1] >= L
+        olens = olens.to(device=after.device, dtype=torch.int64).contiguous()
+        L_ = hip.lib()
+        out = torch.empty(4, dtype=torch.float32, device=after.device)
+        ws = hip.workspace(L_.st5_tacotron_loss_ws_bytes(), after.device)
+        hip.check(L_.st5_tacotron_loss_fwd(after.data_ptr(), before.data_ptr(), logits.data_ptr(), ys.data_ptr(), ys.stride(0),
+                                           labels.data_ptr(), labels.stride(0), olens.data_ptr(), B, L, C, int(r), float(pos_weight),
+                                           out.data_ptr(), ws.data_ptr(), hip.stream()), "st5_tacotron_loss_fwd")
+        ctx.save_for_backward(after, before, logits, ys, labels, olens, out)
+        ctx.meta = (int(r), float(pos_weight))
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        after, before, logits, ys, labels, olens, out = ctx.saved_tensors
+        r, pw = ctx.meta
+        B, L, C = after.shape
+        need = ctx.needs_input_grad
+        da = torch.empty_like(after) if need[0] else None
+        db = torch.empty_like(before) if need[1] else None
+        dl = torch.empty_like(logits) if need[2] else None
+        gs = [g.contiguous() if g is not None else None for g in (g1, g2, g3)]
+        hip.check(hip.lib().st5_tacotron_loss_bwd(after.data_ptr(), before.data_ptr(), logits.data_ptr(), ys.data_ptr(), ys.stride(0),
+                                                  labels.data_ptr(), labels.stride(0), olens.data_ptr(), B, L, C, r, pw, out.data_ptr(),
+                                                  hip.ptr(gs[0]), hip.ptr(gs[1]), hip.ptr(gs[2]), hip.ptr(da), hip.ptr(db), hip.ptr(dl),
+                                                  hip.stream()), "st5_tacotron_loss_bwd")
+        return da, db, dl, None, None, None, None, None
+
+
+def tacotron_loss(after, before, logits, ys, labels, olens, r, pos_weight):
+    """Masked L1 / MSE / stop-token BCE of the speech decoder (text_to_speech_loss.py:186-216, :296-345): `olens` are the
+    untrimmed target lengths, trimmed to a multiple of `r` inside (with the last valid frame's stop label forced to 1)."""
+    return TacotronLossFunction.apply(after, before, logits, ys, labels, olens, r, pos_weight)
+
+
 # -------------------------------------------------------------------------------------------------
 # LayerNorm
 # -------------------------------------------------------------------------------------------------
@@ -1076,11 +1129,11 @@ def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe
     hip.gemm(hip.operand(dqp, nb, zs0=H * T * nb, zs1=T * nb), hip.operand(qt, qld, off=qoff, zs0=T * qld, zs1=hd),
              hip.operand(part, hd, zs0=H * nb * hd, zs1=nb * hd), nb, hd, T, hip.BF16, batch=BH, zdiv=H,
              flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, alpha=alpha)
-    g = torch.zeros(nb, hd, dtype=torch.float32, device=dev)
+    g = torch.empty(nb, hd, dtype=torch.float32, device=dev)
     L = hip.lib()
     ws = hip.workspace(L.st5_colsum_ws_bytes(BH, nb * hd), dev)
-    hip.check(L.st5_colsum_ws(part.data_ptr(), g.data_ptr(), ws.data_ptr(), BH, nb * hd, nb * hd, 1.0, 1, hip.F32, hip.stream()),
-              "st5_colsum_ws")
+    hip.check(L.st5_colsum_ws(part.data_ptr(), g.data_ptr(), ws.data_ptr(), BH, nb * hd, nb * hd, 1.0, 0, hip.F32, hip.stream()),
+              "st5_colsum_ws")   # (overwrite form: two-stage, no zero fill, fixed summation order)
     return g
 
 
@@ -1368,6 +1421,132 @@ def embed_rows(table, tok, pos=None, pidx=None, emb_scale=1.0, pos_scale=1.0):
                                    float(emb_scale), float(pos_scale), _S.dtype)
 
 
+class GumbelVQFunction(torch.autograd.Function):
+    """Gumbel-softmax code selection + code-book lookup + time-wise mix with the encoder states + both perplexities
+    (csrc/vq.hip).  logits [N, G*V] fp32; vars_p the [1, G*V, Dg] fp32 code-book parameter; vars_c its compute-dtype copy (for
+    the backward GEMM); enc [N, G*Dg] compute dtype or None; gumbel [N, G*V] fp32 or None (eval); mix_w [T] fp32 or None;
+    tau float or 1-element device tensor.  Returns (out [N, G*Dg], code_perplexity, prob_perplexity, code rows [N, G] int32)."""
+
+    @staticmethod
+    def forward(ctx, logits, vars_p, vars_c, enc, gumbel, mix_w, tau, training, G, V, T, out_dtype):
+        L = hip.lib()
+        N = logits.shape[0]
+        Dg = vars_p.shape[-1]
+        dev = logits.device
+        logits = logits.contiguous()
+        assert logits.dtype == torch.float32 and logits.shape[1] == G * V and V <= L.st5_vq_vpad()
+        if enc is not None:
+            enc = enc.contiguous()
+            out_dtype = enc.dtype
+        out = torch.empty(N, G * Dg, dtype=out_dtype, device=dev)
+        idx = torch.empty(N, G, dtype=torch.int32, device=dev)
+        avg = torch.empty(G, L.st5_vq_vpad(), dtype=torch.float32, device=dev)
+        perp = torch.empty(2, dtype=torch.float32, device=dev)
+        ws = hip.workspace(L.st5_vq_ws_bytes(), dev)
+        tau_dev = tau if torch.is_tensor(tau) else None
+        hip.check(L.st5_vq_fwd(logits.data_ptr(), hip.ptr(gumbel), vars_p.data_ptr(), hip.ptr(enc), hip.ptr(mix_w),
+                               0.0 if tau_dev is not None else float(tau), hip.ptr(tau_dev), 1 if training else 0, out.data_ptr(),
+                               idx.data_ptr(), avg.data_ptr(), perp.data_ptr(), ws.data_ptr(), N, G, V, Dg, T, _dt(out), hip.stream()),
+                  "st5_vq_fwd")
+        ctx.save_for_backward(logits, gumbel, mix_w, avg, idx, vars_c, tau_dev)
+        ctx.meta = (vars_p, None if tau_dev is not None else float(tau), bool(training), G, V, T, Dg, enc is not None)
+        ctx.mark_non_differentiable(idx)
+        return out, perp[0], perp[1], idx
+
+    @staticmethod
+    def backward(ctx, dout, g_code, g_prob, _g_idx):
+        logits, gumbel, mix_w, avg, idx, vars_c, tau_dev = ctx.saved_tensors
+        vars_p, tau, training, G, V, T, Dg, has_enc = ctx.meta
+        L = hip.lib()
+        N = logits.shape[0]
+        dev = logits.device
+        VP = L.st5_vq_vpad()
+        dout = dout.contiguous()
+        dt = _dt(dout)
+        dsel = None
+        if training and ctx.needs_input_grad[0]:
+            # dsel[n, g, v] = <dOut[n, g*Dg:(g+1)*Dg], vars[g, v, :]>   (one batched NT GEMM over the groups, fp32 out)
+            dsel = torch.empty(N, G * VP, dtype=torch.float32, device=dev)
+            hip.gemm(hip.operand(dout, G * Dg, zs0=Dg), hip.operand(vars_c, Dg, zs0=V * Dg), hip.operand(dsel, G * VP, zs0=VP),
+                     N, V, Dg, dt, batch=G, flags=hip.OUT_F32)
+        dlogits = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        denc = torch.empty_like(dout) if (has_enc and ctx.needs_input_grad[3]) else None
+        if dlogits is not None or denc is not None:
+            if dlogits is None:
+                dlogits = torch.empty_like(logits)
+            hip.check(L.st5_vq_bwd(logits.data_ptr(), hip.ptr(gumbel), hip.ptr(dsel), G * VP, avg.data_ptr(),
+                                   hip.ptr(g_prob.contiguous() if g_prob is not None else None), dout.data_ptr(), hip.ptr(mix_w),
+                                   0.0 if tau_dev is not None else tau, hip.ptr(tau_dev), 1 if training else 0, dlogits.data_ptr(),
+                                   hip.ptr(denc), N, G, V, Dg, T, dt, hip.stream()), "st5_vq_bwd")
+        if vars_p.requires_grad:
+            g = grad_buffer(vars_p)
+            hip.check(L.st5_embed_rows_bwd_det_w(dout.data_ptr(), idx.data_ptr(), g.data_ptr(), N * G, Dg, G * V, 1.0, hip.ptr(mix_w), G, T,
+                                                 dt, hip.stream()), "st5_embed_rows_bwd_det_w")
+            _grad_done(vars_p)
+        return dlogits, None, None, denc, None, None, None, None, None, None, None, None
+
+
+class NCELogitsFunction(torch.autograd.Function):
+    """logits [S, 1 + V] of the HuBERT NCE head from the projected frames x [S, D] (any float dtype), the code-book rows
+    emb_param[row0 : row0 + V] (fp32 parameter) and the per-frame class ids (speech_encoder_postnet.py:56-76); fp32 like the
+    reference.  Gradients: dx is returned, the code-book gradient is accumulated into the parameter's gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, emb_param, row0, V, target, temp):
+        L = hip.lib()
+        S, D = x.shape
+        dev = x.device
+        x = x.contiguous()
+        emb = emb_param.detach()[row0:row0 + V]
+        assert emb.is_contiguous() and emb.dtype == torch.float32
+        tgt = target.to(torch.int32).contiguous()
+        st = hip.stream()
+        en = torch.empty(V, D, dtype=torch.float32, device=dev)
+        inv_e = torch.empty(V, dtype=torch.float32, device=dev)
+        canon = torch.empty(V, dtype=torch.int32, device=dev)
+        hip.check(L.st5_norm_rows(emb.data_ptr(), en.data_ptr(), inv_e.data_ptr(), V, D, hip.F32, st), "st5_norm_rows")
+        hip.check(L.st5_canon_rows(emb.data_ptr(), canon.data_ptr(), V, D, st), "st5_canon_rows")
+        xn = torch.empty(S, D, dtype=torch.float32, device=dev)
+        inv_x = torch.empty(S, dtype=torch.float32, device=dev)
+        logits = torch.empty(S, V + 1, dtype=torch.float32, device=dev)
+        if S > 0:
+            hip.check(L.st5_norm_rows(x.data_ptr(), xn.data_ptr(), inv_x.data_ptr(), S, D, _dt(x), st), "st5_norm_rows")
+            sim = torch.empty(S, V, dtype=torch.float32, device=dev)
+            hip.gemm(hip.operand(xn, D), hip.operand(en, D), hip.operand(sim, V), S, V, D, hip.F32)
+            hip.check(L.st5_nce_logits(sim.data_ptr(), tgt.data_ptr(), canon.data_ptr(), logits.data_ptr(), S, V, float(temp), st), "st5_nce_logits")
+        ctx.save_for_backward(xn, inv_x, en, inv_e, canon, tgt)
+        ctx.meta = (emb_param, row0, V, float(temp), x.dtype)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        xn, inv_x, en, inv_e, canon, tgt = ctx.saved_tensors
+        emb_param, row0, V, temp, xdtype = ctx.meta
+        L = hip.lib()
+        S, D = xn.shape
+        dev = xn.device
+        st = hip.stream()
+        dx = torch.empty(S, D, dtype=xdtype, device=dev) if ctx.needs_input_grad[0] else None
+        if S == 0:
+            return dx, None, None, None, None, None
+        dlogits = dlogits.contiguous().float()
+        dsim = torch.empty(S, V, dtype=torch.float32, device=dev)
+        hip.check(L.st5_nce_logits_bwd(dlogits.data_ptr(), tgt.data_ptr(), canon.data_ptr(), dsim.data_ptr(), S, V, temp, st), "st5_nce_logits_bwd")
+        if dx is not None:
+            dxn = torch.empty(S, D, dtype=torch.float32, device=dev)
+            hip.gemm(hip.operand(dsim, V), hip.operand(en, D), hip.operand(dxn, D), S, D, V, hip.F32, flags=hip.B_KSTRIDED)
+            hip.check(L.st5_norm_rows_bwd(xn.data_ptr(), inv_x.data_ptr(), dxn.data_ptr(), dx.data_ptr(), S, D, 0, hip.dt(xdtype), st),
+                      "st5_norm_rows_bwd")
+        if emb_param.requires_grad:
+            den = torch.empty(V, D, dtype=torch.float32, device=dev)
+            hip.gemm(hip.operand(dsim, V), hip.operand(xn, D), hip.operand(den, D), V, D, S, hip.F32,
+                     flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)   # (OUT_F32: the split-K path, few output tiles / long K)
+            g = grad_buffer(emb_param)[row0:row0 + V]
+            hip.check(L.st5_norm_rows_bwd(en.data_ptr(), inv_e.data_ptr(), den.data_ptr(), g.data_ptr(), V, D, 1, hip.F32, st), "st5_norm_rows_bwd")
+            _grad_done(emb_param)
+        return dx, None, None, None, None, None
+
+
 class SumSqFunction(torch.autograd.Function):
     """mean(x^2) as an fp32 scalar (features_pen, speech_encoder_prenet.py:172)."""
 
@@ -1397,20 +1576,16 @@ def mean_square(x):
 def _conv_w_fwd(w, dtype):
     """[Cout, Cin, k] -> [Cout, k*Cin] compute dtype (cached)."""
     def build():
-        src = w.detach().permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
-        out = torch.empty(src.shape, dtype=dtype, device=w.device)
-        _cast_into(src, out)
-        return out
+        Cout, Cin, k = w.shape   # out[co, j, ci] = w[co, ci, j]
+        return _gather3(w.detach(), torch.empty(Cout, k * Cin, dtype=dtype, device=w.device), (Cout, k, Cin), (Cin * k, 1, k))
     return weight_cache.get(("convw", dtype, id(w)), [w], build)
 
 
 def _conv_w_dgrad_k2(w, dtype):
     """k = 2, stride 2 transposed convolution as ONE NT GEMM: B[j = jj*Cin + ci][k = co] = W[co, ci, jj], K-major ([2*Cin, Cout])."""
     def build():
-        src = w.detach().permute(2, 1, 0).reshape(-1, w.shape[0]).contiguous()   # [k*Cin, Cout]
-        out = torch.empty(src.shape, dtype=dtype, device=w.device)
-        _cast_into(src, out)
-        return out
+        Cout, Cin, k = w.shape   # out[j, ci, co] = w[co, ci, j]
+        return _gather3(w.detach(), torch.empty(k * Cin, Cout, dtype=dtype, device=w.device), (k, Cin, Cout), (1, k, Cin * k))
     return weight_cache.get(("convw_d2", dtype, id(w)), [w], build)
 
 
@@ -1418,13 +1593,11 @@ def _conv_w_even_odd_t(w, dtype):
     """K-major (transposed) forms of _conv_w_even_odd for the NT kernels: even rows [Cin, 2*Cout] = [W2 | W0]^T, odd rows
     [Cin, Cout] = W1^T."""
     def build():
+        Cout, Cin, k = w.shape
         wd = w.detach()
-        ev = torch.cat([wd[:, :, 2], wd[:, :, 0]], 0).t().contiguous()   # [Cin, 2*Cout]
-        od = wd[:, :, 1].t().contiguous()                                # [Cin, Cout]
-        e = torch.empty(ev.shape, dtype=dtype, device=w.device)
-        o = torch.empty(od.shape, dtype=dtype, device=w.device)
-        _cast_into(ev, e)
-        _cast_into(od, o)
+        # e[ci, h, co] = w[co, ci, 2 - 2h] (h = 0: tap 2, h = 1: tap 0);  o[ci, co] = w[co, ci, 1]
+        e = _gather3(wd, torch.empty(Cin, 2 * Cout, dtype=dtype, device=w.device), (Cin, 2, Cout), (k, -2, Cin * k), off=2)
+        o = _gather3(wd, torch.empty(Cin, Cout, dtype=dtype, device=w.device), (Cin, 1, Cout), (k, 0, Cin * k), off=1)
         return e, o
     return weight_cache.get(("convw_eo_t", dtype, id(w)), [w], build)
 
@@ -1432,13 +1605,11 @@ def _conv_w_even_odd_t(w, dtype):
 def _conv_w_even_odd(w, dtype):
     """k=3, stride 2 transposed-conv weights: even rows use [W2; W0] ([2*Cout, Cin]), odd rows W1 ([Cout, Cin])."""
     def build():
+        Cout, Cin, k = w.shape
         wd = w.detach()
-        ev = torch.cat([wd[:, :, 2], wd[:, :, 0]], 0).contiguous()
-        od = wd[:, :, 1].contiguous()
-        e = torch.empty(ev.shape, dtype=dtype, device=w.device)
-        o = torch.empty(od.shape, dtype=dtype, device=w.device)
-        _cast_into(ev, e)
-        _cast_into(od, o)
+        # e[h, co, ci] = w[co, ci, 2 - 2h];  o[co, ci] = w[co, ci, 1]
+        e = _gather3(wd, torch.empty(2 * Cout, Cin, dtype=dtype, device=w.device), (2, Cout, Cin), (-2, Cin * k, k), off=2)
+        o = _gather3(wd, torch.empty(Cout, Cin, dtype=dtype, device=w.device), (1, Cout, Cin), (0, Cin * k, k), off=1)
         return e, o
     return weight_cache.get(("convw_eo", dtype, id(w)), [w], build)
 
@@ -1523,8 +1694,7 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
                 noff, nbs = 0, Lin * Cin
                 P = None
             else:
-                nxt = torch.empty(B, Lin + 2, Cin, dtype=dtype, device=dev)
-                nxt[:, 0].zero_(); nxt[:, -1].zero_()
+                nxt = torch.empty(B, Lin + 2, Cin, dtype=dtype, device=dev)   # (halo rows zeroed below, with the uncovered tail)
                 noff, nbs = Cin, (Lin + 2) * Cin
                 P = pres[li - 1]
             flags_d = 0 if last else hip.DACT
@@ -1554,8 +1724,12 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
                          act=act_d, flags=flags_d)
             else:
                 raise NotImplementedError(f"conv feature layer (k={k}, stride={s}) backward")
-            if covered < Lin:  # trailing input rows no output window touches
-                (nxt if last else nxt[:, 1:-1])[:, covered:].zero_()
+            # halo rows + the trailing input rows no output window touches, one launch
+            if last:
+                if covered < Lin:
+                    hip.check(L.st5_zero_time_edges(nxt.data_ptr(), B, Lin, Cin, 0, covered, _dt(dtype), hip.stream()), "st5_zero_time_edges")
+            else:
+                hip.check(L.st5_zero_time_edges(nxt.data_ptr(), B, Lin + 2, Cin, 1, 1 + covered, _dt(dtype), hip.stream()), "st5_zero_time_edges")
             dpre = nxt
         # layer 0: conv(1->C) + GroupNorm + GELU backward (weights only; the waveform needs no gradient)
         C0, k0, s0 = layers[0]
@@ -1822,18 +1996,15 @@ class Conv1dSameFunction(torch.autograd.Function):
             tmpw = torch.empty(Cout, k * Cin, dtype=torch.float32, device=dev)
             hip.gemm(hip.operand(dy, Cout), hip.operand(xp, Cin, rpb=Lx, bstride=(Lx + 2 * p) * Cin), hip.operand(tmpw, k * Cin),
                      Cout, k * Cin, B * Lx, _dt(dtype), flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
-            grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))
+            _gather3(tmpw, grad_buffer(w), (Cout, Cin, k), (k * Cin, 1, Cin), accumulate=True)   # grad[co, ci, j] += tmpw[co, j, ci]
             _grad_done(w)
         dx = None
         if ctx.needs_input_grad[0]:
             dyp = torch.empty(B, Lx + 2 * p, Cout, dtype=dtype, device=dev)
             hip.check(hip.lib().st5_pad_time(dy.data_ptr(), dyp.data_ptr(), B, Lx, Cout, p, p, _dt(dtype), hip.stream()), "st5_pad_time")
 
-            def build():
-                src = w.detach().flip(-1).permute(1, 2, 0).reshape(Cin, k * Cout).contiguous()  # [ci][jj][co]
-                out = torch.empty(src.shape, dtype=dtype, device=dev)
-                _cast_into(src, out)
-                return out
+            def build():   # out[ci, jj, co] = w[co, ci, k - 1 - jj]
+                return _gather3(w.detach(), torch.empty(Cin, k * Cout, dtype=dtype, device=dev), (Cin, k, Cout), (k, -1, Cin * k), off=k - 1)
             Wd = weight_cache.get(("convw_d", dtype, id(w)), [w], build)
             dx = torch.empty(B, Lx, Cin, dtype=dtype, device=dev)
             hip.gemm(hip.operand(dyp, Cout, rpb=Lx, bstride=(Lx + 2 * p) * Cout), hip.operand(Wd, k * Cout), hip.operand(dx, Cin),
@@ -1938,14 +2109,12 @@ class PostnetFunction(torch.autograd.Function):
                 hip.gemm(hip.operand(dxp, Cout, off=pad * Cout, rpb=Lx, bstride=(Lx + 2 * pad) * Cout),
                          hip.operand(xp, Cin, rpb=Lx, bstride=(Lx + 2 * pad) * Cin), hip.operand(tmpw, k * Cin),
                          Cout, k * Cin, B * Lx, _dt(dtype), flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
-                grad_buffer(w).add_(tmpw.view(Cout, k, Cin).permute(0, 2, 1))   # (glue: layout permute of a <= 1.3 MB tensor)
+                _gather3(tmpw, grad_buffer(w), (Cout, Cin, k), (k * Cin, 1, Cin), accumulate=True)   # grad[co, ci, j] += tmpw[co, j, ci]
                 _grad_done(w)
             if i > 0 or ctx.needs_input_grad[0]:
-                def build(w=w, Cin=Cin, Cout=Cout, k=k):
-                    src = w.detach().flip(-1).permute(1, 2, 0).reshape(Cin, k * Cout).contiguous()  # [ci][jj][co]
-                    out = torch.empty(src.shape, dtype=dtype, device=dev)
-                    _cast_into(src, out)
-                    return out
+                def build(w=w, Cin=Cin, Cout=Cout, k=k):   # out[ci, jj, co] = w[co, ci, k - 1 - jj]
+                    return _gather3(w.detach(), torch.empty(Cin, k * Cout, dtype=dtype, device=dev), (Cin, k, Cout), (k, -1, Cin * k),
+                                    off=k - 1)
                 Wd = weight_cache.get(("convw_d", dtype, id(w)), [w], build)
                 din = torch.empty(B * Lx, Cin, dtype=torch.float32, device=dev)
                 hip.gemm(hip.operand(dxp, Cout, rpb=Lx, bstride=(Lx + 2 * pad) * Cout), hip.operand(Wd, k * Cout), hip.operand(din, Cin),

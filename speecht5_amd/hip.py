@@ -113,6 +113,25 @@ _SIGS = {
                               c_int32, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "st5_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                   c_int32, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "st5_tacotron_loss_ws_bytes": (c_int64, []),
+    "st5_tacotron_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32,
+                                      c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "st5_tacotron_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32,
+                                      c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "st5_embed_rows_bwd_det_w": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_int32, c_int32, c_int, c_void_p]),
+    "st5_vq_ws_bytes": (c_int64, []),
+    "st5_vq_vpad": (c_int32, []),
+    "st5_vq_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    "st5_vq_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p,
+                           c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    "st5_norm_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
+    "st5_norm_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),
+    "st5_canon_rows": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "st5_nce_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "st5_nce_logits_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "st5_gather3": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64, c_int32, c_int, c_void_p]),
+    "st5_zero_time_edges": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "st5_ctc_initial_state": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "st5_ctc_prefix_score": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32,
                                      c_void_p, c_void_p, c_void_p]),

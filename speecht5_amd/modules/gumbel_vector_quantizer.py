@@ -1,12 +1,10 @@
 """GumbelVectorQuantizer (fairseq/modules/gumbel_vector_quantizer.py; used at speecht5.py:95-107,858-882).
 
-The d -> groups*num_vars projection runs on the HIP GEMM.  The Gumbel-softmax sampling, hard one-hot,
-perplexities and the code-book product ([B*T, 200] x [200, 384]) are fp32 torch ops: they are
-RNG-dependent bookkeeping on ~0.1 % of the step and are listed in DESIGN.md as not yet
-ported to HIP."""
+The d -> groups*num_vars projection runs on the HIP GEMM; sampling, hard one-hot selection, code-book lookup, both
+perplexities and (optionally) the time-wise mix with the encoder states are csrc/vq.hip (functional.GumbelVQFunction);
+only the noise draw itself stays a torch RNG call so that its stream matches F.gumbel_softmax."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import functional as Fn
 
@@ -36,32 +34,30 @@ class GumbelVectorQuantizer(nn.Module):
     def set_num_updates(self, num_updates):
         self.curr_temp = max(self.max_temp * self.temp_decay ** num_updates, self.min_temp)
 
-    def sample(self, logits):
-        """Training-time hard Gumbel-softmax (straight-through); overridable for parity tests."""
+    def gumbel_noise(self, logits):
+        """Gumbel(0, 1) noise for the training-time sampling, drawn exactly as F.gumbel_softmax draws it (the parity tests
+        replace this hook with the noise recorded from the reference run)."""
+        return -torch.empty_like(logits).exponential_().log()
+
+    def forward(self, x, produce_targets=False, mix_w=None):
+        """x [B, T, C].  mix_w (optional, [T] fp32 of 0/1): result["x"] is then the time-wise mix w * codes + (1 - w) * x of
+        speecht5.py:870-877 instead of the codes alone (same kernel, csrc/vq.hip)."""
+        result = {"num_vars": self.num_vars * self.groups}
+        bsz, tsz, fsz = x.shape
+        G, V = self.groups, self.num_vars
+        xc = Fn.as_compute(x).reshape(-1, fsz)
+        logits = Fn.as_float(Fn.linear(xc, self.weight_proj.weight, self.weight_proj.bias))      # [B*T, G*V] fp32
         tau = self.curr_temp
         if Fn.static_shapes():   # the temperature decays with the update count: a replayed step reads it from device memory
             tau = Fn.stage_host(lambda: torch.tensor([float(self.curr_temp)], dtype=torch.float32), logits.device)
-        return F.gumbel_softmax(logits.float(), tau=tau, hard=True).type_as(logits)
-
-    def forward(self, x, produce_targets=False):
-        result = {"num_vars": self.num_vars * self.groups}
-        bsz, tsz, fsz = x.shape
-        logits = Fn.as_float(Fn.linear(Fn.as_compute(x).reshape(-1, fsz), self.weight_proj.weight, self.weight_proj.bias))
-        logits = logits.reshape(bsz * tsz * self.groups, -1)
-        _, k = logits.max(-1)
-        hard_x = logits.new_zeros(*logits.shape).scatter_(-1, k.view(-1, 1), 1.0).view(bsz * tsz, self.groups, -1)
-        hard_probs = torch.mean(hard_x.float(), dim=0)
-        result["code_perplexity"] = torch.exp(-torch.sum(hard_probs * torch.log(hard_probs + 1e-7), dim=-1)).sum()
-        avg_probs = torch.softmax(logits.view(bsz * tsz, self.groups, -1).float(), dim=-1).mean(dim=0)
-        result["prob_perplexity"] = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-7), dim=-1)).sum()
+        gum = self.gumbel_noise(logits).view_as(logits) if self.training else None
+        vars_c = Fn.as_compute(self.vars).detach().view(G * V, -1)
+        out, code_pp, prob_pp, rows = Fn.GumbelVQFunction.apply(logits, self.vars, vars_c, xc if mix_w is not None else None, gum, mix_w,
+                                                                tau, self.training, G, V, tsz, xc.dtype)
+        result["code_perplexity"] = code_pp
+        result["prob_perplexity"] = prob_pp
         result["temp"] = self.curr_temp
-        sel = self.sample(logits) if self.training else hard_x
-        sel = sel.view(bsz * tsz, -1)
         if produce_targets:
-            result["targets"] = sel.view(bsz * tsz * self.groups, -1).argmax(dim=-1).view(bsz, tsz, self.groups).detach()
-        # sum_v onehot[b,g,v] * vars[g,v,:]  ==  per-group matmul; the reference materialises the [B*T, G*V, D/G]
-        # product (1.2 GB at cfg 2) before summing -- same values, 200x less traffic
-        q = torch.einsum("bgv,gvd->bgd", sel.view(bsz * tsz, self.groups, self.num_vars),
-                         self.vars.view(self.groups, self.num_vars, -1))
-        result["x"] = q.reshape(bsz, tsz, -1)
+            result["targets"] = (rows.long() - torch.arange(G, device=rows.device) * V).view(bsz, tsz, G)
+        result["x"] = out.view(bsz, tsz, -1)
         return result

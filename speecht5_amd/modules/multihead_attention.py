@@ -28,6 +28,14 @@ class RelPosKeys:
         return self._t
 
 
+def _mask_bytes(mask):
+    """Key-padding mask as the uint8 [B, S] the kernels read: a bool tensor is reinterpreted in place (same 0/1 bytes), no
+    conversion kernel per attention call."""
+    if mask.dtype == torch.bool and mask.is_contiguous():
+        return mask.view(torch.uint8)
+    return mask.to(torch.uint8).contiguous()
+
+
 def _is_causal_mask(attn_mask):
     return attn_mask is not None
 
@@ -74,7 +82,7 @@ class MultiheadAttention(nn.Module, IncrementalState):
         p = self.dropout_p if self.training else 0.0
         kpm = None
         if key_padding_mask is not None:
-            kpm = key_padding_mask.to(torch.uint8).contiguous()
+            kpm = _mask_bytes(key_padding_mask)
         probs = None
         # post-LN blocks add the block input itself as the residual: relay its gradient into the first projection's dX GEMM
         relay = Fn.GradRelay() if (residual is x and x.requires_grad and torch.is_grad_enabled()) else None
@@ -102,7 +110,7 @@ class MultiheadAttention(nn.Module, IncrementalState):
         ([B, t, 2C], projected) and attends over all t cached keys; cross-attention projects the encoder rows once
         (cache["kvp"], [B*S, 2C]) and re-uses them every step.  Returns (out rows [B, C], probs [B,H,1,S] or None)."""
         H, hd, C = self.num_heads, self.head_dim, self.embed_dim
-        kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
+        kpm = _mask_bytes(key_padding_mask) if key_padding_mask is not None else None
         if kv is None:
             qkv = Fn.linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight],
                             [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias])          # [B, 3C]

@@ -22,18 +22,12 @@ class SpeechEncoderPostnet(nn.Module):
         self.untie_final_proj = args.untie_final_proj
         self.final_proj = nn.Linear(args.encoder_embed_dim, final_dim * len(dictionaries) if self.untie_final_proj else final_dim)
 
-    def compute_nce(self, x, pos, negs_emb, target):
-        """logits[s] = [cos(x_s, pos_s), cos(x_s, e_0), ..., cos(x_s, e_{V-1})] / temp with -inf where e_c == pos_s.
-        The projection x comes from the HIP GEMM; the cosine similarity against the 504 x 256 code book and
-        the [S, 505] assembly are small fp32 torch ops (criterion-side arithmetic)."""
-        xf = torch.nn.functional.normalize(x.float(), dim=-1, eps=1e-8)
-        ef = torch.nn.functional.normalize(negs_emb.float(), dim=-1, eps=1e-8)
-        sim = xf @ ef.t()                                   # [S, V]
-        pos_sim = sim.gather(1, target.long().unsqueeze(1))  # [S, 1]
-        # neg c duplicates the positive iff code-book rows c and target are identical: [V,V] row-equality table
-        same = (negs_emb.unsqueeze(0) == negs_emb.unsqueeze(1)).all(-1)
-        sim = sim.masked_fill(same[target.long()], float("-inf"))
-        return torch.cat([pos_sim, sim], dim=1) / self.logit_temp
+    def compute_nce(self, x, i, target):
+        """logits[s] = [cos(x_s, e_{t_s}), cos(x_s, e_0), ..., cos(x_s, e_{V-1})] / temp with -inf where e_c == e_{t_s}, for
+        target list i (code-book rows [row0, row0 + V) of label_embs_concat): functional.NCELogitsFunction -- row
+        normalisations, the [S, V] cosine GEMM and the logit assembly as HIP kernels, fp32 like the reference."""
+        row0 = sum(self.num_classes[:i])
+        return Fn.NCELogitsFunction.apply(x, self.label_embs_concat, row0, self.num_classes[i], target, self.logit_temp)
 
     def forward(self, x, padding_mask, mask_indices, target_list):
         """x [B,T,C] (compute dtype).  Boolean-index gathers are torch glue, the projection is the HIP GEMM."""
@@ -56,7 +50,7 @@ class SpeechEncoderPostnet(nn.Module):
             for i, (p, t) in enumerate(zip(projs, target_list)):
                 tg = t.reshape(-1).index_select(0, sel) if sel_host is not None else t[sel]
                 emb = label_embs_list[i]
-                outs.append(self.compute_nce(Fn.as_float(p.contiguous()), emb[tg.long()], emb, tg))
+                outs.append(self.compute_nce(p.contiguous(), i, tg))
             return outs
 
         mh = ph = None
@@ -84,7 +78,7 @@ class SpeechEncoderPostnet(nn.Module):
         for i, (p, t) in enumerate(zip(projs, target_list)):
             tg = t.reshape(-1)
             emb = label_embs_list[i]
-            logits.append(self.compute_nce(Fn.as_float(p.contiguous()), emb[tg.long()], emb, tg))
+            logits.append(self.compute_nce(p.contiguous(), i, tg))
         valid = ~padding_mask
         out = {"padding_mask": padding_mask,
                "logit_m_list": [None] * len(target_list) if self.skip_masked else logits,

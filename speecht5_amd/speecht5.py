@@ -244,18 +244,17 @@ class T5TransformerModel(FairseqEncoderDecoderModel):
 
         if self.use_codebook:
             enc_btc = encoder_output["encoder_out"][0].transpose(0, 1)
-            q = self.quantizer(enc_btc)
-            tlen = q["x"].size(1)
+            tlen = enc_btc.size(1)
             n_mix = int(tlen * self.codebook_prob)
 
             def draw_mix():   # built on the host: no device-side index_put / sync
                 w = torch.zeros(tlen)
                 w[torch.randperm(tlen)[:n_mix]] = 1.0
                 return w
-            q_w = Fn.stage_host(draw_mix, q["x"].device)
-            # time-wise mix of quantised codes and encoder states (:870-877); fp32 torch arithmetic on [B,T,d]
-            mixed = q_w.view(-1, 1) * q["x"] + (-q_w + 1).view(-1, 1) * Fn.as_float(enc_btc.contiguous())
-            encoder_output["encoder_out"][0] = mixed.transpose(0, 1)
+            q_w = Fn.stage_host(draw_mix, enc_btc.device)
+            # quantised codes, mixed time-wise with the encoder states (:870-877) inside the quantizer's kernel
+            q = self.quantizer(enc_btc.contiguous(), mix_w=q_w)
+            encoder_output["encoder_out"][0] = q["x"].transpose(0, 1)
             tgt = hubert_results if output_type == "speech" else codebook_out
             tgt["prob_perplexity"] = q["prob_perplexity"]
             tgt["code_perplexity"] = q["code_perplexity"]

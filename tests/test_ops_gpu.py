@@ -645,3 +645,31 @@ def test_conv_weight_gradient_and_data_gradient_with_row_split_operands(cuda, k,
     F.gelu(Pr).backward(xr.grad)                         # gelu'(P) * dX
     close(nxt[:, 1:-1][:, :2 * Lo], Pr.grad[:, :2 * Lo], dtype, what="conv data gradient * gelu' (row-split epilogue)")
     assert float(nxt[:, 0].abs().max()) == 0 and float(nxt[:, -1].abs().max()) == 0   # halo rows untouched
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,vocab,cols", [(8192, 83, 768), (5000, 10000, 96), (37, 5, 8)])
+def test_deterministic_row_scatter(cuda, dtype, rows, vocab, cols):
+    """st5_embed_rows_bwd_det(_w): dtable[tok[r]] += scale * w[r] * dy[r] without atomics -- equals index_add to fp32 round-off,
+    is bit-identical from run to run, leaves rows of out-of-range ids alone, honours the per-row weight."""
+    torch.manual_seed(3)
+    tok = torch.randint(0, vocab, (rows,), dtype=torch.int32)
+    tok[::7] = 1                                   # one frequent id (a long run for a single block)
+    tok[5] = -1
+    dy = torch.randn(rows, cols)
+    T, div = 11, 2
+    w = torch.rand(T)
+    L = hip.lib()
+    base = torch.randn(vocab, cols)
+    outs = []
+    dy_d, tok_d, w_d = dev(dy, dtype, cuda), tok.to(cuda), w.to(cuda)
+    for _ in range(2):
+        table = base.clone().to(cuda)
+        hip.check(L.st5_embed_rows_bwd_det_w(dy_d.data_ptr(), tok_d.data_ptr(), table.data_ptr(), rows, cols, vocab, 0.5, w_d.data_ptr(), div, T,
+                                             hip.dt(dtype), hip.stream()), "st5_embed_rows_bwd_det_w")
+        outs.append(table.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ok = tok >= 0
+    rw = w[(torch.arange(rows) // div) % T]
+    ref = base.clone().index_add_(0, tok[ok].long(), 0.5 * rw[ok, None] * rt(dy, dtype)[ok])
+    close(outs[0], ref, torch.float32, what="row scatter")
