@@ -235,7 +235,7 @@ int st5_embed_rows(const float* table, const int32_t* tok, const float* pos, con
 int st5_embed_rows_bwd(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, float scale,
                        int dtype, void* stream);
 /* The same, bit-reproducible (no atomics): the rows are rank-sorted by (table row, position) and every table row is summed in
- * position order by one block.  Tokens outside [0, vocab) contribute nothing.  The sort is quadratic in `rows` (one micro-batch
+ * position order by one block.  Tokens outside [0, vocab) contribute nothing; cols % 4 == 0.  The sort is quadratic in `rows` (one micro-batch
  * of tokens / frames: ~10 us for 8k rows); rows <= 2^22.  Uses one internal workspace: calls must be stream-ordered. */
 int st5_embed_rows_bwd_det(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, int32_t vocab, float scale,
                            int dtype, void* stream);

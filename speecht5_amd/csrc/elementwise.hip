@@ -145,7 +145,15 @@ __global__ void masked_fill_final_kernel(const float* __restrict__ part, float* 
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   float s = 0.f;
-  for (int y = 0; y < ny; ++y) s += part[(long long)y * cols + c];
+  int y = 0;
+  for (; y + 8 <= ny; y += 8) {   // 8 independent loads in flight, summed in order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long long)(y + u) * cols + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; y < ny; ++y) s += part[(long long)y * cols + c];
   dv[c] += s;
 }
 template <typename T>
@@ -212,10 +220,21 @@ __global__ void embed_rows_bwd_kernel(const T* __restrict__ dy, const int32_t* _
 // before its own -- N^2 / 64 wave-steps on ids staged through LDS, ~10 us for 8k rows; (2) segmented sums over the sorted
 // order: the block in whose range a run of equal ids STARTS adds the whole run in position order and is the table row's only
 // writer.
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&v)[4]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = a[i];
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+  const uint2 a = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+}
 constexpr int RS_CHUNK = 2048;
 // block = 64 rows x 4 parts: part p counts inside its quarter of every staged chunk, the four counts are added at the end
 __global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t* __restrict__ tok, int32_t* __restrict__ order, int n) {
-  __shared__ int32_t ids[RS_CHUNK];
+  __shared__ __attribute__((aligned(16))) int32_t ids[RS_CHUNK];
   __shared__ int cnt[4][64];
   const int tl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + tl;
@@ -224,13 +243,18 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t* __restric
   for (int base = 0; base < n; base += RS_CHUNK) {
     const int m = n - base < RS_CHUNK ? n - base : RS_CHUNK;
     __syncthreads();
-    for (int i = threadIdx.x; i < m; i += 256) ids[i] = tok[base + i];
+    for (int i = threadIdx.x; i < RS_CHUNK; i += 256) ids[i] = i < m ? tok[base + i] : 0x7fffffff;
     __syncthreads();
-    const int lo = part * (RS_CHUNK / 4), hi = lo + RS_CHUNK / 4 < m ? lo + RS_CHUNK / 4 : m;
+    // (slots past m hold INT_MAX and never count, so whole pieces are walked with 16-byte LDS reads: 4 ids per round trip)
+    const int lo = part * (RS_CHUNK / 4), hi = lo + RS_CHUNK / 4;
+    if (lo >= m) continue;
+    const int4* v4 = reinterpret_cast<const int4*>(ids + lo);
     if (base + hi <= t) {                        // the whole piece lies before t: ties count
-      for (int i = lo; i < hi; ++i) rank += ids[i] <= my;
+#pragma unroll 2
+      for (int i = 0; i < RS_CHUNK / 16; ++i) { const int4 v = v4[i]; rank += (v.x <= my) + (v.y <= my) + (v.z <= my) + (v.w <= my); }
     } else if (base + lo > t) {                  // the whole piece lies after t: ties do not count
-      for (int i = lo; i < hi; ++i) rank += ids[i] < my;
+#pragma unroll 2
+      for (int i = 0; i < RS_CHUNK / 16; ++i) { const int4 v = v4[i]; rank += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my); }
     } else {
       for (int i = lo; i < hi; ++i) rank += ids[i] < my || (ids[i] == my && base + i < t);
     }
@@ -240,10 +264,11 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t* __restric
   if (part == 0 && t < n) order[cnt[0][tl] + cnt[1][tl] + cnt[2][tl] + cnt[3][tl]] = t;
 }
 constexpr int SEG_R = 16;  // sorted entries per block (run STARTS inside the range belong to the block)
-// grid (ceil(rows / SEG_R), ceil(cols / 64)); lane = one table column of the block's 64-column slab, wave w adds the run's
-// entries w, w + 4, w + 8, ... (a FIXED interleaving, so the result does not depend on timing), 16 independent loads in flight;
-// the four wave sums are combined in wave order.  A run is walked in chunks of 256 sorted entries whose row indices the block
-// loads together (a frequent token is a run of thousands of rows for one block: latency, not bandwidth, is what it costs).
+// grid (ceil(rows / SEG_R), ceil(cols / 256)); lane = four consecutive table columns of the block's 256-column slab (one 8- or
+// 16-byte load per row), wave w adds the run's entries w, w + 4, w + 8, ... (a FIXED interleaving, so the result does not
+// depend on timing), 8 independent row loads in flight; the four wave sums are combined in wave order.  A run is walked in
+// chunks of 256 sorted entries whose row indices the block loads together (a frequent token is a run of thousands of rows for
+// one block: latency, not bandwidth, is what it costs).  cols % 4 == 0.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_rows_bwd_det_kernel(const T* __restrict__ dy, const int32_t* __restrict__ tok,
                                                                  const int32_t* __restrict__ order, float* __restrict__ dtable,
@@ -251,11 +276,11 @@ __global__ __launch_bounds__(256) void embed_rows_bwd_det_kernel(const T* __rest
                                                                  const float* __restrict__ rw, int rw_div, int rw_mod) {
   __shared__ int sh_r[256];
   __shared__ float sh_w[256];
-  __shared__ float sh_p[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = blockIdx.y * 64 + lane;
-  const bool live = c < cols;
+  __shared__ float sh_p[4][64][4];
   __shared__ int sh_id[SEG_R + 1];   // ids of sorted entries s0 - 1 .. s0 + SEG_R - 1 (fetched together: two dependent loads, not 2 x SEG_R)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = (blockIdx.y * 64 + lane) * 4;
+  const bool live = c < cols;
   const long long s0 = (long long)blockIdx.x * SEG_R;
   const long long s1 = s0 + SEG_R < rows ? s0 + SEG_R : rows;
   if (tid <= SEG_R) {
@@ -267,7 +292,7 @@ __global__ __launch_bounds__(256) void embed_rows_bwd_det_kernel(const T* __rest
     const int v = sh_id[s - s0 + 1];
     if (s > 0 && sh_id[s - s0] == v) continue;          // not a run start (block-uniform)
     if (v < 0 || v >= vocab) continue;
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (long long base = s;; base += 256) {
       const long long i = base + tid;
       int r = -1;
@@ -278,26 +303,35 @@ __global__ __launch_bounds__(256) void embed_rows_bwd_det_kernel(const T* __rest
       __syncthreads();
       // the run's entries are a prefix of the chunk (sorted order); this wave takes entries wave, wave + 4, ...
 #pragma unroll 1
-      for (int k0 = 0; k0 < 256; k0 += 64) {
+      for (int k0 = 0; k0 < 256; k0 += 32) {
         if (sh_r[k0] < 0) break;
-        float x[16];
+        float x[8][4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int k = k0 + u * 4 + wave;
-          const int rr = sh_r[k];
-          x[u] = (rr >= 0 && live) ? sh_w[k] * Elem<T>::to_f(dy[(long long)rr * cols + c]) : 0.f;
+        for (int u = 0; u < 8; ++u) {
+          const int rr = sh_r[k0 + u * 4 + wave];
+          if (rr >= 0 && live) ld4<T>(dy + (long long)rr * cols + c, x[u]);
+          else { x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f; }
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc += x[u];   // (entries past the run's end add exact zeros)
+        for (int u = 0; u < 8; ++u) {   // (entries past the run's end add exact zeros)
+          const float w = sh_w[k0 + u * 4 + wave];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(w, x[u][e], acc[e]);
+        }
       }
       if (sh_r[255] < 0) break;                    // the run ended inside this chunk (block-uniform)
     }
     __syncthreads();
-    sh_p[wave][lane] = acc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sh_p[wave][lane][e] = acc[e];
     __syncthreads();
     if (wave == 0 && live) {
-      const float t = ((sh_p[0][lane] + sh_p[1][lane]) + sh_p[2][lane]) + sh_p[3][lane];
-      if (t != 0.f) dtable[(long long)v * cols + c] += scale * t;
+      float* dst = dtable + (long long)v * cols + c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = ((sh_p[0][lane][e] + sh_p[1][lane][e]) + sh_p[2][lane][e]) + sh_p[3][lane][e];
+        if (t != 0.f) dst[e] += scale * t;
+      }
     }
   }
 }
@@ -646,7 +680,7 @@ int32_t* g_order = nullptr;   // sorted-order workspace of the deterministic row
 long long g_order_n = 0;
 extern "C" int st5_embed_rows_bwd_det_w(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, int32_t vocab,
                                         float scale, const float* row_w, int32_t rw_div, int32_t rw_mod, int dtype, void* stream) {
-  if (!dy || !tok || !dtable || rows < 0 || cols <= 0 || vocab <= 0 || (row_w && (rw_div <= 0 || rw_mod <= 0))) return ST5_ERR_ARG;
+  if (!dy || !tok || !dtable || rows < 0 || cols <= 0 || cols % 4 || vocab <= 0 || (row_w && (rw_div <= 0 || rw_mod <= 0))) return ST5_ERR_ARG;
   if (rows == 0) return ST5_OK;
   if (rows > (1ll << 22)) return ST5_ERR_ARG;   // the rank sort is quadratic: meant for token / frame counts of one micro-batch
   hipStream_t s = (hipStream_t)stream;
@@ -658,7 +692,7 @@ extern "C" int st5_embed_rows_bwd_det_w(const void* dy, const int32_t* tok, floa
     g_order_n = want;
   }
   hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, tok, g_order, (int)rows);
-  dim3 grid((unsigned)((rows + SEG_R - 1) / SEG_R), (unsigned)((cols + 63) / 64));
+  dim3 grid((unsigned)((rows + SEG_R - 1) / SEG_R), (unsigned)((cols + 255) / 256));
   DISPATCH(dtype, hipLaunchKernelGGL(embed_rows_bwd_det_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, tok, g_order, dtable, (long long)rows, cols, vocab, scale, row_w, rw_div, rw_mod),
            hipLaunchKernelGGL(embed_rows_bwd_det_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, tok, g_order, dtable, (long long)rows, cols, vocab, scale, row_w, rw_div, rw_mod));
   HIP_CHECK_LAUNCH();

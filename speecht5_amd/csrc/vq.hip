@@ -95,7 +95,15 @@ __global__ __launch_bounds__(256) void vq_final_kernel(const float* __restrict__
   float code_pp = 0.f, prob_pp = 0.f;
   for (int g = 0; g < G; ++g) {
     float a = 0.f, h = 0.f;
-    for (int k = k0; k < k1; ++k) {   // fixed order
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {     // fixed order, 16 independent loads in flight
+      float pa[8], ph[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const float* pw = part + (long long)((k + u) * G + g) * 2 * VP; pa[u] = pw[v]; ph[u] = pw[VP + v]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += pa[u]; h += ph[u]; }
+    }
+    for (; k < k1; ++k) {
       const float* pw = part + (long long)(k * G + g) * 2 * VP;
       a += pw[v]; h += pw[VP + v];
     }

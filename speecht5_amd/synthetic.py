@@ -46,6 +46,24 @@ def text_pretrain_sample(B=16, T=512, vocab=83, mask_idx=None, device="cpu", see
     return to_device(s, device)
 
 
+def t2s_sample(B=32, T_text=100, L=600, vocab=83, spk_dim=512, r=2, device="cpu", seed=1339):
+    """TTS fine-tuning batch (SURVEY.md 8d cfg 3; collater schema of data/text_to_speech_dataset.py:262-281): B texts of
+    T_text tokens, B log-mel targets of L frames (80 bins), reduction factor r."""
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(4, vocab - 2, (B, T_text), generator=g)
+    src[:, -1] = 2
+    mel = torch.randn(B, L, 80, generator=g) * 0.5 - 1
+    prev = torch.cat([mel.new_zeros(B, 1, 80), mel[:, r - 1::r][:, :-1]], 1)[:, : L // r]
+    labels = torch.zeros(B, L)
+    labels[:, -1] = 1.0
+    s = dict(net_input=dict(src_tokens=src, src_lengths=torch.full((B,), T_text, dtype=torch.long), prev_output_tokens=prev,
+                            tgt_lengths=torch.full((B,), prev.shape[1], dtype=torch.long), spkembs=torch.randn(B, spk_dim, generator=g),
+                            task_name="t2s"),
+             labels=labels, dec_target=mel, dec_target_lengths=torch.full((B,), L, dtype=torch.long),
+             src_lengths=torch.full((B,), T_text, dtype=torch.long), target=src, ntokens=int(B * L), id=torch.arange(B), task_name="t2s")
+    return to_device(s, device)
+
+
 def to_device(obj, device):
     if isinstance(obj, torch.Tensor):
         return obj.to(device)
