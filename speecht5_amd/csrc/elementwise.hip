@@ -233,7 +233,8 @@ template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (
 }
 constexpr int RS_CHUNK = 2048;
 // block = 64 rows x 4 parts: part p counts inside its quarter of every staged chunk, the four counts are added at the end
-__global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t* __restrict__ tok, int32_t* __restrict__ order, int n) {
+__global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t* __restrict__ tok, int32_t* __restrict__ order,
+                                                        int32_t* __restrict__ sid, int n) {
   __shared__ __attribute__((aligned(16))) int32_t ids[RS_CHUNK];
   __shared__ int cnt[4][64];
   const int tl = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -261,79 +262,103 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t* __restric
   }
   cnt[part][tl] = rank;
   __syncthreads();
-  if (part == 0 && t < n) order[cnt[0][tl] + cnt[1][tl] + cnt[2][tl] + cnt[3][tl]] = t;
+  if (part == 0 && t < n) { const int r = cnt[0][tl] + cnt[1][tl] + cnt[2][tl] + cnt[3][tl]; order[r] = t; sid[r] = my; }
 }
-constexpr int SEG_R = 16;  // sorted entries per block (run STARTS inside the range belong to the block)
-// grid (ceil(rows / SEG_R), ceil(cols / 256)); lane = four consecutive table columns of the block's 256-column slab (one 8- or
-// 16-byte load per row), wave w adds the run's entries w, w + 4, w + 8, ... (a FIXED interleaving, so the result does not
-// depend on timing), 8 independent row loads in flight; the four wave sums are combined in wave order.  A run is walked in
-// chunks of 256 sorted entries whose row indices the block loads together (a frequent token is a run of thousands of rows for
-// one block: latency, not bandwidth, is what it costs).  cols % 4 == 0.
+// Segmented sums over the sorted order, balanced for runs of any length.  The sorted entries are cut into chunks of SEG; block
+// (chunk, 256-column slab) sums every PIECE (maximal range of equal ids inside the chunk) -- wave w takes pieces w, w + 4, ...,
+// lane = four consecutive table columns, 8 row loads in flight, rows of a piece added in sorted (= position) order.
+//   * a piece that is a whole run goes straight into the table (the run's only writer);
+//   * a piece continuing the previous chunk's last run is stored in head[chunk], a piece continuing into the next chunk in
+//     tail[chunk]; the combine kernel walks every multi-chunk run once, tail -> head -> head ..., in chunk order.
+// No atomics, no timing dependence; a 10 000-row run (a frequent token, a dominant code-book entry) costs its blocks 32 rows each.
+constexpr int SEG = 32;
 template <typename T>
-__global__ __launch_bounds__(256) void embed_rows_bwd_det_kernel(const T* __restrict__ dy, const int32_t* __restrict__ tok,
-                                                                 const int32_t* __restrict__ order, float* __restrict__ dtable,
-                                                                 long long rows, int cols, int vocab, float scale,
-                                                                 const float* __restrict__ rw, int rw_div, int rw_mod) {
-  __shared__ int sh_r[256];
-  __shared__ float sh_w[256];
-  __shared__ float sh_p[4][64][4];
-  __shared__ int sh_id[SEG_R + 1];   // ids of sorted entries s0 - 1 .. s0 + SEG_R - 1 (fetched together: two dependent loads, not 2 x SEG_R)
+__global__ __launch_bounds__(256) void seg_pieces_kernel(const T* __restrict__ dy, const int32_t* __restrict__ order,
+                                                         const int32_t* __restrict__ sid, float* __restrict__ dtable,
+                                                         float* __restrict__ head, float* __restrict__ tail, long long rows, int cols,
+                                                         int vocab, float scale, const float* __restrict__ rw, int rw_div, int rw_mod) {
+  __shared__ int sh_id[SEG + 2];    // ids of sorted entries s0 - 1 .. s0 + SEG
+  __shared__ int sh_r[SEG];
+  __shared__ float sh_w[SEG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = (blockIdx.y * 64 + lane) * 4;
   const bool live = c < cols;
-  const long long s0 = (long long)blockIdx.x * SEG_R;
-  const long long s1 = s0 + SEG_R < rows ? s0 + SEG_R : rows;
-  if (tid <= SEG_R) {
+  const long long s0 = (long long)blockIdx.x * SEG;
+  const int n_in = (int)(rows - s0 < SEG ? rows - s0 : SEG);
+  if (tid < SEG + 2) {
     const long long e = s0 - 1 + tid;
-    sh_id[tid] = (e >= 0 && e < rows) ? tok[order[e]] : (int)0x80000000;
+    sh_id[tid] = (e >= 0 && e < rows) ? sid[e] : (int)0x80000000;
+  }
+  if (tid < SEG) {
+    const int r = tid < n_in ? order[s0 + tid] : -1;
+    sh_r[tid] = r;
+    sh_w[tid] = (r >= 0 && rw) ? rw[(r / rw_div) % rw_mod] : 1.f;
   }
   __syncthreads();
-  for (long long s = s0; s < s1; ++s) {
-    const int v = sh_id[s - s0 + 1];
-    if (s > 0 && sh_id[s - s0] == v) continue;          // not a run start (block-uniform)
-    if (v < 0 || v >= vocab) continue;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long base = s;; base += 256) {
-      const long long i = base + tid;
-      int r = -1;
-      if (i < rows) { const int o = order[i]; if (tok[o] == v) r = o; }
-      __syncthreads();
-      sh_r[tid] = r;
-      sh_w[tid] = (r >= 0 && rw) ? rw[(r / rw_div) % rw_mod] : 1.f;
-      __syncthreads();
-      // the run's entries are a prefix of the chunk (sorted order); this wave takes entries wave, wave + 4, ...
-#pragma unroll 1
-      for (int k0 = 0; k0 < 256; k0 += 32) {
-        if (sh_r[k0] < 0) break;
+  int piece = 0;
+  for (int a = 0; a < n_in;) {
+    const int v = sh_id[a + 1];
+    int b = a + 1;
+    while (b < n_in && sh_id[b + 1] == v) ++b;
+    if ((piece++ & 3) == wave && v >= 0 && v < vocab) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int k0 = a; k0 < b; k0 += 8) {
         float x[8][4];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int rr = sh_r[k0 + u * 4 + wave];
-          if (rr >= 0 && live) ld4<T>(dy + (long long)rr * cols + c, x[u]);
+          if (k0 + u < b && live) ld4<T>(dy + (long long)sh_r[k0 + u] * cols + c, x[u]);
           else { x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f; }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {   // (entries past the run's end add exact zeros)
-          const float w = sh_w[k0 + u * 4 + wave];
+        for (int u = 0; u < 8; ++u) {
+          const float w = k0 + u < b ? sh_w[k0 + u] : 0.f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[e] = fmaf(w, x[u][e], acc[e]);
         }
       }
-      if (sh_r[255] < 0) break;                    // the run ended inside this chunk (block-uniform)
-    }
-    __syncthreads();
+      if (live) {
+        const bool from_prev = a == 0 && sh_id[0] == v, to_next = b == n_in && sh_id[n_in + 1] == v;
+        float* dst;
+        float k = 1.f;
+        if (from_prev) dst = head + (long long)blockIdx.x * cols + c;
+        else if (to_next) dst = tail + (long long)blockIdx.x * cols + c;
+        else { dst = dtable + (long long)v * cols + c; k = scale; }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sh_p[wave][lane][e] = acc[e];
-    __syncthreads();
-    if (wave == 0 && live) {
-      float* dst = dtable + (long long)v * cols + c;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float t = ((sh_p[0][lane][e] + sh_p[1][lane][e]) + sh_p[2][lane][e]) + sh_p[3][lane][e];
-        if (t != 0.f) dst[e] += scale * t;
+        for (int e = 0; e < 4; ++e) dst[e] = (from_prev || to_next) ? acc[e] : dst[e] + k * acc[e];
       }
     }
+    a = b;
   }
+}
+// one thread per (run that starts in chunk ch and continues past it, column): tail[ch] + head[ch+1] + ... in chunk order
+__global__ __launch_bounds__(256) void seg_combine_kernel(const int32_t* __restrict__ sid, float* __restrict__ dtable,
+                                                          const float* __restrict__ head, const float* __restrict__ tail, long long rows,
+                                                          int cols, int vocab, float scale) {
+  const long long ch = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const long long last = (ch + 1) * SEG - 1;
+  if (last + 1 >= rows || c >= cols) return;            // no next chunk
+  const int v = sid[last];
+  if (sid[last + 1] != v || v < 0 || v >= vocab) return; // the chunk's last run ends here
+  if (sid[ch * SEG] == v && ch > 0 && sid[ch * SEG - 1] == v) return;   // the whole chunk continues an earlier run: not the start
+  float acc = tail[ch * cols + c];
+  const long long nch = (rows + SEG - 1) / SEG;
+  bool more = true;
+  for (long long k = ch + 1; more; k += 8) {            // eight chunks' loads in flight; consumed strictly in chunk order
+    float h[8];
+    bool go[8];                                          // chunk k + u consists of this id only AND continues into the next one
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long kk = k + u, kl = (kk + 1) * SEG - 1;
+      h[u] = kk < nch ? head[kk * cols + c] : 0.f;       // (chunks past the run's end are loaded but never added)
+      go[u] = kk < nch && kl + 1 < rows && sid[kl] == v && sid[kl + 1] == v;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (more) { acc += h[u]; more = go[u]; }
+    }
+  }
+  dtable[(long long)v * cols + c] += scale * acc;
 }
 
 // x[b, t, :] = 0 for t < head or t >= tail_start  (x [B, Tp, C]): the halo / uncovered rows of the convolution-gradient buffers
@@ -676,25 +701,33 @@ extern "C" int st5_embed_rows_bwd(const void* dy, const int32_t* tok, float* dta
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
-int32_t* g_order = nullptr;   // sorted-order workspace of the deterministic row scatter (grow-only)
-long long g_order_n = 0;
+char* g_scatter_ws = nullptr;   // workspace of the deterministic row scatter: order | sorted ids | head | tail (grow-only)
+size_t g_scatter_bytes = 0;
 extern "C" int st5_embed_rows_bwd_det_w(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, int32_t vocab,
                                         float scale, const float* row_w, int32_t rw_div, int32_t rw_mod, int dtype, void* stream) {
   if (!dy || !tok || !dtable || rows < 0 || cols <= 0 || cols % 4 || vocab <= 0 || (row_w && (rw_div <= 0 || rw_mod <= 0))) return ST5_ERR_ARG;
   if (rows == 0) return ST5_OK;
   if (rows > (1ll << 22)) return ST5_ERR_ARG;   // the rank sort is quadratic: meant for token / frame counts of one micro-batch
   hipStream_t s = (hipStream_t)stream;
-  if (rows > g_order_n) {   // (first use / growth: outside stream capture, like every other workspace of this library)
-    if (g_order) (void)hipFree(g_order);
-    g_order = nullptr;
-    const long long want = rows < 65536 ? 65536 : rows;
-    if (hipMalloc(&g_order, want * sizeof(int32_t)) != hipSuccess) { g_order_n = 0; return ST5_ERR_LAUNCH; }
-    g_order_n = want;
+  const long long nch = (rows + SEG - 1) / SEG;
+  const size_t ints = (((size_t)rows * 2 * sizeof(int32_t)) + 255) & ~(size_t)255;
+  const size_t need = ints + (size_t)2 * nch * cols * sizeof(float);
+  if (need > g_scatter_bytes) {   // (first use / growth: outside stream capture, like every other workspace of this library)
+    if (g_scatter_ws) (void)hipFree(g_scatter_ws);
+    g_scatter_ws = nullptr; g_scatter_bytes = 0;
+    const size_t want = need < (size_t(8) << 20) ? (size_t(8) << 20) : need;
+    if (hipMalloc(&g_scatter_ws, want) != hipSuccess) return ST5_ERR_LAUNCH;
+    g_scatter_bytes = want;
   }
-  hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, tok, g_order, (int)rows);
-  dim3 grid((unsigned)((rows + SEG_R - 1) / SEG_R), (unsigned)((cols + 255) / 256));
-  DISPATCH(dtype, hipLaunchKernelGGL(embed_rows_bwd_det_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, tok, g_order, dtable, (long long)rows, cols, vocab, scale, row_w, rw_div, rw_mod),
-           hipLaunchKernelGGL(embed_rows_bwd_det_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, tok, g_order, dtable, (long long)rows, cols, vocab, scale, row_w, rw_div, rw_mod));
+  int32_t* order = reinterpret_cast<int32_t*>(g_scatter_ws);
+  int32_t* sid = order + rows;
+  float* head = reinterpret_cast<float*>(g_scatter_ws + ints);
+  float* tail = head + (size_t)nch * cols;
+  hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, tok, order, sid, (int)rows);
+  dim3 grid((unsigned)nch, (unsigned)((cols + 255) / 256));
+  DISPATCH(dtype, hipLaunchKernelGGL(seg_pieces_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, order, sid, dtable, head, tail, (long long)rows, cols, vocab, scale, row_w, rw_div, rw_mod),
+           hipLaunchKernelGGL(seg_pieces_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, order, sid, dtable, head, tail, (long long)rows, cols, vocab, scale, row_w, rw_div, rw_mod));
+  hipLaunchKernelGGL(seg_combine_kernel, grid, dim3(256), 0, s, sid, dtable, head, tail, (long long)rows, cols, vocab, scale);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

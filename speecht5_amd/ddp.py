@@ -254,7 +254,9 @@ def _fusion_ordered_parameters(module):
     pos = {id(p): i for i, p in enumerate(params)}
     groups = []
     for m in module.modules():
-        if isinstance(m, MultiheadAttention):
+        if isinstance(m, _CrossKV):
+            groups += m.fused_groups()
+        elif isinstance(m, MultiheadAttention):
             projs = [m.q_proj, m.k_proj, m.v_proj] if m.self_attention else [m.k_proj, m.v_proj]
             groups.append([q.weight for q in projs])
             if all(q.bias is not None for q in projs):
@@ -274,6 +276,22 @@ def _fusion_ordered_parameters(module):
         if id(p) not in done:
             out.append(p); done.add(id(p))
     return out
+
+
+class _CrossKV(torch.nn.Module):
+    """Ordering / bucket holder (not part of the model tree): the k_proj / v_proj of every decoder layer's cross-attention.
+    The decoder projects them with ONE GEMM (modules/decoder.py), so their weights (and biases) sit next to each other in the
+    flat buffers in stacking order, and their gradients are complete only when the gradient of the encoder output is."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.lins = torch.nn.ModuleList([lin for l in layers for lin in (l.encoder_attn.k_proj, l.encoder_attn.v_proj)])
+
+    def fused_groups(self):
+        g = [[lin.weight for lin in self.lins]]
+        if all(lin.bias is not None for lin in self.lins):
+            g.append([lin.bias for lin in self.lins])
+        return g
 
 
 class BucketGroup:
@@ -309,6 +327,8 @@ def default_buckets(model):
     if dec is not None and hasattr(dec, "layers"):
         groups += [BucketGroup([l]) for l in reversed(list(dec.layers))]
     ehead = [m for m in (getattr(model, n, None) for n in ("hubert_layer", "quantizer")) if m is not None]
+    if dec is not None and hasattr(dec, "layers") and len(dec.layers) > 1 and all(getattr(l, "encoder_attn", None) is not None for l in dec.layers):
+        ehead.append(_CrossKV(dec.layers))   # (listed after the decoder layers: this group owns these projections)
     if ehead and enc is not None:
         groups.append(BucketGroup(ehead, triggers=[(enc, "out")]))
     if enc is not None and hasattr(enc, "layers"):

@@ -1183,21 +1183,43 @@ class SelfAttentionFunction(torch.autograd.Function):
         return dqkv, dpe, None, None
 
 
+class KVShare:
+    """Keys / values of EVERY decoder layer's cross-attention projected by one GEMM (decoder.py: the encoder output is the same
+    for all layers): kv_all [B*S, L*2d], layer l reads columns [l*2d, (l+1)*2d).  In the backward every layer writes its
+    dK / dV into its column slice of ONE gradient buffer; only the layer that ran first in the forward (the last one to run
+    backward) hands that buffer to autograd, the others return None -- so autograd adds nothing and the projection's data
+    gradient is one GEMM over K = L*2d."""
+
+    def __init__(self, n_layers, width, may_skip_layers):
+        self.n_layers, self.width, self.may_skip = n_layers, width, may_skip_layers
+        self.first = None      # id of the forward call that ran first
+        self.grad = None
+
+    def grad_buffer(self, like):
+        if self.grad is None:
+            self.grad = (torch.zeros_like if self.may_skip else torch.empty_like)(like)
+        return self.grad
+
+
 class CrossAttentionFunction(torch.autograd.Function):
     """q [B*T, d], kv [B*S, 2d] -> ctx [B*T, d] (+ probabilities [B*H, T, lds], differentiable: the
-    guided-attention loss of TTS fine-tuning back-propagates through them)."""
+    guided-attention loss of TTS fine-tuning back-propagates through them).  cfg may carry (kv_ld, kv_off, share): kv is then
+    the all-layer projection [B*S, kv_ld] and this layer's keys / values start at column kv_off (KVShare)."""
 
     @staticmethod
     def forward(ctx_, q, kv, kpm, cfg):
-        B, H, T, S, hd, p_drop, want_probs = cfg
+        B, H, T, S, hd, p_drop, want_probs = cfg[:7]
         d = H * hd
+        kld, koff, share = cfg[7:10] if len(cfg) > 7 else (2 * d, 0, None)
+        if share is not None and share.first is None:
+            share.first = id(ctx_)
         seed = next_seed() if p_drop > 0 else 0
         if _can_flash(q.dtype, hd, want_probs):
-            ctx, lse, _ = _flash_fwd((q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), B, H, T, S, hd, None, 0, kpm, False, p_drop, seed)
+            ctx, lse, _ = _flash_fwd((q, d, 0), (kv, kld, koff), (kv, kld, koff + d), B, H, T, S, hd, None, 0, kpm, False, p_drop, seed)
             ctx_.save_for_backward(q, kv, ctx, lse, kpm)
             ctx_.meta = (cfg, seed, True)
             return ctx, None
-        ctx, probs, pdrop = _attn_fwd((q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), B, H, T, S, hd, None, 0, kpm, False, p_drop, seed)
+        ctx, probs, pdrop = _attn_fwd((q, d, 0), (kv, kld, koff), (kv, kld, koff + d), B, H, T, S, hd, None, 0, kpm, False, p_drop, seed)
         ctx_.save_for_backward(q, kv, probs, pdrop)
         ctx_.meta = (cfg, seed, False)
         if want_probs:
@@ -1207,25 +1229,28 @@ class CrossAttentionFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx_, dctx, dprobs):
-        (B, H, T, S, hd, p_drop, _), seed, flash = ctx_.meta
+        cfg, seed, flash = ctx_.meta
+        B, H, T, S, hd, p_drop, _ = cfg[:7]
         d = H * hd
+        kld, koff, share = cfg[7:10] if len(cfg) > 7 else (2 * d, 0, None)
+        kv = ctx_.saved_tensors[1]
+        dq = torch.empty_like(ctx_.saved_tensors[0])
+        dkv = share.grad_buffer(kv) if share is not None else torch.empty_like(kv)
         if flash:
             q, kv, ctx, lse, kpm = ctx_.saved_tensors
-            dq = torch.empty_like(q)
-            dkv = torch.empty_like(kv)
-            _flash_bwd(dctx.contiguous(), ctx, lse, (q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), (dq, d, 0), (dkv, 2 * d, 0),
-                       (dkv, 2 * d, d), B, H, T, S, hd, None, False, 0, kpm, False, p_drop, seed)
-            return dq, dkv, None, None
-        q, kv, probs, pdrop = ctx_.saved_tensors
-        dq = torch.empty_like(q)
-        dkv = torch.empty_like(kv)
-        extra = None
-        if dprobs is not None:
-            extra = dprobs.reshape(B * H, T, S).float().contiguous()
-        if dctx is None:
-            dctx = torch.zeros(B * T, d, dtype=q.dtype, device=q.device)
-        _attn_bwd(dctx.contiguous(), (q, d, 0), (kv, 2 * d, 0), (kv, 2 * d, d), (dq, d, 0), (dkv, 2 * d, 0), (dkv, 2 * d, d),
-                  probs, pdrop, extra, B, H, T, S, hd, None, False, 0, p_drop, seed)
+            _flash_bwd(dctx.contiguous(), ctx, lse, (q, d, 0), (kv, kld, koff), (kv, kld, koff + d), (dq, d, 0), (dkv, kld, koff),
+                       (dkv, kld, koff + d), B, H, T, S, hd, None, False, 0, kpm, False, p_drop, seed)
+        else:
+            q, kv, probs, pdrop = ctx_.saved_tensors
+            extra = None
+            if dprobs is not None:
+                extra = dprobs.reshape(B * H, T, S).float().contiguous()
+            if dctx is None:
+                dctx = torch.zeros(B * T, d, dtype=q.dtype, device=q.device)
+            _attn_bwd(dctx.contiguous(), (q, d, 0), (kv, kld, koff), (kv, kld, koff + d), (dq, d, 0), (dkv, kld, koff), (dkv, kld, koff + d),
+                      probs, pdrop, extra, B, H, T, S, hd, None, False, 0, p_drop, seed)
+        if share is not None and share.first != id(ctx_):
+            dkv = None    # (this layer's slice is in the shared buffer; the first-run layer returns it)
         return dq, dkv, None, None
 
 

@@ -69,6 +69,16 @@ class TransformerDecoder(FairseqIncrementalDecoder):
             enc_pad = encoder_out["encoder_padding_mask"][0]
         x = Fn.as_compute(prev_output_tokens.contiguous()).view(B * T, C)
         causal = not full_context_alignment
+        # keys / values of every layer's cross-attention in ONE projection of the encoder output (same input for all layers;
+        # the reference runs k_proj / v_proj per layer, transformer_layer.py:352-366): [B*S, L*2C], layer l = columns l*2C...
+        kv_all, share = None, None
+        cross = [l.encoder_attn for l in self.layers]
+        if enc_rows is not None and all(a is not None for a in cross) and len(cross) > 1:
+            ws = [w for a in cross for w in (a.k_proj.weight, a.v_proj.weight)]
+            bs = [b for a in cross for b in (a.k_proj.bias, a.v_proj.bias)]
+            if all(b is not None for b in bs) and all(w.shape == ws[0].shape for w in ws):
+                kv_all = Fn.linear(enc_rows, ws, bs)
+                share = Fn.KVShare(len(cross), 2 * C, self.training and self.decoder_layerdrop > 0)
         attn_list, attn = [], None
         inner_states = [x.view(B, T, C).transpose(0, 1)]
         for idx, layer in enumerate(self.layers):
@@ -76,7 +86,8 @@ class TransformerDecoder(FairseqIncrementalDecoder):
                 x = Fn.layer_boundary(x, layer)   # skipped layer: its (zero) gradient bucket still reports ready here
                 continue  # LayerDropModuleList semantics (torch RNG)
             want = bool(idx == alignment_layer or alignment_layer == -1)
-            x, layer_attn = layer.forward_rows(x, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want)
+            x, layer_attn = layer.forward_rows(x, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want,
+                                               kv_all=(kv_all, idx * 2 * C, share) if kv_all is not None else None)
             inner_states.append(x.view(B, T, C).transpose(0, 1))
             if layer_attn is not None and want:
                 attn = layer_attn.transpose(0, 1)       # [H,B,T,S] as the reference's per-head weights

@@ -75,7 +75,7 @@ class MultiheadAttention(nn.Module, IncrementalState):
 
     # ---- batch-major row interface used by the layer mirrors (no layout copies) ----
     def forward_rows(self, x, B, T, *, kv=None, S=None, key_padding_mask=None, causal=False, position_bias=None,
-                     residual=None, out_dropout=0.0, need_weights=False):
+                     residual=None, out_dropout=0.0, need_weights=False, kv_all=None):
         """x [B*T, C] rows (query source); kv [B*S, C] rows (cross-attention source) or None for self-attention.
         Returns (out rows [B*T, C] = dropout(out_proj(attn)) + residual, probs [B,H,T,S] fp32 or None)."""
         H, hd = self.num_heads, self.head_dim
@@ -86,7 +86,7 @@ class MultiheadAttention(nn.Module, IncrementalState):
         probs = None
         # post-LN blocks add the block input itself as the residual: relay its gradient into the first projection's dX GEMM
         relay = Fn.GradRelay() if (residual is x and x.requires_grad and torch.is_grad_enabled()) else None
-        if kv is None:
+        if kv is None and kv_all is None:
             qkv = Fn.linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight],
                             [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], relay_in=relay)
             pe, maxrel, pe_t = None, 0, None
@@ -97,8 +97,12 @@ class MultiheadAttention(nn.Module, IncrementalState):
             ctx = Fn.SelfAttentionFunction.apply(qkv, pe, kpm, (B, H, T, hd, maxrel, causal, p, pe_t))
         else:
             q = Fn.linear(x, self.q_proj.weight, self.q_proj.bias, relay_in=relay)
-            kvp = Fn.linear(kv, [self.k_proj.weight, self.v_proj.weight], [self.k_proj.bias, self.v_proj.bias])
-            ctx, probs = Fn.CrossAttentionFunction.apply(q, kvp, kpm, (B, H, T, S, hd, p, need_weights))
+            if kv_all is not None:   # (tensor [B*S, ld], column offset of this layer's [K | V], functional.KVShare)
+                kvt, koff, share = kv_all
+                ctx, probs = Fn.CrossAttentionFunction.apply(q, kvt, kpm, (B, H, T, S, hd, p, need_weights, kvt.shape[1], koff, share))
+            else:
+                kvp = Fn.linear(kv, [self.k_proj.weight, self.v_proj.weight], [self.k_proj.bias, self.v_proj.bias])
+                ctx, probs = Fn.CrossAttentionFunction.apply(q, kvp, kpm, (B, H, T, S, hd, p, need_weights))
         out = Fn.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual,
                         dropout_p=out_dropout if self.training else 0.0, relay_out=relay)
         return out, probs

@@ -91,7 +91,7 @@ class TransformerDecoderLayer(nn.Module):
         if has_relative_attention_bias:
             self.norm_k = LayerNorm(self.embed_dim // args.decoder_attention_heads)  # unused (:241), kept for checkpoints
 
-    def forward_rows(self, x, B, T, enc_rows, S, enc_padding_mask, self_padding_mask, causal, need_attn):
+    def forward_rows(self, x, B, T, enc_rows, S, enc_padding_mask, self_padding_mask, causal, need_attn, kv_all=None):
         """transformer_layer.py:262-404 without incremental state.  Returns (rows, cross-attn probs [B,H,T,S] or None)."""
         ft = self.freeze_decoder_updates <= self.num_updates
         tr = self.training
@@ -108,7 +108,7 @@ class TransformerDecoderLayer(nn.Module):
         if self.encoder_attn is not None and enc_rows is not None:
             h = self.encoder_attn_layer_norm(x) if nb else x
             x, attn = self.encoder_attn.forward_rows(h, B, T, kv=enc_rows, S=S, key_padding_mask=enc_padding_mask, residual=x,
-                                                     out_dropout=p, need_weights=need_attn or (not tr and self.need_attn))
+                                                     out_dropout=p, need_weights=need_attn or (not tr and self.need_attn), kv_all=kv_all)
             if not nb:
                 x = self.encoder_attn_layer_norm(x)
         with torch.no_grad() if not ft else contextlib.ExitStack():
