@@ -358,6 +358,8 @@ int st5_canon_rows(const float* e, int32_t* canon, int32_t V, int32_t D, void* s
 int st5_nce_logits(const float* sim, const int32_t* target, const int32_t* canon, float* logits, int64_t S, int32_t V, float temp, void* stream);
 int st5_nce_logits_bwd(const float* dlogits, const int32_t* target, const int32_t* canon, float* dsim, int64_t S, int32_t V, float temp,
                        void* stream);
+/* A/B switch of the LayerNorm backward: upper bound of its block count (default 256). */
+int st5_layernorm_set_max_blocks(int n);
 /* ---- CTC prefix scoring for joint CTC / attention beam search (sequence_generator.py:273-418 calls espnet's
  * CTCPrefixScore per hypothesis on the host; in-tree copy Speech2C/speech2c/models/modules/ctc_prefix_score.py:10-112) ----
  * x: fp32 CTC log-posteriors [T, V] of ONE utterance (device).  A state is r[T][2] fp32 = log r_t^n, log r_t^b of a prefix.

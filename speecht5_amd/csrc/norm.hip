@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
 // workspace into dgamma/dbeta (+=).
 // ------------------------------------------------------------------------------------------------
 constexpr int RPW = 4;          // rows per wave per iteration
-constexpr int LN_MAX_BLOCKS = 256;
+int g_ln_max_blocks = 256;     // blocks of the single-pass LayerNorm backward (A/B: st5_layernorm_set_max_blocks)
 
 template <typename T> __device__ __forceinline__ void load4f(const T* p, float (&v)[4]);
 template <> __device__ __forceinline__ void load4f<float>(const float* p, float (&v)[4]) {
@@ -370,7 +370,7 @@ int ln_flush(hipStream_t s) {
 
 int ln_blocks(long long rows) {
   long long n = (rows + 4 * RPW - 1) / (4 * RPW);
-  return (int)(n < LN_MAX_BLOCKS ? (n < 1 ? 1 : n) : LN_MAX_BLOCKS);
+  return (int)(n < g_ln_max_blocks ? (n < 1 ? 1 : n) : g_ln_max_blocks);
 }
 
 // ---- column reductions: out[c] (+)= scale * sum_r f(r, c) --------------------------------------
@@ -594,6 +594,8 @@ extern "C" int st5_layernorm_defer(int enabled, void* stream) {
   return ST5_OK;
 }
 extern "C" int st5_layernorm_flush(void* stream) { return ln_flush(reinterpret_cast<hipStream_t>(stream)); }
+/* A/B switch: upper bound of the backward's block count (partials workspace = blocks x 2 x cols floats). */
+extern "C" int st5_layernorm_set_max_blocks(int n) { if (n < 1 || n > 4096) return ST5_ERR_ARG; g_ln_max_blocks = n; return ST5_OK; }
 
 // out[c] (+)= scale * sum_r x[r, c]; uses an internal static workspace-free two-stage path via `ws`
 // passed through the trailing part of `out`?  No: colsum allocates nothing -- the caller provides
