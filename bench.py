@@ -150,7 +150,7 @@ def main():
 
     if use_graph:
         from speecht5_amd.graph import StepGraph
-        sg = StepGraph(one_update, opt=opt, model=model, device=device, on_step=advance)
+        sg = StepGraph(one_update, opt=opt, model=model, device=device, on_step=advance, prefetch_host=os.environ.get("ST5_PREFETCH_HOST", "1") == "1")
         for i in range(max(a.warmup - 2, 1)):
             step(i)
         counter[0] = max(a.warmup - 2, 1) - 1

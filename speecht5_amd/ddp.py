@@ -374,12 +374,17 @@ class FusedAdam:
         dev = self.pflat.device
         self.hyper_dev = torch.zeros(2, dtype=torch.float32, device=dev)
         self.hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self.hyper_host2 = None
 
-    def push_hyper(self):
-        """Host -> device copy of (lr, next step count); call before the step that will read it."""
-        self.hyper_host[0] = float(self.lr)
-        self.hyper_host[1] = float(self.t + 1)
-        self.hyper_dev.copy_(self.hyper_host, non_blocking=True)
+    def push_hyper(self, slot=0):
+        """Host -> device copy of (lr, next step count); call before the step that will read it.  `slot` picks one of two
+        pinned images (the copy is asynchronous: a caller that runs ahead of the GPU alternates them, graph.StepGraph)."""
+        if slot and self.hyper_host2 is None:
+            self.hyper_host2 = torch.zeros(2, dtype=torch.float32).pin_memory()
+        h = self.hyper_host2 if slot else self.hyper_host
+        h[0] = float(self.lr)
+        h[1] = float(self.t + 1)
+        self.hyper_dev.copy_(h, non_blocking=True)
 
     def backward(self, loss):
         loss.backward()

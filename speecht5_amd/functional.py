@@ -53,6 +53,7 @@ class SeedSlots:
         self.n = n
         self.dev = torch.zeros(n, dtype=torch.int64, device=device)
         self.host = torch.zeros(n, dtype=torch.int64).pin_memory()
+        self.host2 = None   # second pinned image (graph.StepGraph prefetch_host)
         self.k = 0          # slots handed out in the step being recorded / captured
         self.used = 0       # slots one step uses (fixed after the recording step)
 
@@ -64,13 +65,21 @@ class SeedSlots:
 
     def begin_step(self):
         """Fill the slots with the seeds the host counter yields for this step (same values as the eager path)."""
+        self.produce(0)
+        self.upload(0)
+
+    def produce(self, slot):
         n = self.used if self.used else self.n
         base = _S.counter
         import numpy as np
         vals = ((np.uint64(_S.seed) << np.uint64(32)) | ((np.arange(1, n + 1, dtype=np.uint64) + np.uint64(base)) & np.uint64(0xFFFFFFFF)))
-        self.host[:n] = torch.from_numpy(vals.astype(np.int64))
-        self.dev.copy_(self.host, non_blocking=True)
+        if slot and self.host2 is None:
+            self.host2 = torch.empty_like(self.host).pin_memory()
+        (self.host2 if slot else self.host)[:n] = torch.from_numpy(vals.astype(np.int64))
         _S.counter += n
+
+    def upload(self, slot):
+        self.dev.copy_(self.host2 if slot else self.host, non_blocking=True)
         self.k = 0
 
 
@@ -108,11 +117,23 @@ class HostStaging:
         return e[0]
 
     def refresh(self):
+        self.produce(0)
+        self.upload(0)
+
+    # The two halves of refresh(), for a replay loop that produces the NEXT step's host inputs on a helper thread while the
+    # current step runs (graph.StepGraph(prefetch_host=True)): `slot` selects one of two pinned images per entry, so the host
+    # may write step k+1's data while step k's upload (queued behind step k-1 on the stream) has not executed yet.
+    def produce(self, slot):
         for e in self.entries:
             h = e[2]()
             assert e[1].shape == h.shape
-            e[1].copy_(h)
-            e[0].copy_(e[1], non_blocking=True)
+            if slot and len(e) == 3:
+                e.append(torch.empty(h.shape, dtype=h.dtype).pin_memory())
+            (e[3] if slot else e[1]).copy_(h)
+
+    def upload(self, slot):
+        for e in self.entries:
+            e[0].copy_(e[3] if slot else e[1], non_blocking=True)
 
 
 staging = HostStaging()

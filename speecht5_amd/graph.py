@@ -19,7 +19,7 @@ from . import functional as Fn
 
 
 class StepGraph:
-    def __init__(self, step_fn, opt=None, model=None, device=None, seed_slots=1024, on_step=None):
+    def __init__(self, step_fn, opt=None, model=None, device=None, seed_slots=1024, on_step=None, prefetch_host=False):
         """step_fn(): one full update on the current stream -- zero_grad, forward/backward of every micro-batch, finish,
         optimizer step -- without host synchronisation.  `opt`: the FusedAdam whose (lr, step) must follow the host."""
         self.step_fn = step_fn
@@ -27,6 +27,16 @@ class StepGraph:
         self.opt = opt
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.graph = None
+        # prefetch_host: hipGraphLaunch keeps the calling thread until the previous launch of the same graph has drained (measured:
+        # graph.replay() returns after 40-60 ms), so the host part of the NEXT step's preparation (on_step, seed values, the CPU
+        # producers of the staged inputs: ~1.2 ms) would sit between two replays with the GPU idle.  With prefetch_host it runs on
+        # a helper thread while the launch call blocks (the call releases the GIL), into the second pinned image of every staged
+        # buffer; replay() then only enqueues the uploads.  The CPU random streams are drawn in the same order, one step EARLIER
+        # than without (after the last replay one prepared, unused step has advanced them).
+        self.prefetch_host = prefetch_host
+        self._ahead = None      # (thread, slot) preparing the next step
+        self._slot = 0
+        self._uploaded = [None, None]   # event after the last upload from each pinned slot (the slot may be rewritten only after it)
         self.slots = Fn.SeedSlots(seed_slots, self.device)
         self.stream = torch.cuda.Stream(device=self.device)
         if model is not None:
@@ -81,19 +91,57 @@ class StepGraph:
         assert self.slots.k == self.slots.used, "the captured step used a different number of dropout seeds than the recorded one"
         self._pending = True   # buffers are already staged for the first replay
 
-    def _pre_replay(self):
+    def _produce(self, slot):
+        """Host half of the preparation of one step (no device work)."""
         if self.on_step is not None:
             self.on_step()
-        self.slots.begin_step()
-        Fn.staging.refresh()
+        self.slots.produce(slot)
+        Fn.staging.produce(slot)
+
+    def _upload(self, slot):
+        self.slots.upload(slot)
+        Fn.staging.upload(slot)
         if self.opt is not None:
-            self.opt.push_hyper()
+            self.opt.push_hyper(slot)
+        # the uploads are asynchronous reads of pinned host images: remember when this slot's have executed (a host that runs
+        # ahead of the GPU -- small steps -- must not rewrite the images before that)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._uploaded[slot] = ev
+
+    def _pre_replay(self):
+        if self._uploaded[0] is not None:
+            self._uploaded[0].synchronize()
+        self._produce(0)
+        self._upload(0)
 
     def replay(self):
         if self._pending:
             self._pending = False
+        elif self._ahead is not None:
+            th, slot = self._ahead
+            th.join()
+            self._ahead = None
+            if self._ahead_error is not None:
+                raise self._ahead_error
+            self._upload(slot)
         else:
             self._pre_replay()
+        if self.prefetch_host:
+            import threading
+            self._slot ^= 1
+            self._ahead_error = None
+            if self._uploaded[self._slot] is not None:
+                self._uploaded[self._slot].synchronize()
+
+            def work(slot=self._slot):
+                try:
+                    self._produce(slot)
+                except BaseException as e:   # surfaced by the next replay()
+                    self._ahead_error = e
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            self._ahead = (th, self._slot)
         self.graph.replay()
         if self.opt is not None:
             self.opt.t += 1

@@ -61,9 +61,9 @@ def _run(cuda, dtype, mode, nsteps=3, seed_offset=0):
             model.set_num_updates(n[0])
             opt.lr = 1e-3 * (1 + 0.1 * n[0])          # a schedule: the replayed step must follow the host's learning rate
 
-        if mode == "graph":
+        if mode in ("graph", "graph_prefetch"):
             from speecht5_amd.graph import StepGraph
-            sg = StepGraph(step, opt=opt, model=model, device=cuda, on_step=advance)
+            sg = StepGraph(step, opt=opt, model=model, device=cuda, on_step=advance, prefetch_host=mode == "graph_prefetch")
             sg.record(); sg.record(); sg.capture()
             for _ in range(nsteps - 2):
                 sg.replay()
@@ -107,6 +107,16 @@ def test_graph_replay_equals_eager_fixed_shape(cuda, dtype, seed_offset):
     for a, b, name in ((pg, ps, "parameters"), (mg, ms, "first moment"), (vg, vs, "second moment")):
         d = float((a - b).abs().max())
         assert d <= tol * max(1.0, float(b.abs().max())), f"{name}: max difference {d:.3e} (tolerance {tol:.1e})"
+
+
+def test_replay_with_host_prefetch_thread_equals_plain_replay(cuda):
+    """StepGraph(prefetch_host=True) prepares the next step's host inputs on a helper thread while the launch call blocks: the
+    same random draws in the same order, only earlier -- 5 updates (3 of them replayed) must come out bit for bit."""
+    a = _run(cuda, torch.bfloat16, "graph", 5)
+    b = _run(cuda, torch.bfloat16, "graph_prefetch", 5)
+    assert a[3] == b[3] == 5
+    for x, y, name in zip(a[:3], b[:3], ("parameters", "first moment", "second moment")):
+        assert torch.equal(x, y), name
 
 
 def test_fixed_shape_form_equals_reference_shaped_form(cuda):
