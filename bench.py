@@ -111,7 +111,15 @@ def main():
     from speecht5_amd.synthetic import speech_pretrain_sample, text_pretrain_sample
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     args, task, model, crit = build(device, dtype)
-    ddp = FlatGradDataParallel(model)
+    # One rank: the update is captured into a HIP graph after the warm-up steps and REPLAYED in the timed region (fresh dropout
+    # seeds / span masks / lr per replay: speecht5_amd/graph.py).  Several ranks: eager enqueue (RCCL collectives stay outside
+    # graphs here).  ST5_GRAPH=0 or --no-graph forces the eager path.
+    use_graph = world == 1 and not a.no_graph and os.environ.get("ST5_GRAPH", "1") == "1" and not dist.is_initialized()
+    overlap_fwd = use_graph and os.environ.get("ST5_OVERLAP_FWD", "1") == "1"   # (eager enqueue is host-bound: nothing to gain)
+    wgrad_env = os.environ.get("ST5_WGRAD_STREAM")
+    # replayed step: forward passes of the two micro-batches side by side, no weight-gradient stream (see ddp.py); eager step:
+    # the weight-gradient stream hides ~3.5 ms of dW GEMMs behind the data-gradient chain
+    ddp = FlatGradDataParallel(model, wgrad_stream=(wgrad_env == "1") if wgrad_env is not None else not (use_graph and overlap_fwd))
     opt = FusedAdam(ddp, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0)
     Fn.manual_seed(1337 + rank)
     import numpy as np
@@ -126,7 +134,10 @@ def main():
         ddp.zero_grad()
         # --update-freq 2: gradients of the first micro-batch only accumulate (no_sync); the bucket all-reduces are
         # launched from the backward of the LAST micro-batch, each bucket once, after its last local contribution
-        ddp.accumulate(micro, lambda s: task.train_step(s, model, crit, None, i, sync=False))
+        if overlap_fwd:   # forward passes of the two micro-batches side by side on two streams, backward passes in turn
+            ddp.accumulate_overlapped(micro, lambda s: task.forward_loss(s, model, crit, i))
+        else:
+            ddp.accumulate(micro, lambda s: task.train_step(s, model, crit, None, i, sync=False))
         ddp.finish()
         opt.step(grad_scale=1.0 / len(micro))
 
@@ -135,10 +146,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # One rank: the update is captured into a HIP graph after the warm-up steps and REPLAYED in the timed region (fresh dropout
-    # seeds / span masks / lr per replay: speecht5_amd/graph.py).  Several ranks: eager enqueue (RCCL collectives stay outside
-    # graphs here).  ST5_GRAPH=0 or --no-graph forces the eager path.
-    use_graph = world == 1 and not a.no_graph and os.environ.get("ST5_GRAPH", "1") == "1" and not dist.is_initialized()
     counter = [0]
 
     def one_update():
@@ -236,7 +243,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "SpeechT5-Base pretrain step (speech 8x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
                                       "fwd+bwd+allreduce+clip+Adam, per GPU", "arch": "t5_transformer_base (12 enc + 6 dec, d=768)",
-                          "enqueue": "hip-graph replay" if use_graph else "eager",
+                          "enqueue": "hip-graph replay" if use_graph else "eager", "micro_batch_forward": "side by side on two streams" if overlap_fwd else "in turn",
                           "global_speech_batch": a.batch * world, "clip_seconds": 10, "parallelism": f"dp{world}",
                           "dropout": 0.1, "layerdrop": 0.0},
                "roofline": roof}

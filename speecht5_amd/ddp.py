@@ -41,7 +41,7 @@ class _Trigger(torch.autograd.Function):
 
 
 class FlatGradDataParallel:
-    def __init__(self, model, process_group=None, bucket_groups=None):
+    def __init__(self, model, process_group=None, bucket_groups=None, wgrad_stream=None):
         """bucket_groups: list of lists of modules, in the order their backward completes; parameters not covered by
         any group form a final bucket.  Default: derived from a T5TransformerModel (see `default_buckets`)."""
         self.model = model
@@ -109,6 +109,7 @@ class FlatGradDataParallel:
         # it AND every bucket before it has been reported ready -- and finish() launches the rest, again in index order.
         # A rank that skipped a layer (LayerDrop, another modality) simply defers from that bucket on; it never reorders.
         self._accumulating = False
+        self._fwd_streams = []   # forward streams of micro-batches 1.. (accumulate_overlapped)
         self._ready = [False] * len(self.buckets)
         self._next = 0
         self._works = []
@@ -122,7 +123,11 @@ class FlatGradDataParallel:
                 hip.check(hip.lib().st5_layernorm_defer(1, hip.stream()), "st5_layernorm_defer")
             # weight-gradient GEMMs of the transformer layers on their own stream (functional.set_wgrad_stream): their
             # gradient buffers have no other writer (no tied weights inside a layer)
-            if os.environ.get("ST5_WGRAD_STREAM", "1") == "1":
+            # wgrad_stream: None = the ST5_WGRAD_STREAM switch (default on).  Worth 3.5 ms per update when the step is enqueued
+            # eagerly; inside a replayed graph it brings nothing (48.05 vs 47.9 ms) and, worse, the graph executor then puts
+            # the second micro-batch's forward stream (accumulate_overlapped) behind the whole weight-gradient branch
+            # (measured: 48.3 ms with both, 45.0 ms with the forward overlap alone) -- bench.py turns it off for replay.
+            if (os.environ.get("ST5_WGRAD_STREAM", "1") == "1") if wgrad_stream is None else wgrad_stream:
                 from .modules.transformer_layer import TransformerSentenceEncoderLayer, TransformerDecoderLayer
                 from .modules.speech_encoder_prenet import ConvFeatureExtractionModel
                 for m in model.modules():
@@ -194,6 +199,35 @@ class FlatGradDataParallel:
             with (self.no_sync() if i + 1 < n else contextlib.nullcontext()):
                 out.append(fn(mb))
         return out
+
+    def accumulate_overlapped(self, micro_batches, forward_loss):
+        """The micro-batches of one update with their FORWARD passes side by side: forward_loss(sample) -> normalised loss
+        tensor (forward only).  Micro-batch 0 runs on the current stream, micro-batch i on its own stream (forked here); the
+        backward passes then run one after the other (they accumulate into the same gradient buffers), every one except the
+        last under no_sync().  Autograd runs a node's backward on the stream of its forward, so micro-batch i's backward stays
+        on its stream; the engine orders it behind the previous backward (its root gradient is produced on the current stream)
+        and makes the current stream wait for it at the end.  Measured on the two micro-batches of the pre-training update
+        (speech 8 x 10 s, text 16 x 512; graph replay): forward pair 14.5 -> 10.8 ms (tools/fwd_overlap.py) -- the forward
+        passes are strings of small kernels that leave most of the chip idle on their own."""
+        n = len(micro_batches)
+        cur = torch.cuda.current_stream()
+        while len(self._fwd_streams) < n - 1:
+            self._fwd_streams.append(torch.cuda.Stream(device=self.flat.device))
+        for st in self._fwd_streams[: n - 1]:
+            st.wait_stream(cur)          # every forward starts from here (what precedes: zero_grad, the previous update)
+        losses = []
+        for i, mb in enumerate(micro_batches):
+            if i == 0:
+                losses.append(forward_loss(mb))
+            else:
+                with torch.cuda.stream(self._fwd_streams[i - 1]):
+                    losses.append(forward_loss(mb))
+        for i, loss in enumerate(losses):
+            with (self.no_sync() if i + 1 < n else contextlib.nullcontext()):
+                loss.backward()
+        for st in self._fwd_streams[: n - 1]:
+            cur.wait_stream(st)
+        return [l.detach() for l in losses]
 
     # -- step API ----------------------------------------------------------------------------------
     def close(self):

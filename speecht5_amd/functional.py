@@ -187,10 +187,19 @@ class _WeightCache:
     def get(self, key, params, build):
         ver = tuple((p.data_ptr(), p._version) for p in params)
         hit = self.store.get(key)
+        cur = hip.stream() if params and params[0].is_cuda else None
         if hit is not None and hit[0] == ver:
+            if hit[2] is not None and cur != hit[3] and cur not in hit[4]:
+                # built on another stream (two micro-batches forward side by side): this stream waits for the build once
+                torch.cuda.current_stream().wait_event(hit[2])
+                hit[4].add(cur)
             return hit[1]
         val = build()
-        self.store[key] = (ver, val)
+        ev = None
+        if cur is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+        self.store[key] = (ver, val, ev, cur, set())
         return val
 
     def clear(self):
@@ -1107,6 +1116,21 @@ def set_attention_stream(stream):
     """Second stream for the attention backward (dq and dkv kernels side by side, st5_flash_attn_bwd_2s); None = off."""
     _S.attn_side = stream
     _S.attn_side_raw = stream.cuda_stream if stream is not None else None
+    _S.attn_owner = None
+
+
+def _attn_side_raw():
+    """Second stream of the attention backward (None = single-stream backward).  Only the stream that first asks gets it: with
+    the micro-batches' backward passes on different streams (ddp.accumulate_overlapped) a helper stream forked from a second
+    parent inside one graph capture crashed hipStreamEndCapture (also with one helper per parent), so backward passes running
+    on another stream do dq and dkv in turn (the side-by-side form is worth ~0.3 ms per micro-batch)."""
+    if _S.attn_side is None:
+        return None
+    cur = hip.stream()
+    owner = _S.__dict__.setdefault("attn_owner", None)
+    if owner is None:
+        _S.attn_owner = owner = cur
+    return _S.attn_side_raw if cur == owner else None
 
 
 def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe, maxrel, kpm, causal, p_drop, seed, qp=None,
@@ -1132,7 +1156,7 @@ def _flash_bwd(dctx, ctx, lse, q, k, v, dq, dk, dv, B, H, T, S, hd, pe, want_dpe
                                               _eptr(dq), dq[1], _eptr(dk), dk[1], _eptr(dv), dv[1], lse.data_ptr(), dvec.data_ptr(),
                                               hip.ptr(pe), hip.ptr(qp), hip.ptr(dqp), hip.ptr(kpm), B, H, T, S, hd, nb, maxrel,
                                               1 if causal else 0, _ceil8(S), alpha, p_drop, seed, hip.BF16, hip.stream(),
-                                              _S.attn_side_raw), "st5_flash_attn_bwd_2s")
+                                              _attn_side_raw()), "st5_flash_attn_bwd_2s")
     if pe is None:
         return None
     dqt, dqld, dqoff = dq

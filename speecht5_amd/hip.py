@@ -312,7 +312,9 @@ _ws = {}
 
 
 def workspace(nbytes, device):
-    key = (device.type, device.index)
+    """Grow-only scratch buffer of the CURRENT stream (two micro-batches may run forward side by side on two streams: a
+    buffer shared between streams would be written by both)."""
+    key = (device.type, device.index, stream())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

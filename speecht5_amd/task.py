@@ -159,6 +159,14 @@ class SpeechT5Task:
         agg["loss"] = loss.detach().item() if sync else loss.detach()
         return agg["loss"], 1.0, agg
 
+    def forward_loss(self, sample, model, criterion, update_num):
+        """The forward half of train_step (tasks/speecht5.py:519-538): the locally normalised loss of one micro-batch; the
+        caller runs .backward() (ddp.accumulate_overlapped runs the forward passes of an update's micro-batches side by side)."""
+        model.train()
+        model.set_num_updates(update_num)
+        loss, sample_size, _ = criterion(model, sample)
+        return loss / sample_size
+
     def valid_step(self, sample, model, criterion):
         model.eval()
         with torch.no_grad():

@@ -50,9 +50,14 @@ def _run(cuda, dtype, mode, nsteps=3, seed_offset=0):
         torch.manual_seed(5 + seed_offset)
         n = [0]
 
+        overlap = mode.endswith("_overlap")
+
         def step():
             ddp.zero_grad()
-            ddp.accumulate(micro, lambda s: task.train_step(s, model, crit, None, n[0], sync=False))
+            if overlap:   # forward passes of the two micro-batches side by side on two streams
+                ddp.accumulate_overlapped(micro, lambda s: task.forward_loss(s, model, crit, n[0]))
+            else:
+                ddp.accumulate(micro, lambda s: task.train_step(s, model, crit, None, n[0], sync=False))
             ddp.finish()
             opt.step(grad_scale=0.5)
 
@@ -61,14 +66,14 @@ def _run(cuda, dtype, mode, nsteps=3, seed_offset=0):
             model.set_num_updates(n[0])
             opt.lr = 1e-3 * (1 + 0.1 * n[0])          # a schedule: the replayed step must follow the host's learning rate
 
-        if mode in ("graph", "graph_prefetch"):
+        if mode in ("graph", "graph_prefetch", "graph_overlap"):
             from speecht5_amd.graph import StepGraph
             sg = StepGraph(step, opt=opt, model=model, device=cuda, on_step=advance, prefetch_host=mode == "graph_prefetch")
             sg.record(); sg.record(); sg.capture()
             for _ in range(nsteps - 2):
                 sg.replay()
         else:
-            Fn._S.force_static = mode == "static"
+            Fn._S.force_static = mode.startswith("static")
             for _ in range(nsteps):
                 advance()
                 step()
@@ -117,6 +122,22 @@ def test_replay_with_host_prefetch_thread_equals_plain_replay(cuda):
     assert a[3] == b[3] == 5
     for x, y, name in zip(a[:3], b[:3], ("parameters", "first moment", "second moment")):
         assert torch.equal(x, y), name
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_micro_batch_forwards_side_by_side_equal_in_turn(cuda, dtype):
+    """ddp.accumulate_overlapped (forward passes of the update's two micro-batches on two streams, backward passes in turn) against
+    ddp.accumulate, eager and replayed: the same kernels with the same seeds -- in bf16 any difference at all would be a race."""
+    ref = _run(cuda, dtype, "static", 4)
+    for mode in ("static_overlap", "graph_overlap"):
+        got = _run(cuda, dtype, mode, 4)
+        assert got[3] == ref[3] == 4
+        for x, y, name in zip(ref[:3], got[:3], ("parameters", "first moment", "second moment")):
+            if dtype == torch.bfloat16:
+                assert torch.equal(x, y), f"{mode}: {name}"
+            else:
+                d = float((x - y).abs().max())
+                assert d <= 2e-5 * max(1.0, float(x.abs().max())), f"{mode}: {name} differ by {d:.3e}"
 
 
 def test_fixed_shape_form_equals_reference_shaped_form(cuda):
