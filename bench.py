@@ -222,8 +222,11 @@ def main():
     roof = {"bound": "mfma", "kernel": f"NT-form st5_gemm launches <{a.dtype}>: gemm_nt_glds_kernel (128x128 tiles: Linear / attention-projection "
                       "forward and data-gradient GEMMs) + gemm_nt256_kernel (256x256 tiles: the long conv feature-extractor GEMMs); "
                       "`traffic` is per launch of gemm_nt_glds_kernel",
-            "note": "launch durations are measured inside the step, i.e. beside the weight-gradient stream's kernels "
-                    "(ST5_WGRAD_STREAM=0 gives the isolated rate, ~8 % higher)",
+            "note": ("launch durations: HIP events around every st5_gemm launch of ONE eagerly enqueued update after the timed region "
+                     "(replayed launches carry no events), micro-batches side by side on two streams as in the timed steps"
+                     if use_graph else
+                     "launch durations are measured inside the step, i.e. beside the weight-gradient stream's kernels "
+                     "(ST5_WGRAD_STREAM=0 gives the isolated rate, ~8 % higher)"),
             "achieved": round(flops / secs / 1e12, 2) if secs > 0 else None, "peak": peak, "unit": "TFLOP/s",
             "frac": round(flops / secs / 1e12 / peak, 4) if secs > 0 else None, "traffic": traffic,
             "traffic_source": traffic_src,
@@ -243,7 +246,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "SpeechT5-Base pretrain step (speech 8x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
                                       "fwd+bwd+allreduce+clip+Adam, per GPU", "arch": "t5_transformer_base (12 enc + 6 dec, d=768)",
-                          "enqueue": "hip-graph replay" if use_graph else "eager", "micro_batch_forward": "side by side on two streams" if overlap_fwd else "in turn",
+                          "enqueue": "hip-graph replay" if use_graph else "eager", "micro_batches": "forward and backward side by side on two streams, two gradient buffers" if overlap_fwd else "in turn",
                           "global_speech_batch": a.batch * world, "clip_seconds": 10, "parallelism": f"dp{world}",
                           "dropout": 0.1, "layerdrop": 0.0},
                "roofline": roof}

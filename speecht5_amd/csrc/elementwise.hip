@@ -701,8 +701,10 @@ extern "C" int st5_embed_rows_bwd(const void* dy, const int32_t* tok, float* dta
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
-char* g_scatter_ws = nullptr;   // workspace of the deterministic row scatter: order | sorted ids | head | tail (grow-only)
-size_t g_scatter_bytes = 0;
+// workspace of the deterministic row scatter: order | sorted ids | head | tail (grow-only), one per stream
+struct ScatterWs { hipStream_t stream; char* ptr; size_t bytes; };
+ScatterWs g_scatter[4] = {};
+int g_nscatter = 0;
 extern "C" int st5_embed_rows_bwd_det_w(const void* dy, const int32_t* tok, float* dtable, int64_t rows, int32_t cols, int32_t vocab,
                                         float scale, const float* row_w, int32_t rw_div, int32_t rw_mod, int dtype, void* stream) {
   if (!dy || !tok || !dtable || rows < 0 || cols <= 0 || cols % 4 || vocab <= 0 || (row_w && (rw_div <= 0 || rw_mod <= 0))) return ST5_ERR_ARG;
@@ -712,13 +714,23 @@ extern "C" int st5_embed_rows_bwd_det_w(const void* dy, const int32_t* tok, floa
   const long long nch = (rows + SEG - 1) / SEG;
   const size_t ints = (((size_t)rows * 2 * sizeof(int32_t)) + 255) & ~(size_t)255;
   const size_t need = ints + (size_t)2 * nch * cols * sizeof(float);
-  if (need > g_scatter_bytes) {   // (first use / growth: outside stream capture, like every other workspace of this library)
-    if (g_scatter_ws) (void)hipFree(g_scatter_ws);
-    g_scatter_ws = nullptr; g_scatter_bytes = 0;
-    const size_t want = need < (size_t(8) << 20) ? (size_t(8) << 20) : need;
-    if (hipMalloc(&g_scatter_ws, want) != hipSuccess) return ST5_ERR_LAUNCH;
-    g_scatter_bytes = want;
+  ScatterWs* w = nullptr;
+  for (int i = 0; i < g_nscatter; ++i)
+    if (g_scatter[i].stream == s) w = &g_scatter[i];
+  if (!w) {
+    static int victim = 0;
+    w = g_nscatter < 4 ? &g_scatter[g_nscatter++] : &g_scatter[victim++ % 4];   // (stream churn: recycle, the old owner is gone)
+    if (w->stream != s && w->ptr && hipDeviceSynchronize() != hipSuccess) return ST5_ERR_LAUNCH;
+    w->stream = s;
   }
+  if (need > w->bytes) {   // (first use / growth: outside stream capture, like every other workspace of this library)
+    if (w->ptr) (void)hipFree(w->ptr);
+    w->ptr = nullptr; w->bytes = 0;
+    const size_t want = need < (size_t(8) << 20) ? (size_t(8) << 20) : need;
+    if (hipMalloc(&w->ptr, want) != hipSuccess) return ST5_ERR_LAUNCH;
+    w->bytes = want;
+  }
+  char* g_scatter_ws = w->ptr;
   int32_t* order = reinterpret_cast<int32_t*>(g_scatter_ws);
   int32_t* sid = order + rows;
   float* head = reinterpret_cast<float*>(g_scatter_ws + ints);

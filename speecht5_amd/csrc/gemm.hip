@@ -598,20 +598,48 @@ __global__ __launch_bounds__(256) void splitk_multi_reduce_kernel(const MrArgs a
 }
 
 bool g_defer = false;
-MrArgs g_pending;            // g_pending.n descriptors queued
-int g_pending_blocks = 0;
-float* g_arena = nullptr;    // slab arena for deferred reductions (grown between flushes only)
-size_t g_arena_bytes = 0, g_arena_used = 0;
+// Deferred-reduction state, ONE PER STREAM: the queued descriptors belong to GEMMs of that stream and are folded by a launch on
+// that stream (the backward passes of two micro-batches may run on two streams at once; a flush on one of them must not read
+// slabs the other stream is still writing).  Each state has its own bump arena.
+struct DeferState {
+  hipStream_t stream;
+  MrArgs pending;            // pending.n descriptors queued
+  int pending_blocks;
+  float* arena;              // slab arena for deferred reductions (grown between flushes only)
+  size_t arena_bytes, arena_used;
+};
+constexpr int DEFER_STREAMS = 4;
+DeferState g_dstates[DEFER_STREAMS] = {};
+int g_ndstates = 0;
+DeferState* defer_state(hipStream_t s, bool create) {
+  for (int i = 0; i < g_ndstates; ++i)
+    if (g_dstates[i].stream == s) return &g_dstates[i];
+  if (!create) return nullptr;
+  if (g_ndstates == DEFER_STREAMS) {   // stream churn (tests): recycle an idle state
+    for (int i = 0; i < g_ndstates; ++i)
+      if (g_dstates[i].pending.n == 0) { g_dstates[i].stream = s; return &g_dstates[i]; }
+    return nullptr;
+  }
+  DeferState* d = &g_dstates[g_ndstates++];
+  d->stream = s; d->pending.n = 0; d->pending_blocks = 0; d->arena = nullptr; d->arena_bytes = d->arena_used = 0;
+  return d;
+}
+#define g_pending (ds->pending)
+#define g_pending_blocks (ds->pending_blocks)
+#define g_arena (ds->arena)
+#define g_arena_bytes (ds->arena_bytes)
+#define g_arena_used (ds->arena_used)
 
-int flush_pending(hipStream_t s) {
-  if (g_pending.n == 0) return ST5_OK;
-  hipLaunchKernelGGL(splitk_multi_reduce_kernel, dim3((unsigned)g_pending_blocks), dim3(256), 0, s, g_pending);
+int flush_state(DeferState* ds) {
+  if (!ds || g_pending.n == 0) return ST5_OK;
+  hipLaunchKernelGGL(splitk_multi_reduce_kernel, dim3((unsigned)g_pending_blocks), dim3(256), 0, ds->stream, g_pending);
   g_pending.n = 0; g_pending_blocks = 0; g_arena_used = 0;
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
+int flush_pending(hipStream_t s) { return flush_state(defer_state(s, false)); }
 // slab space for one deferred GEMM, or nullptr when the arena must grow (caller flushes, grows, retries)
-float* arena_take(size_t bytes) {
+float* arena_take(DeferState* ds, size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
   if (g_arena_used + bytes > g_arena_bytes) return nullptr;
   float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(g_arena) + g_arena_used);
@@ -1319,10 +1347,12 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   if (nsplit > 1 && g_defer && (p.flags & ST5_GEMM_DEFERRABLE) && !p.C.rpb && p.C.ld % 4 == 0) {
     const size_t need = ((size_t)nsplit * p.M * p.N + (p.asum ? (size_t)nsplit * p.M : 0)) * sizeof(float);
     // the same output twice in one batch (tied weights) would race inside the batched reduction: fold what is pending first
+    DeferState* ds = defer_state(s, true);
+    if (!ds) return ST5_ERR_LAUNCH;
     for (int j = 0; j < g_pending.n; ++j)
       if (g_pending.d[j].C == p.C.ptr) { const int rc = flush_pending(s); if (rc) return rc; break; }
     if (g_pending.n == MR_MAX) { const int rc = flush_pending(s); if (rc) return rc; }
-    float* slabs = arena_take(need);
+    float* slabs = arena_take(ds, need);
     if (!slabs) {
       const int rc = flush_pending(s);
       if (rc) return rc;
@@ -1333,7 +1363,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
         if (hipMalloc(&g_arena, want) != hipSuccess) { g_arena = nullptr; g_arena_bytes = 0; return ST5_ERR_LAUNCH; }
         g_arena_bytes = want;
       }
-      slabs = arena_take(need);
+      slabs = arena_take(ds, need);
       if (!slabs) return ST5_ERR_LAUNCH;
     }
     st5_gemm_params q = p;
@@ -1381,10 +1411,19 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   return launch<float>(p, c_vec_ok, nsplit, s);
 }
 
+#undef g_pending
+#undef g_pending_blocks
+#undef g_arena
+#undef g_arena_bytes
+#undef g_arena_used
+
 /* Deferred split-K reductions (see splitk_multi_reduce_kernel).  While enabled, outputs of split-K GEMMs are complete only
  * after st5_gemm_flush_splitk(); disabling flushes. */
 extern "C" int st5_gemm_defer_splitk(int enabled, void* stream) {
-  if (!enabled && g_defer) { const int rc = flush_pending(reinterpret_cast<hipStream_t>(stream)); if (rc) return rc; }
+  (void)stream;
+  if (!enabled && g_defer) {   // fold whatever is queued, every state on its own stream
+    for (int i = 0; i < g_ndstates; ++i) { const int rc = flush_state(&g_dstates[i]); if (rc) return rc; }
+  }
   g_defer = enabled != 0;
   return ST5_OK;
 }

@@ -356,17 +356,37 @@ __global__ __launch_bounds__(1024) void ln_bwd_final_multi_kernel(const LnFinalA
   }
 }
 bool g_ln_defer = false;
-LnFinalArgs g_ln_pending;
-int g_ln_blocks = 0;
-float* g_ln_arena = nullptr;
-size_t g_ln_arena_bytes = 0, g_ln_arena_used = 0;
-int ln_flush(hipStream_t s) {
-  if (g_ln_pending.n == 0) return ST5_OK;
-  hipLaunchKernelGGL(ln_bwd_final_multi_kernel, dim3((unsigned)g_ln_blocks), dim3(1024), 0, s, g_ln_pending);
+// deferred-reduction state, one per stream (as the split-K states of gemm.hip: two backward passes may run on two streams)
+struct LnDeferState { hipStream_t stream; LnFinalArgs pending; int blocks; float* arena; size_t arena_bytes, arena_used; };
+constexpr int LN_DEFER_STREAMS = 4;
+LnDeferState g_lnstates[LN_DEFER_STREAMS] = {};
+int g_nlnstates = 0;
+LnDeferState* ln_state(hipStream_t s, bool create) {
+  for (int i = 0; i < g_nlnstates; ++i)
+    if (g_lnstates[i].stream == s) return &g_lnstates[i];
+  if (!create) return nullptr;
+  if (g_nlnstates == LN_DEFER_STREAMS) {
+    for (int i = 0; i < g_nlnstates; ++i)
+      if (g_lnstates[i].pending.n == 0) { g_lnstates[i].stream = s; return &g_lnstates[i]; }
+    return nullptr;
+  }
+  LnDeferState* d = &g_lnstates[g_nlnstates++];
+  d->stream = s; d->pending.n = 0; d->blocks = 0; d->arena = nullptr; d->arena_bytes = d->arena_used = 0;
+  return d;
+}
+#define g_ln_pending (ls->pending)
+#define g_ln_blocks (ls->blocks)
+#define g_ln_arena (ls->arena)
+#define g_ln_arena_bytes (ls->arena_bytes)
+#define g_ln_arena_used (ls->arena_used)
+int ln_flush_state(LnDeferState* ls) {
+  if (!ls || g_ln_pending.n == 0) return ST5_OK;
+  hipLaunchKernelGGL(ln_bwd_final_multi_kernel, dim3((unsigned)g_ln_blocks), dim3(1024), 0, ls->stream, g_ln_pending);
   g_ln_pending.n = 0; g_ln_blocks = 0; g_ln_arena_used = 0;
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
+int ln_flush(hipStream_t s) { return ln_flush_state(ln_state(s, false)); }
 
 int ln_blocks(long long rows) {
   long long n = (rows + 4 * RPW - 1) / (4 * RPW);
@@ -514,6 +534,8 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
     const size_t shm = pg ? (size_t)8 * cols * sizeof(float) : 0;
     bool deferred = false;
     if (pg && g_ln_defer) {
+      LnDeferState* ls = ln_state(s, true);
+      if (!ls) return ST5_ERR_LAUNCH;
       // the same parameter twice in one batch (two micro-batches) would race inside the batched reduction: fold first
       for (int j = 0; j < g_ln_pending.n; ++j)
         if ((dgamma && g_ln_pending.d[j].dgamma == dgamma) || (dbeta && g_ln_pending.d[j].dbeta == dbeta)) {
@@ -586,10 +608,18 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
   return ST5_OK;
 }
 
+#undef g_ln_pending
+#undef g_ln_blocks
+#undef g_ln_arena
+#undef g_ln_arena_bytes
+#undef g_ln_arena_used
 /* Deferred dgamma / dbeta reductions (see ln_bwd_final_multi_kernel).  While enabled, the parameter gradients of
  * st5_layernorm_bwd (vector path) are complete only after st5_layernorm_flush() on the same stream; disabling flushes. */
 extern "C" int st5_layernorm_defer(int enabled, void* stream) {
-  if (!enabled && g_ln_defer) { const int rc = ln_flush(reinterpret_cast<hipStream_t>(stream)); if (rc) return rc; }
+  (void)stream;
+  if (!enabled && g_ln_defer) {
+    for (int i = 0; i < g_nlnstates; ++i) { const int rc = ln_flush_state(&g_lnstates[i]); if (rc) return rc; }
+  }
   g_ln_defer = enabled != 0;
   return ST5_OK;
 }

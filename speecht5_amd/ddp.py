@@ -109,7 +109,8 @@ class FlatGradDataParallel:
         # it AND every bucket before it has been reported ready -- and finish() launches the rest, again in index order.
         # A rank that skipped a layer (LayerDrop, another modality) simply defers from that bucket on; it never reorders.
         self._accumulating = False
-        self._fwd_streams = []   # forward streams of micro-batches 1.. (accumulate_overlapped)
+        self._fwd_streams = []   # streams of micro-batches 1.. (accumulate_overlapped)
+        self.flat2 = None        # second gradient buffer (accumulate_overlapped), allocated on first use
         self._ready = [False] * len(self.buckets)
         self._next = 0
         self._works = []
@@ -200,16 +201,20 @@ class FlatGradDataParallel:
                 out.append(fn(mb))
         return out
 
-    def accumulate_overlapped(self, micro_batches, forward_loss):
-        """The micro-batches of one update with their FORWARD passes side by side: forward_loss(sample) -> normalised loss
-        tensor (forward only).  Micro-batch 0 runs on the current stream, micro-batch i on its own stream (forked here); the
-        backward passes then run one after the other (they accumulate into the same gradient buffers), every one except the
-        last under no_sync().  Autograd runs a node's backward on the stream of its forward, so micro-batch i's backward stays
-        on its stream; the engine orders it behind the previous backward (its root gradient is produced on the current stream)
-        and makes the current stream wait for it at the end.  Measured on the two micro-batches of the pre-training update
-        (speech 8 x 10 s, text 16 x 512; graph replay): forward pair 14.5 -> 10.8 ms (tools/fwd_overlap.py) -- the forward
-        passes are strings of small kernels that leave most of the chip idle on their own."""
+    def accumulate_overlapped(self, micro_batches, forward_loss, backward="side_by_side"):
+        """The (two) micro-batches of one update on two streams: forward_loss(sample) -> normalised loss tensor (forward only).
+        Micro-batch 0 runs on the current stream, micro-batch 1 on its own stream, forked here; autograd runs a node's backward
+        on the stream of its forward.  backward = "side_by_side": micro-batch 1 accumulates into a SECOND flat gradient buffer
+        (its param.grad views are switched while its backward is enqueued), so the two backward passes are independent and run
+        concurrently; the buffers are summed afterwards.  backward = "in_turn": same two buffers, same arithmetic, the second
+        backward ordered behind the first (bit-identical results: the race check of tests/test_graph_gpu.py).  One rank only
+        (bucket all-reduces need the summed gradients; the multi-rank path uses accumulate()).
+        Measured on the pre-training update (speech 8 x 10 s + text 16 x 512, graph replay): in turn 47.8 ms, forward passes side
+        by side 44.8 ms, forward and backward side by side 37.4 ms -- on their own the micro-batches are strings of kernels that
+        leave much of the chip idle (the reference's trainer runs them in turn, trainer semantics unchanged)."""
+        from . import hip
         n = len(micro_batches)
+        assert n <= 2 and not self.collectives, "accumulate_overlapped: one rank, at most two micro-batches per update"
         cur = torch.cuda.current_stream()
         while len(self._fwd_streams) < n - 1:
             self._fwd_streams.append(torch.cuda.Stream(device=self.flat.device))
@@ -223,11 +228,38 @@ class FlatGradDataParallel:
                 with torch.cuda.stream(self._fwd_streams[i - 1]):
                     losses.append(forward_loss(mb))
         for i, loss in enumerate(losses):
-            with (self.no_sync() if i + 1 < n else contextlib.nullcontext()):
-                loss.backward()
+            st = cur if i == 0 else self._fwd_streams[i - 1]
+            if i > 0 and backward == "in_turn":
+                st.wait_stream(cur)      # (behind micro-batch 0's backward)
+            with self._grad_slot(i), torch.cuda.stream(st):
+                loss.backward()          # (root gradient on `st`: no dependence on the other micro-batch's stream)
+                # this stream's deferred reductions (split-K slabs, LayerNorm partials) are folded on this stream
+                hip.check(hip.lib().st5_layernorm_flush(hip.stream()), "st5_layernorm_flush")
+                hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")
         for st in self._fwd_streams[: n - 1]:
             cur.wait_stream(st)
+        if n > 1:   # flat += flat2
+            hip.check(hip.lib().st5_axpby(self.flat2.data_ptr(), self.flat.data_ptr(), self.flat.numel(), 1.0, 1.0, hip.F32, hip.stream()),
+                      "st5_axpby")
         return [l.detach() for l in losses]
+
+    @contextlib.contextmanager
+    def _grad_slot(self, slot):
+        """param.grad -> views of gradient buffer `slot` (0 = the flat buffer, 1 = its twin) while a backward is enqueued."""
+        if slot == 0:
+            yield
+            return
+        if self.flat2 is None:
+            self.flat2 = torch.zeros_like(self.flat)
+            self._views2 = [self.flat2[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
+            self._views1 = [p.grad for p in self.params]
+        for p, v in zip(self.params, self._views2):
+            p.grad = v
+        try:
+            yield
+        finally:
+            for p, v in zip(self.params, self._views1):
+                p.grad = v
 
     # -- step API ----------------------------------------------------------------------------------
     def close(self):
@@ -248,6 +280,8 @@ class FlatGradDataParallel:
     def zero_grad(self):
         assert not self._works, "zero_grad() between backward and finish(): all-reduces are in flight"
         self.flat.zero_()
+        if self.flat2 is not None:
+            self.flat2.zero_()
         self._reset_round()
 
     def check_grad_views(self):

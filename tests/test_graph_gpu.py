@@ -50,12 +50,13 @@ def _run(cuda, dtype, mode, nsteps=3, seed_offset=0):
         torch.manual_seed(5 + seed_offset)
         n = [0]
 
-        overlap = mode.endswith("_overlap")
+        overlap = "_overlap" in mode
 
         def step():
             ddp.zero_grad()
-            if overlap:   # forward passes of the two micro-batches side by side on two streams
-                ddp.accumulate_overlapped(micro, lambda s: task.forward_loss(s, model, crit, n[0]))
+            if overlap:   # the two micro-batches on two streams (second one into its own gradient buffer)
+                ddp.accumulate_overlapped(micro, lambda s: task.forward_loss(s, model, crit, n[0]),
+                                          backward="in_turn" if mode.endswith("_turn") else "side_by_side")
             else:
                 ddp.accumulate(micro, lambda s: task.train_step(s, model, crit, None, n[0], sync=False))
             ddp.finish()
@@ -124,20 +125,26 @@ def test_replay_with_host_prefetch_thread_equals_plain_replay(cuda):
         assert torch.equal(x, y), name
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_micro_batch_forwards_side_by_side_equal_in_turn(cuda, dtype):
-    """ddp.accumulate_overlapped (forward passes of the update's two micro-batches on two streams, backward passes in turn) against
-    ddp.accumulate, eager and replayed: the same kernels with the same seeds -- in bf16 any difference at all would be a race."""
-    ref = _run(cuda, dtype, "static", 4)
+def test_micro_batches_side_by_side_equal_in_turn(cuda):
+    """ddp.accumulate_overlapped: the update's two micro-batches on two streams, the second accumulating into its own gradient
+    buffer.  backward="side_by_side" (both backward passes concurrently) against backward="in_turn" (the same arithmetic with
+    the second backward ordered behind the first), eager and replayed: bf16, so ANY difference would be a race."""
+    ref = _run(cuda, torch.bfloat16, "static_overlap_turn", 4)
     for mode in ("static_overlap", "graph_overlap"):
-        got = _run(cuda, dtype, mode, 4)
+        got = _run(cuda, torch.bfloat16, mode, 4)
         assert got[3] == ref[3] == 4
         for x, y, name in zip(ref[:3], got[:3], ("parameters", "first moment", "second moment")):
-            if dtype == torch.bfloat16:
-                assert torch.equal(x, y), f"{mode}: {name}"
-            else:
-                d = float((x - y).abs().max())
-                assert d <= 2e-5 * max(1.0, float(x.abs().max())), f"{mode}: {name} differ by {d:.3e}"
+            assert torch.equal(x, y), f"{mode}: {name}"
+
+
+def test_two_gradient_buffers_equal_one(cuda):
+    """... and the two-buffer scheme against plain accumulation into one buffer (ddp.accumulate): the same sums up to the order
+    of fp32 additions for parameters with several contributions (fp32 compute mode: no bf16 rounding to amplify that)."""
+    ref = _run(cuda, torch.float32, "static", 3)
+    got = _run(cuda, torch.float32, "static_overlap", 3)
+    for x, y, name in zip(ref[:3], got[:3], ("parameters", "first moment", "second moment")):
+        d = float((x - y).abs().max())
+        assert d <= 2e-5 * max(1.0, float(x.abs().max())), f"{name} differ by {d:.3e}"
 
 
 def test_fixed_shape_form_equals_reference_shaped_form(cuda):
