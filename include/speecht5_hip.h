@@ -370,6 +370,12 @@ int st5_layernorm_set_max_blocks(int n);
 int st5_ctc_initial_state(const float* x, int32_t T, int32_t V, int32_t blank, float* r, void* stream);
 int st5_ctc_prefix_score(const float* x, int32_t T, int32_t V, int32_t blank, int32_t eos, const float* r_prev, const int64_t* last,
                          int32_t out_len, const int64_t* cs, int32_t nh, int32_t nc, float* log_psi, float* r_new, void* stream);
+/* ... over TWO gradient buffers: the step uses g + g2 (g2 may be NULL); zero_grads != 0 leaves both buffers zeroed.  With
+ * st5_sumsq_pair (sum of squares of x + y) for the clipping norm this replaces "g += g2", two fills and the plain step. */
+int st5_adam_step_pair(float* p, float* g, float* g2, int32_t zero_grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
+                       void* bf16_mirror, const float* hyper_dev, void* stream);
+int st5_sumsq_pair(const float* x, const float* y, float* out, int64_t n, float scale, int32_t accumulate, void* stream);
 /* Dropout seeds: every `seed` argument of this library may instead be a device pointer to the 64-bit seed, tagged with bit 63
  * (seed = (1 << 63) | pointer): the kernels then read the seed from memory (csrc/common.h resolve_seed).  Used by captured HIP
  * graphs, whose kernel arguments cannot change between replays. */

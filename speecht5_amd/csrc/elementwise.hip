@@ -116,6 +116,25 @@ __global__ void sumsq_kernel(const T* __restrict__ x, float* __restrict__ part, 
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// sum of squares of x + y (fp32): the gradient norm over two gradient buffers
+__global__ void sumsq_pair_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ part, long long n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long long nv = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[i], b = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float v = a[e] + b[e]; s = fmaf(v, v, s); }
+  }
+  for (long long i = nv * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = x[i] + y[i];
+    s = fmaf(v, v, s);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
 __global__ void sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int n, float scale,
                                  int accumulate) {
   __shared__ double red[4];
@@ -566,6 +585,17 @@ extern "C" int st5_sumsq(const void* x, float* out, int64_t n, float scale, int3
   dim3 grid = grid_for(n / 8 + 1);
   DISPATCH(dtype, hipLaunchKernelGGL(sumsq_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, part, (long long)n),
            hipLaunchKernelGGL(sumsq_kernel<float>, grid, dim3(256), 0, s, (const float*)x, part, (long long)n));
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, s, part, out, (int)grid.x, scale, accumulate);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_sumsq_pair(const float* x, const float* y, float* out, int64_t n, float scale, int32_t accumulate, void* stream) {
+  if (!x || !y || !out || n < 0) return ST5_ERR_ARG;
+  float* part = scratch();
+  if (!part) return ST5_ERR_LAUNCH;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid = grid_for(n / 8 + 1);
+  hipLaunchKernelGGL(sumsq_pair_kernel, grid, dim3(256), 0, s, x, y, part, (long long)n);
   hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, s, part, out, (int)grid.x, scale, accumulate);
   HIP_CHECK_LAUNCH();
   return ST5_OK;

@@ -9,7 +9,9 @@
 namespace {
 // hyper: optional device array {lr, step} that overrides the by-value lr / step count (a captured HIP graph replays
 // constant kernel arguments; the host refreshes these two floats before every replay)
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+// g2 (optional): second gradient buffer, the step uses g + g2 (two micro-batches accumulated side by side, ddp.py);
+// zero_grads: both buffers are left zeroed (saves the two fill launches of the next zero_grad()).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ g2, int zero_grads,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ mirror, long long n,
                                                    float lr, float b1, float b2, float eps, float wd, float t,
@@ -30,7 +32,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   const long long nv = n / 4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
-    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+    if (g2) {
+      const f32x4 g2v = reinterpret_cast<const f32x4*>(g2)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gg[e] += g2v[e];
+    }
+    if (zero_grads) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<f32x4*>(g)[i] = z;
+      if (g2) reinterpret_cast<f32x4*>(g2)[i] = z;
+    }
     f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
     f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
@@ -53,7 +65,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
   for (long long i = nv * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    const float ge = g[i] * coef;
+    const float ge = (g[i] + (g2 ? g2[i] : 0.f)) * coef;
+    if (zero_grads) { g[i] = 0.f; if (g2) g2[i] = 0.f; }
     const float mi = b1 * m[i] + (1.f - b1) * ge;
     const float vi = b2 * v[i] + (1.f - b2) * ge * ge;
     m[i] = mi; v[i] = vi;
@@ -93,6 +106,9 @@ __global__ __launch_bounds__(256) void multi_transpose_kernel(const bf16_t* __re
 extern "C" int st5_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                                  float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
                                  void* bf16_mirror, const float* hyper_dev, void* stream);
+extern "C" int st5_adam_step_pair(float* p, float* g, float* g2, int32_t zero_grads, float* m, float* v, int64_t n, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm,
+                                  float grad_scale, void* bf16_mirror, const float* hyper_dev, void* stream);
 
 extern "C" int st5_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int32_t step, const float* gnorm_sq,
@@ -104,12 +120,19 @@ extern "C" int st5_adam_step(float* p, const float* g, float* m, float* v, int64
 extern "C" int st5_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                                  float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
                                  void* bf16_mirror, const float* hyper_dev, void* stream) {
+  return st5_adam_step_pair(p, const_cast<float*>(g), nullptr, 0, m, v, n, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq, max_norm,
+                            grad_scale, bf16_mirror, hyper_dev, stream);
+}
+
+extern "C" int st5_adam_step_pair(float* p, float* g, float* g2, int32_t zero_grads, float* m, float* v, int64_t n, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm,
+                                  float grad_scale, void* bf16_mirror, const float* hyper_dev, void* stream) {
   if (!p || !g || !m || !v || n < 0 || (step < 1 && !hyper_dev)) return ST5_ERR_ARG;
   if (n == 0) return ST5_OK;
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)bf16_mirror,
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, g2, zero_grads, m, v, (bf16_t*)bf16_mirror,
                      (long long)n,
                      lr, beta1, beta2, eps, weight_decay, (float)step, gnorm_sq, max_norm, grad_scale, hyper_dev);
   HIP_CHECK_LAUNCH();

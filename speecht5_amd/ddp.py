@@ -111,6 +111,8 @@ class FlatGradDataParallel:
         self._accumulating = False
         self._fwd_streams = []   # streams of micro-batches 1.. (accumulate_overlapped)
         self.flat2 = None        # second gradient buffer (accumulate_overlapped), allocated on first use
+        self._pair_pending = False   # flat2 holds gradients not yet summed into flat
+        self._grads_zeroed = False   # the optimizer left both buffers zeroed: the next zero_grad() has nothing to do
         self._ready = [False] * len(self.buckets)
         self._next = 0
         self._works = []
@@ -238,10 +240,19 @@ class FlatGradDataParallel:
                 hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")
         for st in self._fwd_streams[: n - 1]:
             cur.wait_stream(st)
-        if n > 1:   # flat += flat2
+        # the update's gradient is flat + flat2: FusedAdam.step reads both (and leaves both zeroed); anyone else gets the sum
+        # through sum_gradient_buffers()
+        self._pair_pending = n > 1
+        return [l.detach() for l in losses]
+
+    def sum_gradient_buffers(self):
+        """flat += flat2 (second micro-batch's gradients of accumulate_overlapped) when that sum is still outstanding."""
+        from . import hip
+        if self._pair_pending:
             hip.check(hip.lib().st5_axpby(self.flat2.data_ptr(), self.flat.data_ptr(), self.flat.numel(), 1.0, 1.0, hip.F32, hip.stream()),
                       "st5_axpby")
-        return [l.detach() for l in losses]
+            self.flat2.zero_()
+            self._pair_pending = False
 
     @contextlib.contextmanager
     def _grad_slot(self, slot):
@@ -279,9 +290,13 @@ class FlatGradDataParallel:
 
     def zero_grad(self):
         assert not self._works, "zero_grad() between backward and finish(): all-reduces are in flight"
-        self.flat.zero_()
-        if self.flat2 is not None:
-            self.flat2.zero_()
+        if self._grads_zeroed:
+            self._grads_zeroed = False      # (FusedAdam's kernel zeroed them while reading)
+        else:
+            self.flat.zero_()
+            if self.flat2 is not None:
+                self.flat2.zero_()
+        self._pair_pending = False
         self._reset_round()
 
     def check_grad_views(self):
@@ -304,6 +319,8 @@ class FlatGradDataParallel:
         assert not self._accumulating, "finish() inside no_sync()"
         self.check_grad_views()
         self._flush_splitk()
+        if self.collectives:
+            self.sum_gradient_buffers()
         if self.collectives:
             self._launch_in_order(True)
             for w in self._works:
@@ -462,13 +479,28 @@ class FusedAdam:
         self.t += 1
         L = hip.lib()
         g = self.ddp.flat
-        if self.clip > 0:
-            hip.check(L.st5_sumsq(g.data_ptr(), self.gnorm_sq.data_ptr(), g.numel(), 1.0, 0, hip.F32, hip.stream()), "st5_sumsq")
-        hip.check(L.st5_adam_step_dev(self.pflat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), g.numel(), self.lr,
-                                      self.betas[0], self.betas[1], self.eps, self.wd, self.t,
-                                      self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
-                                      self.wflat.data_ptr() if self.mirror is not None else 0, hip.ptr(self.hyper_dev), hip.stream()),
-                  "st5_adam_step_dev")
+        if self.ddp._pair_pending and self.ddp.world == 1:
+            # two gradient buffers (ddp.accumulate_overlapped): norm and update over g + g2 in the kernels themselves, both
+            # buffers left zeroed -- no "g += g2" pass, no fills before the next update
+            g2 = self.ddp.flat2
+            if self.clip > 0:
+                hip.check(L.st5_sumsq_pair(g.data_ptr(), g2.data_ptr(), self.gnorm_sq.data_ptr(), g.numel(), 1.0, 0, hip.stream()), "st5_sumsq_pair")
+            hip.check(L.st5_adam_step_pair(self.pflat.data_ptr(), g.data_ptr(), g2.data_ptr(), 1, self.m.data_ptr(), self.v.data_ptr(), g.numel(),
+                                           self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                           self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
+                                           self.wflat.data_ptr() if self.mirror is not None else 0, hip.ptr(self.hyper_dev), hip.stream()),
+                      "st5_adam_step_pair")
+            self.ddp._pair_pending = False
+            self.ddp._grads_zeroed = True
+        else:
+            self.ddp.sum_gradient_buffers()
+            if self.clip > 0:
+                hip.check(L.st5_sumsq(g.data_ptr(), self.gnorm_sq.data_ptr(), g.numel(), 1.0, 0, hip.F32, hip.stream()), "st5_sumsq")
+            hip.check(L.st5_adam_step_dev(self.pflat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), g.numel(), self.lr,
+                                          self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                          self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
+                                          self.wflat.data_ptr() if self.mirror is not None else 0, hip.ptr(self.hyper_dev), hip.stream()),
+                      "st5_adam_step_dev")
         # parameters changed in place through the flat view: invalidate the compute-dtype weight cache (entries that do
         # not come from the bf16 image: conv / fp32 / non-adjacent stacks) and refresh the transposed copies
         Fn.weight_cache.clear()

@@ -133,6 +133,9 @@ _SIGS = {
     "st5_gather3": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64, c_int32, c_int, c_void_p]),
     "st5_zero_time_edges": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "st5_layernorm_set_max_blocks": (c_int, [c_int]),
+    "st5_adam_step_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                                   c_int32, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "st5_sumsq_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int32, c_void_p]),
     "st5_ctc_initial_state": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "st5_ctc_prefix_score": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32,
                                      c_void_p, c_void_p, c_void_p]),
