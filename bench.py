@@ -119,6 +119,8 @@ def main():
     wgrad_env = os.environ.get("ST5_WGRAD_STREAM")
     # replayed step: forward passes of the two micro-batches side by side, no weight-gradient stream (see ddp.py); eager step:
     # the weight-gradient stream hides ~3.5 ms of dW GEMMs behind the data-gradient chain
+    if os.environ.get("ST5_NT_TILE"):   # A/B: 1 = 128x128 always, 2 = 256x256 always (default: per problem)
+        hip.lib().st5_gemm_set_nt_tile(int(os.environ["ST5_NT_TILE"]))
     ddp = FlatGradDataParallel(model, wgrad_stream=(wgrad_env == "1") if wgrad_env is not None else not (use_graph and overlap_fwd))
     opt = FusedAdam(ddp, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0)
     Fn.manual_seed(1337 + rank)
