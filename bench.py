@@ -111,11 +111,15 @@ def main():
     from speecht5_amd.synthetic import speech_pretrain_sample, text_pretrain_sample
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     args, task, model, crit = build(device, dtype)
-    # One rank: the update is captured into a HIP graph after the warm-up steps and REPLAYED in the timed region (fresh dropout
-    # seeds / span masks / lr per replay: speecht5_amd/graph.py).  Several ranks: eager enqueue (RCCL collectives stay outside
-    # graphs here).  ST5_GRAPH=0 or --no-graph forces the eager path.
-    use_graph = world == 1 and not a.no_graph and os.environ.get("ST5_GRAPH", "1") == "1" and not dist.is_initialized()
+    # The update is captured into a HIP graph after the warm-up steps and REPLAYED in the timed region (fresh dropout
+    # seeds / span masks / lr per replay: speecht5_amd/graph.py).  ST5_GRAPH=0 or --no-graph: eager enqueue (with the bucketed
+    # all-reduces overlapped with the backward when there are several ranks).
+    use_graph = not a.no_graph and os.environ.get("ST5_GRAPH", "1") == "1"
     overlap_fwd = use_graph and os.environ.get("ST5_OVERLAP_FWD", "1") == "1"   # (eager enqueue is host-bound: nothing to gain)
+    # several ranks: the captured part is the local phase (both micro-batches, no collectives); ONE all-reduce of the flat
+    # gradient buffer and the Adam step follow every replay eagerly (ddp.local_phase / all_reduce_gradients)
+    split_update = use_graph and dist.is_initialized()
+    assert overlap_fwd or not split_update, "replayed multi-rank update: needs the side-by-side micro-batches (ST5_OVERLAP_FWD=1)"
     wgrad_env = os.environ.get("ST5_WGRAD_STREAM")
     # replayed step: forward passes of the two micro-batches side by side, no weight-gradient stream (see ddp.py); eager step:
     # the weight-gradient stream hides ~3.5 ms of dW GEMMs behind the data-gradient chain
@@ -132,11 +136,25 @@ def main():
     text = text_pretrain_sample(B=16, T=512, vocab=vocab, mask_idx=task.dicts["text"].index("<mask>"), device=device, seed=2337 + rank)
     micro = [speech, text]
 
+    def local_part(i):   # (split_update) what the graph holds: gradients of this rank's two micro-batches, summed into ddp.flat
+        ddp.zero_grad()
+        with ddp.local_phase():
+            ddp.accumulate_overlapped(micro, lambda s: task.forward_loss(s, model, crit, i))
+        ddp.sum_gradient_buffers()
+
+    def exchange_and_update():   # (split_update) eager tail: sum over ranks, then mean over ranks and micro-batches inside Adam
+        ddp.all_reduce_gradients(average=False)
+        opt.step(grad_scale=1.0 / (len(micro) * world))
+
     def step(i):
+        if split_update:
+            local_part(i)
+            exchange_and_update()
+            return
         ddp.zero_grad()
         # --update-freq 2: gradients of the first micro-batch only accumulate (no_sync); the bucket all-reduces are
         # launched from the backward of the LAST micro-batch, each bucket once, after its last local contribution
-        if overlap_fwd:   # forward passes of the two micro-batches side by side on two streams, backward passes in turn
+        if overlap_fwd:   # the two micro-batches side by side on two streams, forward and backward (two gradient buffers)
             ddp.accumulate_overlapped(micro, lambda s: task.forward_loss(s, model, crit, i))
         else:
             ddp.accumulate(micro, lambda s: task.train_step(s, model, crit, None, i, sync=False))
@@ -151,7 +169,7 @@ def main():
     counter = [0]
 
     def one_update():
-        step(counter[0])
+        (local_part if split_update else step)(counter[0])
 
     def advance():   # host-side state a replayed step does not touch: the update counter behind the quantizer temperature etc.
         counter[0] += 1
@@ -159,7 +177,8 @@ def main():
 
     if use_graph:
         from speecht5_amd.graph import StepGraph
-        sg = StepGraph(one_update, opt=opt, model=model, device=device, on_step=advance, prefetch_host=os.environ.get("ST5_PREFETCH_HOST", "1") == "1")
+        sg = StepGraph(one_update, opt=opt, model=model, device=device, on_step=advance, prefetch_host=os.environ.get("ST5_PREFETCH_HOST", "1") == "1",
+                       after_fn=exchange_and_update if split_update else None)
         for i in range(max(a.warmup - 2, 1)):
             step(i)
         counter[0] = max(a.warmup - 2, 1) - 1
@@ -249,7 +268,8 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "SpeechT5-Base pretrain step (speech 8x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
                                       "fwd+bwd+allreduce+clip+Adam, per GPU", "arch": "t5_transformer_base (12 enc + 6 dec, d=768)",
-                          "enqueue": "hip-graph replay" if use_graph else "eager", "micro_batches": "forward and backward side by side on two streams, two gradient buffers" if overlap_fwd else "in turn",
+                          "enqueue": ("hip-graph replay of the local phase + eager all-reduce (one message) + Adam" if split_update else
+                                      "hip-graph replay" if use_graph else "eager"), "micro_batches": "forward and backward side by side on two streams, two gradient buffers" if overlap_fwd else "in turn",
                           "global_speech_batch": a.batch * world, "clip_seconds": 10, "parallelism": f"dp{world}",
                           "dropout": 0.1, "layerdrop": 0.0},
                "roofline": roof}

@@ -109,6 +109,7 @@ class FlatGradDataParallel:
         # it AND every bucket before it has been reported ready -- and finish() launches the rest, again in index order.
         # A rank that skipped a layer (LayerDrop, another modality) simply defers from that bucket on; it never reorders.
         self._accumulating = False
+        self._local_phase = False   # local_phase(): no bucket triggers, gradients reduced afterwards by all_reduce_gradients()
         self._fwd_streams = []   # streams of micro-batches 1.. (accumulate_overlapped)
         self.flat2 = None        # second gradient buffer (accumulate_overlapped), allocated on first use
         self._pair_pending = False   # flat2 holds gradients not yet summed into flat
@@ -150,7 +151,7 @@ class FlatGradDataParallel:
     # -- hooks -------------------------------------------------------------------------------------
     def _boundary(self, x, module, tag=None):
         bi = self.module_bucket.get((id(module), tag))
-        if bi is None or not self.collectives or not x.requires_grad:
+        if bi is None or not self.collectives or self._local_phase or not x.requires_grad:
             return x
         return _Trigger.apply(x, self, bi)
 
@@ -209,14 +210,16 @@ class FlatGradDataParallel:
         on the stream of its forward.  backward = "side_by_side": micro-batch 1 accumulates into a SECOND flat gradient buffer
         (its param.grad views are switched while its backward is enqueued), so the two backward passes are independent and run
         concurrently; the buffers are summed afterwards.  backward = "in_turn": same two buffers, same arithmetic, the second
-        backward ordered behind the first (bit-identical results: the race check of tests/test_graph_gpu.py).  One rank only
-        (bucket all-reduces need the summed gradients; the multi-rank path uses accumulate()).
+        backward ordered behind the first (bit-identical results: the race check of tests/test_graph_gpu.py).  Several ranks: only
+        inside local_phase() (the bucket all-reduces of the overlapped path need summed gradients: that path uses accumulate()).
         Measured on the pre-training update (speech 8 x 10 s + text 16 x 512, graph replay): in turn 47.8 ms, forward passes side
         by side 44.8 ms, forward and backward side by side 37.4 ms -- on their own the micro-batches are strings of kernels that
         leave much of the chip idle (the reference's trainer runs them in turn, trainer semantics unchanged)."""
         from . import hip
         n = len(micro_batches)
-        assert n <= 2 and not self.collectives, "accumulate_overlapped: one rank, at most two micro-batches per update"
+        assert n <= 2, "accumulate_overlapped: at most two micro-batches per update"
+        assert not self.collectives or self._local_phase, \
+            "accumulate_overlapped with several ranks: inside local_phase(), followed by all_reduce_gradients()"
         cur = torch.cuda.current_stream()
         while len(self._fwd_streams) < n - 1:
             self._fwd_streams.append(torch.cuda.Stream(device=self.flat.device))
@@ -245,12 +248,41 @@ class FlatGradDataParallel:
         self._pair_pending = n > 1
         return [l.detach() for l in losses]
 
+    @contextlib.contextmanager
+    def local_phase(self):
+        """Forward + backward of ALL micro-batches of an update with the bucket triggers off: gradients stay local (both
+        buffers of accumulate_overlapped allowed), nothing is enqueued on the process group -- so the whole phase can be captured
+        into a HIP graph on several ranks too.  Follow with all_reduce_gradients() (eager)."""
+        old, self._local_phase = self._local_phase, True
+        try:
+            yield
+        finally:
+            self._local_phase = old
+
+    def all_reduce_gradients(self, average=True):
+        """The exchange step after a local_phase(): ONE all-reduce over the whole flat buffer (same call on every rank, so
+        the order question of the bucketed path does not arise; 617 MB for Base: a single large message is what the xGMI
+        links move fastest).  No overlap with the backward -- the price of replaying the backward as a graph, which saves more
+        (bench.py).  average=False leaves the SUM (the caller folds 1/world into the optimizer's grad_scale)."""
+        assert not self._accumulating and not self._works
+        self.check_grad_views()
+        self._flush_splitk()
+        self.sum_gradient_buffers()
+        if self.collectives:
+            dist.all_reduce(self.flat, group=self.pg)
+            if average and self.world > 1:
+                self.flat.mul_(1.0 / self.world)
+        self._reset_round()
+
     def sum_gradient_buffers(self):
         """flat += flat2 (second micro-batch's gradients of accumulate_overlapped) when that sum is still outstanding."""
         from . import hip
         if self._pair_pending:
-            hip.check(hip.lib().st5_axpby(self.flat2.data_ptr(), self.flat.data_ptr(), self.flat.numel(), 1.0, 1.0, hip.F32, hip.stream()),
-                      "st5_axpby")
+            if self.flat.is_cuda:
+                hip.check(hip.lib().st5_axpby(self.flat2.data_ptr(), self.flat.data_ptr(), self.flat.numel(), 1.0, 1.0, hip.F32, hip.stream()),
+                          "st5_axpby")
+            else:   # (host buffers: the gloo tests of this wrapper's bookkeeping on a stand-in model)
+                self.flat.add_(self.flat2)
             self.flat2.zero_()
             self._pair_pending = False
 

@@ -11,18 +11,23 @@ What makes a training step replayable:
   * data-dependent shapes are replaced by fixed-shape forms while recording (functional.static_shapes(): the NCE head scores
     every frame and passes selection masks; the sample size becomes a device scalar);
   * the optimizer reads the learning rate and step count from device memory (FusedAdam.enable_device_hyper).
-Not supported in a captured step (asserted): LayerDrop (host-side control flow would be frozen), multi-rank collectives
-(the N > 1 path stays eager), host reads of device values."""
+Not supported in a captured step (asserted): LayerDrop (host-side control flow would be frozen), host reads of device values,
+collectives.  Several ranks: the captured part is the LOCAL phase of the update (zero_grad, forward / backward of every
+micro-batch: ddp.local_phase()), and `after_fn` -- gradient all-reduce + optimizer step -- is enqueued eagerly behind every
+replay (a handful of launches)."""
 import torch
 
 from . import functional as Fn
 
 
 class StepGraph:
-    def __init__(self, step_fn, opt=None, model=None, device=None, seed_slots=1024, on_step=None, prefetch_host=False):
+    def __init__(self, step_fn, opt=None, model=None, device=None, seed_slots=1024, on_step=None, prefetch_host=False, after_fn=None):
         """step_fn(): one full update on the current stream -- zero_grad, forward/backward of every micro-batch, finish,
-        optimizer step -- without host synchronisation.  `opt`: the FusedAdam whose (lr, step) must follow the host."""
+        optimizer step -- without host synchronisation.  `opt`: the FusedAdam whose (lr, step) must follow the host.
+        after_fn(): optional eager tail of the update, NOT captured (then step_fn must not contain the optimizer step: after_fn
+        does, after the collectives)."""
         self.step_fn = step_fn
+        self.after_fn = after_fn
         self.on_step = on_step   # host-side bookkeeping a replay skips (e.g. model.set_num_updates(n)): called before every step
         self.opt = opt
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -69,6 +74,8 @@ class StepGraph:
                 self.opt.push_hyper()
             self.slots.begin_step()
             self._run("record")
+            if self.after_fn is not None:
+                self.after_fn()
         cur.wait_stream(self.stream)
         if not self.slots.used:
             self.slots.used = self.slots.k
@@ -86,7 +93,7 @@ class StepGraph:
         with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
             self._run("capture")
         # the capture pass itself executed nothing: the host-side step counter it advanced is rolled back
-        if self.opt is not None:
+        if self.opt is not None and self.after_fn is None:
             self.opt.t = t0
         assert self.slots.k == self.slots.used, "the captured step used a different number of dropout seeds than the recorded one"
         self._pending = True   # buffers are already staged for the first replay
@@ -143,7 +150,9 @@ class StepGraph:
             th.start()
             self._ahead = (th, self._slot)
         self.graph.replay()
-        if self.opt is not None:
+        if self.after_fn is not None:
+            self.after_fn()          # (its optimizer step advances opt.t itself)
+        elif self.opt is not None:
             self.opt.t += 1
 
     def __call__(self):

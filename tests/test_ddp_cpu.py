@@ -63,7 +63,7 @@ def _micro(X, rank, u, U):
     return X[i:i + 4]
 
 
-def _worker(rank, world, port, ret, U, skips):
+def _worker(rank, world, port, ret, U, skips, local=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from speecht5_amd.ddp import FlatGradDataParallel
@@ -86,8 +86,18 @@ def _worker(rank, world, port, ret, U, skips):
         # modality mix: micro-batch (rank + u) odd uses the extra head
         model(_micro(X, rank, u, U), use_extra=((rank + u) % 2 == 1), skip=skips[rank][u]).pow(2).mean().backward()
         during.append(len(launched))
-    ddp.accumulate(list(range(U)), fwd_bwd)
-    ddp.finish()
+    if local:
+        # the replayed-step form (bench.py, N > 1): every micro-batch local, the second one into the twin gradient buffer,
+        # then ONE all-reduce over the whole flat buffer
+        with ddp.local_phase():
+            for u in range(U):
+                with ddp._grad_slot(u % 2):
+                    fwd_bwd(u)
+            ddp._pair_pending = U > 1
+        ddp.all_reduce_gradients()
+    else:
+        ddp.accumulate(list(range(U)), fwd_bwd)
+        ddp.finish()
     dist.all_reduce = orig
     # model.zero_grad() drops the views: the wrapper must notice and re-install them
     model.zero_grad(set_to_none=True)
@@ -115,15 +125,15 @@ def _reference(world, U, skips):
     return {n: v / world for n, v in tot.items()}   # mean over ranks of the per-rank SUM over micro-batches
 
 
-def _run(U, skips):
+def _run(U, skips, local=False):
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() * 7 + U * 13 + len(str(skips))) % 2000
-    mp.spawn(_worker, args=(2, port, ret, U, skips), nprocs=2, join=True)
+    port = 29500 + (os.getpid() * 7 + U * 13 + len(str(skips)) + 5 * local) % 2000
+    mp.spawn(_worker, args=(2, port, ret, U, skips, local), nprocs=2, join=True)
     return ret, _reference(2, U, skips)
 
 
-def _check(ret, ref):
+def _check(ret, ref, one_message=False):
     for r in range(2):
         for n, v in ref.items():
             assert torch.allclose(ret[r]["grads"][n], v, atol=1e-6), (r, n, (ret[r]["grads"][n] - v).abs().max())
@@ -132,7 +142,10 @@ def _check(ret, ref):
     assert torch.equal(ret[0]["flat"], ret[1]["flat"])
     # same collectives in the same order on both ranks, each bucket exactly once, in index order
     assert ret[0]["launched"] == ret[1]["launched"]
-    assert ret[0]["launched"] == [(s, e - s) for s, e in ret[0]["buckets"]]
+    if one_message:
+        assert ret[0]["launched"] == [(0, ret[0]["flat"].numel())]
+    else:
+        assert ret[0]["launched"] == [(s, e - s) for s, e in ret[0]["buckets"]]
 
 
 NOSKIP = [[(), ()], [(), ()]]
@@ -164,3 +177,14 @@ def test_ranks_skipping_different_layers_keep_collective_order():
     skips = [[(), (1,)], [(0,), (2,)]]
     ret, ref = _run(2, skips)
     _check(ret, ref)
+
+
+def test_local_phase_then_one_all_reduce():
+    """local_phase() + all_reduce_gradients(): the form a replayed (HIP graph) update takes on several ranks -- no bucket
+    triggers during either backward, micro-batch 1 into the second gradient buffer, one all-reduce of everything; ranks that
+    skip different layers included.  Same mean as the bucketed path."""
+    skips = [[(), (1,)], [(0,), (2,)]]
+    ret, ref = _run(2, skips, local=True)
+    _check(ret, ref, one_message=True)
+    for r in range(2):
+        assert ret[r]["during"] == [0, 0], "a collective was issued inside local_phase()"

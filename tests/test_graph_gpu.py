@@ -52,7 +52,23 @@ def _run(cuda, dtype, mode, nsteps=3, seed_offset=0):
 
         overlap = "_overlap" in mode
 
+        split = mode.endswith("_split")   # several-rank form: local phase (graph) + one all-reduce + Adam (eager tail)
+
+        def local_part():
+            ddp.zero_grad()
+            with ddp.local_phase():
+                ddp.accumulate_overlapped(micro, lambda s: task.forward_loss(s, model, crit, n[0]))
+            ddp.sum_gradient_buffers()
+
+        def exchange_and_update():
+            ddp.all_reduce_gradients(average=False)
+            opt.step(grad_scale=0.5 / ddp.world)
+
         def step():
+            if split:
+                local_part()
+                exchange_and_update()
+                return
             ddp.zero_grad()
             if overlap:   # the two micro-batches on two streams (second one into its own gradient buffer)
                 ddp.accumulate_overlapped(micro, lambda s: task.forward_loss(s, model, crit, n[0]),
@@ -67,9 +83,10 @@ def _run(cuda, dtype, mode, nsteps=3, seed_offset=0):
             model.set_num_updates(n[0])
             opt.lr = 1e-3 * (1 + 0.1 * n[0])          # a schedule: the replayed step must follow the host's learning rate
 
-        if mode in ("graph", "graph_prefetch", "graph_overlap"):
+        if mode in ("graph", "graph_prefetch", "graph_overlap", "graph_split"):
             from speecht5_amd.graph import StepGraph
-            sg = StepGraph(step, opt=opt, model=model, device=cuda, on_step=advance, prefetch_host=mode == "graph_prefetch")
+            sg = StepGraph(local_part if split else step, opt=opt, model=model, device=cuda, on_step=advance,
+                           prefetch_host=mode == "graph_prefetch", after_fn=exchange_and_update if split else None)
             sg.record(); sg.record(); sg.capture()
             for _ in range(nsteps - 2):
                 sg.replay()
@@ -135,6 +152,27 @@ def test_micro_batches_side_by_side_equal_in_turn(cuda):
         assert got[3] == ref[3] == 4
         for x, y, name in zip(ref[:3], got[:3], ("parameters", "first moment", "second moment")):
             assert torch.equal(x, y), f"{mode}: {name}"
+
+
+def test_replayed_local_phase_with_eager_all_reduce_and_adam(cuda):
+    """The several-rank form of the replayed update (bench.py --gpus N > 1): graph = zero_grad + both micro-batches under
+    ddp.local_phase() + buffer sum; behind every replay, eagerly, ONE all-reduce of the flat buffer (RCCL, here a one-rank
+    group: ST5_DDP_FORCE_COLLECTIVES) and the Adam step.  Bit for bit the one-rank replayed update, eager and replayed."""
+    import os
+    import torch.distributed as dist
+    ref = _run(cuda, torch.bfloat16, "graph_overlap", 5)
+    os.environ["ST5_DDP_FORCE_COLLECTIVES"] = "1"
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29600 + os.getpid() % 300}", rank=0, world_size=1,
+                            device_id=cuda)
+    try:
+        for mode in ("static_split", "graph_split"):
+            got = _run(cuda, torch.bfloat16, mode, 5)
+            assert got[3] == ref[3] == 5
+            for x, y, name in zip(ref[:3], got[:3], ("parameters", "first moment", "second moment")):
+                assert torch.equal(x, y), f"{mode}: {name}"
+    finally:
+        dist.destroy_process_group()
+        del os.environ["ST5_DDP_FORCE_COLLECTIVES"]
 
 
 def test_two_gradient_buffers_equal_one(cuda):
