@@ -34,15 +34,17 @@ sys.path.insert(0, ROOT)
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 
 
-def build(device, compute_dtype):
+def build(device, compute_dtype, arch="base"):
     from speecht5_amd import functional as Fn
     from speecht5_amd.criterions import SpeechT5Criterion
-    from speecht5_amd.speecht5 import t5_transformer_base
+    from speecht5_amd.speecht5 import t5_transformer_base, t5_transformer_large
     from speecht5_amd.task import SpeechT5Task
     Fn.set_compute_dtype(compute_dtype)
     args = Namespace(label_rates=50, sample_rate=16000, speech_odim=80, bert_init=True, use_codebook=True,
                      share_input_output_embed=True, encoder_layerdrop=0.0, decoder_layerdrop=0.0)
-    t5_transformer_base(args)
+    (t5_transformer_large if arch == "large" else t5_transformer_base)(args)
+    if arch == "large":   # (the architecture function leaves the LayerDrop default of 0.05 in: not replayable, see graph.py)
+        args.encoder_layerdrop = args.decoder_layerdrop = 0.0
     task = SpeechT5Task.synthetic(args)
     torch.manual_seed(1337)
     model = task.build_model(args).to(device)
@@ -92,6 +94,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=8, help="speech clips (10 s) per GPU per step")
+    ap.add_argument("--arch", default="base", choices=["base", "large"],
+                    help="large = t5_transformer_large (24 + 6 layers, d = 1024, pre-LN), same two micro-batches, bf16 GEMMs: a side "
+                         "measurement (BASELINE.json cfg 5 asks for fp8 GEMMs, which do not exist here); the headline is base")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying a captured HIP graph")
     a = ap.parse_args()
 
@@ -110,7 +115,7 @@ def main():
     from speecht5_amd.ddp import FlatGradDataParallel, FusedAdam
     from speecht5_amd.synthetic import speech_pretrain_sample, text_pretrain_sample
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    args, task, model, crit = build(device, dtype)
+    args, task, model, crit = build(device, dtype, a.arch)
     # The update is captured into a HIP graph after the warm-up steps and REPLAYED in the timed region (fresh dropout
     # seeds / span masks / lr per replay: speecht5_amd/graph.py).  ST5_GRAPH=0 or --no-graph: eager enqueue (with the bucketed
     # all-reduces overlapped with the backward when there are several ranks).
@@ -263,17 +268,18 @@ def main():
                      "frac_of_8TBps": round(b_ / t_ / 8e12, 4) if t_ > 0 else None}
     roof["hbm_bound_kernels"] = hbm
     if rank == 0:
-        out = {"metric": "audio-sec/s fwd+bwd SpeechT5-Base", "value": round(audio_seconds / dt, 2), "unit": "audio-sec/s",
+        out = {"metric": "audio-sec/s fwd+bwd SpeechT5-" + ("Large" if a.arch == "large" else "Base"), "value": round(audio_seconds / dt, 2), "unit": "audio-sec/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "SpeechT5-Base pretrain step (speech 8x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
-                                      "fwd+bwd+allreduce+clip+Adam, per GPU", "arch": "t5_transformer_base (12 enc + 6 dec, d=768)",
+               "config": {"workload": "SpeechT5-" + ("Large" if a.arch == "large" else "Base") + " pretrain step (speech 8x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
+                                      "fwd+bwd+allreduce+clip+Adam, per GPU", "arch": ("t5_transformer_large (24 enc + 6 dec, d=1024, pre-LN, layer-norm feature extractor)" if a.arch == "large"
+                                   else "t5_transformer_base (12 enc + 6 dec, d=768)"),
                           "enqueue": ("hip-graph replay of the local phase + eager all-reduce (one message) + Adam" if split_update else
                                       "hip-graph replay" if use_graph else "eager"), "micro_batches": "forward and backward side by side on two streams, two gradient buffers" if overlap_fwd else "in turn",
                           "global_speech_batch": a.batch * world, "clip_seconds": 10, "parallelism": f"dp{world}",
                           "dropout": 0.1, "layerdrop": 0.0},
                "roofline": roof}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.arch == "base":
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out))
     if dist.is_initialized():

@@ -333,6 +333,30 @@ int st5_tacotron_loss_bwd(const float* after, const float* before, const float* 
                           const float* labels, int64_t labels_bstride, const int64_t* olens, int32_t B, int32_t L, int32_t C, int32_t r,
                           float pos_weight, const float* out4, const float* g_l1, const float* g_mse, const float* g_bce, float* d_after,
                           float* d_before, float* d_logits, void* stream);
+/* ---- CTC loss of the ASR criterion (speech_to_text_loss.py:301-337: F.ctc_loss(lprobs, flat targets, input_lengths,
+ * target_lengths, blank, reduction="sum", zero_infinity), torch's own recursion since the reference turns cuDNN off) ----
+ * lprobs [T, B, V] fp32 log-probabilities; targets int64, sentence b's labels at targets[target_offsets[b] ...
+ * + target_lengths[b]) (lengths clamped to max_target_len); all index arrays on the device.
+ * fwd: nll [B], loss[0] = sum_b nll_b (an impossible alignment counts 0 with zero_infinity); ws >= st5_ctc_loss_ws_bytes
+ * keeps the alpha rows.  bwd: grad [T, B, V] = grad_out[0] * (exp(lprobs) - posterior) for t < input_lengths[b], else 0 --
+ * the form torch's ctc_loss backward returns (the gradient w.r.t. the logits in front of the log-softmax; pushing it through
+ * the log-softmax backward leaves it unchanged). */
+int64_t st5_ctc_loss_ws_bytes(int32_t T, int32_t B, int32_t max_target_len);
+int st5_ctc_loss_fwd(const float* lprobs, const int64_t* targets, const int64_t* target_offsets, const int64_t* input_lengths,
+                     const int64_t* target_lengths, int32_t T, int32_t B, int32_t V, int32_t max_target_len, int32_t blank,
+                     int32_t zero_infinity, float* nll, float* loss, void* ws, void* stream);
+int st5_ctc_loss_bwd(const float* lprobs, const int64_t* targets, const int64_t* target_offsets, const int64_t* input_lengths,
+                     const int64_t* target_lengths, int32_t T, int32_t B, int32_t V, int32_t max_target_len, int32_t blank,
+                     int32_t zero_infinity, const float* nll, const float* grad_out, const void* ws, float* grad, void* stream);
+/* ---- guided attention loss of the TTS criterion (text_to_speech_loss.py:370-427) ----
+ * att [B, H, To, Ti] fp32 (the selected heads of the selected layers, concatenated), ilens / olens int64 [B] on the device.
+ * fwd: out2 = {alpha * mean over (to < olen_b, ti < ilen_b) of (1 - exp(-(ti/ilen_b - to/olen_b)^2 / (2 sigma^2))) att, alpha / count}.
+ * bwd: datt = grad_out[0] * out2[1] * weight inside the selection, 0 outside. */
+int64_t st5_guided_attn_ws_bytes(void);
+int st5_guided_attn_fwd(const float* att, const int64_t* ilens, const int64_t* olens, int32_t B, int32_t H, int32_t To, int32_t Ti,
+                        float sigma, float alpha, float* out2, void* ws, void* stream);
+int st5_guided_attn_bwd(const int64_t* ilens, const int64_t* olens, int32_t B, int32_t H, int32_t To, int32_t Ti, float sigma,
+                        const float* out2, const float* grad_out, float* datt, void* stream);
 /* ---- Gumbel vector quantizer + time-wise code / encoder-state mix (speecht5.py:95-107, 858-882; csrc/vq.hip) ----
  * logits, gumbel [N, G*V] fp32 (V <= 128); vars [G*V, Dg] fp32; enc / out [N, G*Dg] (dtype); mix_w [T] fp32 or NULL (rows are
  * (b, t) with t = n % T); tau by value or from tau_dev.  training = 0: hard arg-max of the logits, no noise.

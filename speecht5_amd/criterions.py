@@ -64,6 +64,9 @@ class GuidedMultiHeadAttentionLoss(nn.Module):
     def forward(self, att_ws, ilens, olens):
         B, _, To, Ti = att_ws.shape
         dev = att_ws.device
+        if att_ws.is_cuda and att_ws.dtype == torch.float32:   # one reduction pass + one gradient pass (csrc/ctc_loss.hip)
+            return Fn.guided_attention_loss(att_ws, torch.as_tensor(ilens, device=dev), torch.as_tensor(olens, device=dev),
+                                            self.sigma, self.alpha)
         ilens = torch.as_tensor(ilens, device=dev).float()
         olens = torch.as_tensor(olens, device=dev).float()
         gx = torch.arange(To, device=dev).float()[None, :, None] / olens[:, None, None]
@@ -328,6 +331,9 @@ class SpeechtoTextLoss(nn.Module):
         targets_flat = sample["target"].masked_select(pad_mask)
         target_lengths = sample["target_lengths"] if "target_lengths" in sample else pad_mask.sum(-1)
         target_lengths = target_lengths - 1
+        if lprobs.is_cuda and lprobs.dtype == torch.float32:   # alpha / beta recursions as two kernels (csrc/ctc_loss.hip)
+            return Fn.ctc_loss_sum(lprobs, targets_flat, input_lengths, target_lengths, self.blank_idx, self.zero_infinity,
+                                   max_target_len=sample["target"].size(1))
         return F.ctc_loss(lprobs, targets_flat, input_lengths, target_lengths, blank=self.blank_idx, reduction="sum",
                           zero_infinity=self.zero_infinity)
 

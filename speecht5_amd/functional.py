@@ -924,6 +924,87 @@ def tacotron_loss(after, before, logits, ys, labels, olens, r, pos_weight):
     return TacotronLossFunction.apply(after, before, logits, ys, labels, olens, r, pos_weight)
 
 
+class CTCLossFunction(torch.autograd.Function):
+    """Sum of the CTC negative log-likelihoods (csrc/ctc_loss.hip): one block per sentence walks the alpha recursion, the
+    backward the beta recursion and the per-class posteriors.  Gradient in the form torch's ctc_loss returns."""
+
+    @staticmethod
+    def forward(ctx, lprobs, targets, target_offsets, input_lengths, target_lengths, max_target_len, blank, zero_infinity):
+        T, B, V = lprobs.shape
+        lprobs = lprobs.contiguous()
+        assert lprobs.dtype == torch.float32, "CTC runs on fp32 log-probabilities (speech_to_text_loss.py:324: log_softmax(...).float())"
+        dev = lprobs.device
+        idx = [t.to(device=dev, dtype=torch.int64).contiguous() for t in (targets, target_offsets, input_lengths, target_lengths)]
+        L_ = hip.lib()
+        nll = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        alpha = torch.empty(max(int(L_.st5_ctc_loss_ws_bytes(T, B, int(max_target_len))), 4) // 4, dtype=torch.float32, device=dev)
+        hip.check(L_.st5_ctc_loss_fwd(lprobs.data_ptr(), hip.ptr(idx[0]) if idx[0].numel() else 0, idx[1].data_ptr(), idx[2].data_ptr(),
+                                      idx[3].data_ptr(), T, B, V, int(max_target_len), int(blank), int(bool(zero_infinity)),
+                                      nll.data_ptr(), loss.data_ptr(), alpha.data_ptr(), hip.stream()), "st5_ctc_loss_fwd")
+        ctx.save_for_backward(lprobs, *idx, nll, alpha)
+        ctx.meta = (int(max_target_len), int(blank), int(bool(zero_infinity)))
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lprobs, targets, offsets, in_len, tg_len, nll, alpha = ctx.saved_tensors
+        maxL, blank, zi = ctx.meta
+        T, B, V = lprobs.shape
+        grad = torch.empty_like(lprobs)
+        g = g.contiguous().float()
+        hip.check(hip.lib().st5_ctc_loss_bwd(lprobs.data_ptr(), hip.ptr(targets) if targets.numel() else 0, offsets.data_ptr(),
+                                             in_len.data_ptr(), tg_len.data_ptr(), T, B, V, maxL, blank, zi, nll.data_ptr(), g.data_ptr(),
+                                             alpha.data_ptr(), grad.data_ptr(), hip.stream()), "st5_ctc_loss_bwd")
+        return grad, None, None, None, None, None, None, None
+
+
+def ctc_loss_sum(lprobs, targets_flat, input_lengths, target_lengths, blank, zero_infinity=True, max_target_len=None):
+    """F.ctc_loss(lprobs [T, B, V], flat targets, input_lengths, target_lengths, blank, reduction="sum", zero_infinity)
+    (speech_to_text_loss.py:333-337).  max_target_len: an upper bound known on the host (default: read from the device)."""
+    target_lengths = target_lengths.to(lprobs.device)
+    offsets = torch.cumsum(target_lengths, 0) - target_lengths
+    if max_target_len is None:
+        max_target_len = int(target_lengths.max()) if target_lengths.numel() else 0
+    return CTCLossFunction.apply(lprobs, targets_flat, offsets, input_lengths, target_lengths, max_target_len, blank, zero_infinity)
+
+
+class GuidedAttentionFunction(torch.autograd.Function):
+    """alpha * mean of the guided-attention penalty over the valid (to, ti) region (csrc/ctc_loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, att, ilens, olens, sigma, alpha):
+        B, H, To, Ti = att.shape
+        att = att.contiguous()
+        assert att.dtype == torch.float32
+        dev = att.device
+        ilens = ilens.to(device=dev, dtype=torch.int64).contiguous()
+        olens = olens.to(device=dev, dtype=torch.int64).contiguous()
+        L_ = hip.lib()
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        ws = hip.workspace(L_.st5_guided_attn_ws_bytes(), dev)
+        hip.check(L_.st5_guided_attn_fwd(att.data_ptr(), ilens.data_ptr(), olens.data_ptr(), B, H, To, Ti, float(sigma), float(alpha),
+                                         out.data_ptr(), ws.data_ptr(), hip.stream()), "st5_guided_attn_fwd")
+        ctx.save_for_backward(ilens, olens, out)
+        ctx.meta = (B, H, To, Ti, float(sigma))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ilens, olens, out = ctx.saved_tensors
+        B, H, To, Ti, sigma = ctx.meta
+        datt = torch.empty(B, H, To, Ti, dtype=torch.float32, device=out.device)
+        g = g.contiguous().float()
+        hip.check(hip.lib().st5_guided_attn_bwd(ilens.data_ptr(), olens.data_ptr(), B, H, To, Ti, sigma, out.data_ptr(), g.data_ptr(),
+                                                datt.data_ptr(), hip.stream()), "st5_guided_attn_bwd")
+        return datt, None, None, None, None
+
+
+def guided_attention_loss(att, ilens, olens, sigma, alpha):
+    """GuidedMultiHeadAttentionLoss (text_to_speech_loss.py:370-427) on att [B, H, To, Ti] fp32."""
+    return GuidedAttentionFunction.apply(att, ilens, olens, sigma, alpha)
+
+
 # -------------------------------------------------------------------------------------------------
 # LayerNorm
 # -------------------------------------------------------------------------------------------------

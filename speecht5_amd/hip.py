@@ -119,6 +119,15 @@ _SIGS = {
     "st5_tacotron_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32,
                                       c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "st5_embed_rows_bwd_det_w": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_int32, c_int32, c_int, c_void_p]),
+    "st5_ctc_loss_ws_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+    "st5_ctc_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    "st5_ctc_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "st5_guided_attn_ws_bytes": (c_int64, []),
+    "st5_guided_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p,
+                                    c_void_p]),
+    "st5_guided_attn_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "st5_vq_ws_bytes": (c_int64, []),
     "st5_vq_vpad": (c_int32, []),
     "st5_vq_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -673,3 +673,51 @@ def test_deterministic_row_scatter(cuda, dtype, rows, vocab, cols):
     rw = w[(torch.arange(rows) // div) % T]
     ref = base.clone().index_add_(0, tok[ok].long(), 0.5 * rw[ok, None] * rt(dy, dtype)[ok])
     close(outs[0], ref, torch.float32, what="row scatter")
+
+
+def test_ctc_loss_matches_torch(cuda):
+    """st5_ctc_loss_fwd / _bwd against torch's own CTC recursion on the host (what the reference runs with cuDNN off,
+    speech_to_text_loss.py:333-337): ragged frame and label counts, repeated labels (the l'_s != l'_{s-2} rule), an empty
+    target, a sentence with more labels than frames (impossible: zeroed by zero_infinity), frames past a sentence's length."""
+    from speecht5_amd import functional as Fn
+    torch.manual_seed(3)
+    T, B, V, blank = 37, 6, 11, 4
+    logits = torch.randn(T, B, V) * 2.0
+    in_len = torch.tensor([37, 30, 12, 37, 5, 1])
+    tgs = [[1, 1, 2, 3, 3, 3, 5], [7, 8, 7, 8, 7], [], [9] * 18, [1, 2, 3, 1, 2, 3, 1, 2], [6]]
+    tg_len = torch.tensor([len(t) for t in tgs])
+    flat = torch.tensor([c for t in tgs for c in t], dtype=torch.long)
+    for scale in (1.0, 0.37):
+        ref_in = logits.clone().double().requires_grad_(True)
+        ref = F.ctc_loss(ref_in.log_softmax(-1), flat, in_len, tg_len, blank=blank, reduction="sum", zero_infinity=True)
+        (ref * scale).backward()
+        x = logits.to(cuda).requires_grad_(True)
+        got = Fn.ctc_loss_sum(x.log_softmax(-1), flat.to(cuda), in_len.to(cuda), tg_len.to(cuda), blank, True, max_target_len=20)
+        (got * scale).backward()
+        assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)), (float(got), float(ref))
+        err = float((x.grad.cpu().double() - ref_in.grad).abs().max())
+        assert err <= 1e-4 * float(ref_in.grad.abs().max()), err   # (fp32 log-space recursions vs fp64)
+    # without zero_infinity the impossible sentence makes the sum infinite, as in torch
+    got = Fn.ctc_loss_sum(logits.to(cuda).log_softmax(-1), flat.to(cuda), in_len.to(cuda), tg_len.to(cuda), blank, False, max_target_len=20)
+    assert torch.isinf(got)
+
+
+def test_guided_attention_loss_matches_formula(cuda):
+    """st5_guided_attn_fwd / _bwd against the reference formula (text_to_speech_loss.py:370-427) in fp64."""
+    from speecht5_amd import functional as Fn
+    torch.manual_seed(4)
+    B, H, To, Ti = 3, 4, 29, 17
+    att = torch.rand(B, H, To, Ti)
+    ilens, olens = torch.tensor([17, 9, 13]), torch.tensor([29, 20, 5])
+    a = att.double().requires_grad_(True)
+    gx = torch.arange(To).double()[None, :, None] / olens[:, None, None]
+    gy = torch.arange(Ti).double()[None, None, :] / ilens[:, None, None]
+    w = 1.0 - torch.exp(-((gy - gx) ** 2) / (2 * 0.4 ** 2))
+    mask = (torch.arange(To)[None, :, None] < olens[:, None, None]) & (torch.arange(Ti)[None, None, :] < ilens[:, None, None])
+    ref = 10.0 * torch.mean((w.unsqueeze(1) * a).masked_select(mask.unsqueeze(1).expand(B, H, To, Ti)))
+    (ref * 0.5).backward()
+    x = att.to(cuda).requires_grad_(True)
+    got = Fn.guided_attention_loss(x, ilens, olens, 0.4, 10.0)
+    (got * 0.5).backward()
+    assert abs(float(got) - float(ref)) <= 2e-6 * abs(float(ref)), (float(got), float(ref))
+    assert float((x.grad.cpu().double() - a.grad).abs().max()) <= 2e-6 * float(a.grad.abs().max())
