@@ -116,17 +116,22 @@ __global__ void sumsq_kernel(const T* __restrict__ x, float* __restrict__ part, 
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-// sum of squares of x + y (fp32): the gradient norm over two gradient buffers
+// sum of squares of x + y (fp32): the gradient norm over two gradient buffers.  Same partition and summation order as
+// sumsq_kernel<float> (8 elements per thread and trip), so norm(x + y) comes out bit-identical whether the buffers were summed
+// first (several ranks: all-reduce in between) or are summed here.
 __global__ void sumsq_pair_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ part, long long n) {
   __shared__ float red[4];
   float s = 0.f;
-  const long long nv = n / 4;
+  const long long nv = n / 8;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
-    const f32x4 a = reinterpret_cast<const f32x4*>(x)[i], b = reinterpret_cast<const f32x4*>(y)[i];
+    const f32x4 a0 = reinterpret_cast<const f32x4*>(x)[2 * i], a1 = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+    const f32x4 b0 = reinterpret_cast<const f32x4*>(y)[2 * i], b1 = reinterpret_cast<const f32x4*>(y)[2 * i + 1];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float v = a[e] + b[e]; s = fmaf(v, v, s); }
+    for (int e = 0; e < 4; ++e) { const float v = a0[e] + b0[e]; s = fmaf(v, v, s); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float v = a1[e] + b1[e]; s = fmaf(v, v, s); }
   }
-  for (long long i = nv * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = nv * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float v = x[i] + y[i];
     s = fmaf(v, v, s);
   }

@@ -279,6 +279,8 @@ class FlatGradDataParallel:
         from . import hip
         if self._pair_pending:
             if self.flat.is_cuda:
+                # both buffers complete first: weight gradients may still sit in split-K slabs / on the weight-gradient stream
+                self._flush_splitk()
                 hip.check(hip.lib().st5_axpby(self.flat2.data_ptr(), self.flat.data_ptr(), self.flat.numel(), 1.0, 1.0, hip.F32, hip.stream()),
                           "st5_axpby")
             else:   # (host buffers: the gloo tests of this wrapper's bookkeeping on a stand-in model)

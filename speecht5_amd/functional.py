@@ -106,7 +106,7 @@ class HostStaging:
             if self.i == len(self.entries):
                 self.entries.append([torch.empty(h.shape, dtype=h.dtype, device=device), torch.empty(h.shape, dtype=h.dtype).pin_memory(), producer])
             e = self.entries[self.i]
-            assert e[1].shape == h.shape and e[1].dtype == h.dtype, "a staged step input changed shape between steps"
+            assert e[0] is not None and e[1].shape == h.shape and e[1].dtype == h.dtype, "a staged step input changed shape between steps"
             e[2] = producer
             e[1].copy_(h)
             e[0].copy_(e[1], non_blocking=True)
@@ -115,6 +115,27 @@ class HostStaging:
         e = self.entries[self.i]   # capture: contents were refreshed by refresh()
         self.i += 1
         return e[0]
+
+    def draw(self, fn):
+        """A host-side random draw whose VALUE steers nothing in a replayed step (LayerDrop probabilities at LayerDrop 0, which
+        graph.StepGraph asserts) but which CONSUMES the CPU random stream: recorded like a staged input without a device buffer
+        and repeated before every replay, so the stream stays in step with the eager path (the span masks drawn after it come
+        out the same)."""
+        if self.mode is None:
+            return fn()
+        if self.mode == "record":
+            v = fn()
+            if self.i == len(self.entries):
+                self.entries.append([None, v, fn])
+            e = self.entries[self.i]
+            assert e[0] is None, "the step's sequence of staged inputs / host draws changed between steps"
+            e[1], e[2] = v, fn
+            self.i += 1
+            return v
+        e = self.entries[self.i]   # capture: nothing is drawn; the recorded value stands in
+        assert e[0] is None
+        self.i += 1
+        return e[1]
 
     def refresh(self):
         self.produce(0)
@@ -126,6 +147,8 @@ class HostStaging:
     def produce(self, slot):
         for e in self.entries:
             h = e[2]()
+            if e[0] is None:   # (draw(): consumed, not used)
+                continue
             assert e[1].shape == h.shape
             if slot and len(e) == 3:
                 e.append(torch.empty(h.shape, dtype=h.dtype).pin_memory())
@@ -133,7 +156,8 @@ class HostStaging:
 
     def upload(self, slot):
         for e in self.entries:
-            e[0].copy_(e[3] if slot else e[1], non_blocking=True)
+            if e[0] is not None:
+                e[0].copy_(e[3] if slot else e[1], non_blocking=True)
 
 
 staging = HostStaging()
@@ -142,6 +166,11 @@ staging = HostStaging()
 def stage_host(producer, device):
     """Device copy of the CPU tensor `producer()` returns (see HostStaging)."""
     return staging.get(producer, device)
+
+
+def host_draw(fn):
+    """fn() now, and again before every replay of a captured step (see HostStaging.draw)."""
+    return staging.draw(fn)
 
 
 def static_shapes():

@@ -101,7 +101,7 @@ class TransformerEncoder(FairseqEncoder):
             pos_k = self.pos_emb()[0] if self.args.relative_position_embedding else None
         r, d = None, None
         for i, layer in enumerate(self.layers):
-            dropout_probability = np.random.random()
+            dropout_probability = Fn.host_draw(np.random.random)   # (drawn per layer even at LayerDrop 0, as the reference does)
             frozen = (not ft) and i not in self.no_freeze_encoder_layer
             with torch.no_grad() if frozen else contextlib.ExitStack():
                 if not self.training or (dropout_probability > self.encoder_layerdrop) or i == self.unb_enc_layer:
