@@ -94,6 +94,8 @@ int st5_stream_fork(void* from_stream, void* to_stream);
 int st5_gemm_set_glds(int enabled);
 /* NT block tile: 0 = chosen per problem (default), 1 = 128x128 always, 2 = 256x256 always (A/B measurements only). */
 int st5_gemm_set_nt_tile(int mode);
+/* Block count the split-K choice of the fp32-output (weight-gradient) GEMMs aims for; default 384 (1.5 per CU). */
+int st5_gemm_set_splitk_target(int blocks);
 /* Batch the slab reductions of split-K GEMMs (weight gradients): while enabled, a split-K st5_gemm only queues its reduction;
  * st5_gemm_flush_splitk launches ONE kernel that folds every queued reduction into its output (the outputs are complete
  * only after the flush; same stream as the GEMMs).  Used by the data-parallel wrapper, which flushes before it reduces a

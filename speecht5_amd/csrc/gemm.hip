@@ -1056,6 +1056,7 @@ int launch_nt256(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
+int g_splitk_target = 384;   // blocks a split-K weight-gradient GEMM aims for (st5_gemm_set_splitk_target)
 int g_nt_tile = 0;   // 0 = choose per problem, 1 = always 128^2, 2 = always 256^2 (A/B switch, st5_gemm_set_nt_tile)
 
 #ifdef GEMM_TIMING
@@ -1336,7 +1337,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
     const int bk = 128 / es;
     const int nk = (p.K + bk - 1) / bk;
     if (tiles < 200 && nk >= 16) {
-      long long want = (384 + tiles - 1) / tiles;
+      long long want = (g_splitk_target + tiles - 1) / tiles;
       long long maxs = nk / 8;  // at least 8 k-tiles per split
       nsplit = (int)(want < maxs ? want : maxs);
       if (nsplit < 1) nsplit = 1;
@@ -1432,4 +1433,6 @@ extern "C" int st5_gemm_flush_splitk(void* stream) { return flush_pending(reinte
 /* A/B switch for the LDS-DMA NT kernel (tools/bench_kernels.py uses it for within-process comparisons). */
 extern "C" int st5_gemm_set_glds(int enabled) { g_use_glds = enabled != 0; return ST5_OK; }
 /* NT block tile: 0 = per-problem choice (default), 1 = 128x128 always, 2 = 256x256 always (A/B measurements). */
+/* Block count the split-K choice of the fp32-output (weight-gradient) GEMMs aims for (default 384 = 1.5 per CU). */
+extern "C" int st5_gemm_set_splitk_target(int blocks) { if (blocks < 1 || blocks > 4096) return ST5_ERR_ARG; g_splitk_target = blocks; return ST5_OK; }
 extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 2) return ST5_ERR_ARG; g_nt_tile = mode; return ST5_OK; }
