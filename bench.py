@@ -130,6 +130,8 @@ def main():
     # the weight-gradient stream hides ~3.5 ms of dW GEMMs behind the data-gradient chain
     if os.environ.get("ST5_NT_TILE"):   # A/B: 1 = 128x128 always, 2 = 256x256 always (default: per problem)
         hip.lib().st5_gemm_set_nt_tile(int(os.environ["ST5_NT_TILE"]))
+    if os.environ.get("ST5_DEEP_RING"):   # A/B: "max_blocks,nbuf" of the 128x128 NT kernel's deep operand ring (nbuf 2 = off)
+        hip.lib().st5_gemm_set_deep_ring(*[int(v) for v in os.environ["ST5_DEEP_RING"].split(",")])
     if os.environ.get("ST5_SPLITK_TARGET"):   # A/B: block count the weight-gradient split-K aims for
         hip.lib().st5_gemm_set_splitk_target(int(os.environ["ST5_SPLITK_TARGET"]))
     ddp = FlatGradDataParallel(model, wgrad_stream=(wgrad_env == "1") if wgrad_env is not None else not (use_graph and overlap_fwd))

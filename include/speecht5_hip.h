@@ -96,6 +96,8 @@ int st5_gemm_set_glds(int enabled);
 int st5_gemm_set_nt_tile(int mode);
 /* Block count the split-K choice of the fp32-output (weight-gradient) GEMMs aims for; default 384 (1.5 per CU). */
 int st5_gemm_set_splitk_target(int blocks);
+/* 128x128 NT kernel: grids of at most max_blocks blocks (one per CU) use an nbuf-stage operand ring (2 = never; default 256, 4). */
+int st5_gemm_set_deep_ring(int max_blocks, int nbuf);
 /* Batch the slab reductions of split-K GEMMs (weight gradients): while enabled, a split-K st5_gemm only queues its reduction;
  * st5_gemm_flush_splitk launches ONE kernel that folds every queued reduction into its output (the outputs are complete
  * only after the flush; same stream as the GEMMs).  Used by the data-parallel wrapper, which flushes before it reduces a

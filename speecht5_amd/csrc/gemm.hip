@@ -705,10 +705,6 @@ int launch(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-#ifndef GLDS_NBUF_V
-#define GLDS_NBUF_V 2
-#endif
-constexpr int GLDS_NBUF = GLDS_NBUF_V;  // 64 KB LDS => two blocks per CU; 3- and 4-deep rings at one block per CU measured 10-25 % slower
 
 #ifndef GEMM_ABL
 #define GEMM_ABL 0
@@ -720,7 +716,7 @@ __device__ unsigned long long g_gemm_timing[8];
 #define GPROBE(i)
 #endif
 
-template <typename T>
+template <typename T, int NBUF>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
 #ifdef GEMM_TIMING
   unsigned int tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -776,7 +772,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
 
   const int nk = p.K / BK;
 #pragma unroll
-  for (int t = 0; t < GLDS_NBUF - 1; ++t)
+  for (int t = 0; t < NBUF - 1; ++t)
     if (t < nk) issue(t, t);
   const int frow = lane & 31, fhalf = lane >> 5;
   const int arow0 = wr * 64 + frow, brow0 = wc * 64 + frow;
@@ -785,7 +781,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
     // tile kt has landed when at most the 8 loads of tile kt+1 are still outstanding
     {
       int ahead = nk - 1 - kt;
-      ahead = ahead < GLDS_NBUF - 2 ? ahead : GLDS_NBUF - 2;  // tiles allowed to stay in flight
+      ahead = ahead < NBUF - 2 ? ahead : NBUF - 2;  // tiles allowed to stay in flight
       if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -794,9 +790,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
     __builtin_amdgcn_s_barrier();
     GPROBE(1);
 #if GEMM_ABL != 2
-    if (kt + GLDS_NBUF - 1 < nk) issue(kt + GLDS_NBUF - 1, (kt + GLDS_NBUF - 1) % GLDS_NBUF);
+    if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
 #endif
-    const char* cur = dsm + (kt % GLDS_NBUF) * 2 * TILE_BYTES;
+    const char* cur = dsm + (kt % NBUF) * 2 * TILE_BYTES;
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       const frag_t a0 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0, kg * 2 + fhalf));
@@ -1070,19 +1066,36 @@ namespace {
 #endif
 
 
+// Ring depth of the 128^2 NT kernel (template parameter NBUF).  2 stages (64 KB LDS) let two blocks share a CU and cover each
+// other's LDS-DMA landing latency (~1 us per k-step against 0.25 us of MFMAs): the right shape for grids of several blocks
+// per CU.  A grid of <= 256 blocks has the CU to itself; there a deeper ring (loads two or three k-steps ahead) helps a little:
+// measured on the pre-training update with the micro-batches in turn 48.24 -> 47.33 ms (4 stages), 47.41 (3 stages); deep rings
+// for EVERY grid were 10-25 % slower (round 1).  With the two micro-batches side by side (ddp.accumulate_overlapped) the
+// other stream's blocks are the latency cover and 128 KB blocks keep them off the CU: 37.70 -> 38.27 ms, so that mode turns
+// the deep ring off (st5_gemm_set_deep_ring(0, 2)).
+int g_deep_blocks = 256, g_deep_nbuf = 4;
+
 template <typename T>
 int launch_glds(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, 1, p.batch), block(NTHREADS);
-  const size_t shm = (size_t)GLDS_NBUF * 2 * TILE_BYTES;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return ST5_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_nt_glds_kernel<T>), grid, block, shm, s, p, c_vec_ok);
+  const int nk = p.K / (128 / (int)sizeof(T));
+  const bool deep = sizeof(T) == 2 && (long long)tiles * p.batch <= g_deep_blocks && nk >= 4 && g_deep_nbuf > 2;
+  if (deep && g_deep_nbuf == 4)
+    hipLaunchKernelGGL((gemm_nt_glds_kernel<T, 4>), grid, block, (size_t)4 * 2 * TILE_BYTES, s, p, c_vec_ok);
+  else if (deep)
+    hipLaunchKernelGGL((gemm_nt_glds_kernel<T, 3>), grid, block, (size_t)3 * 2 * TILE_BYTES, s, p, c_vec_ok);
+  else
+    hipLaunchKernelGGL((gemm_nt_glds_kernel<T, 2>), grid, block, (size_t)2 * 2 * TILE_BYTES, s, p, c_vec_ok);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -1435,4 +1448,9 @@ extern "C" int st5_gemm_set_glds(int enabled) { g_use_glds = enabled != 0; retur
 /* NT block tile: 0 = per-problem choice (default), 1 = 128x128 always, 2 = 256x256 always (A/B measurements). */
 /* Block count the split-K choice of the fp32-output (weight-gradient) GEMMs aims for (default 384 = 1.5 per CU). */
 extern "C" int st5_gemm_set_splitk_target(int blocks) { if (blocks < 1 || blocks > 4096) return ST5_ERR_ARG; g_splitk_target = blocks; return ST5_OK; }
+/* 128^2 NT kernel: grids of at most `max_blocks` blocks run with an `nbuf`-stage operand ring (2 = off, 3, 4). */
+extern "C" int st5_gemm_set_deep_ring(int max_blocks, int nbuf) {
+  if (max_blocks < 0 || nbuf < 2 || nbuf > 4) return ST5_ERR_ARG;
+  g_deep_blocks = max_blocks; g_deep_nbuf = nbuf; return ST5_OK;
+}
 extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 2) return ST5_ERR_ARG; g_nt_tile = mode; return ST5_OK; }

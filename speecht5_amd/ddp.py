@@ -221,6 +221,10 @@ class FlatGradDataParallel:
         assert not self.collectives or self._local_phase, \
             "accumulate_overlapped with several ranks: inside local_phase(), followed by all_reduce_gradients()"
         cur = torch.cuda.current_stream()
+        if not self._fwd_streams and n > 1 and os.environ.get("ST5_DEEP_RING") is None:   # (the env switch: bench.py A/B)
+            # side by side, a one-block-per-CU GEMM grid gets its latency cover from the other stream's blocks; the deep operand
+            # ring of csrc/gemm.hip (128 KB of LDS per block) would keep those off the CU: 37.7 vs 38.3 ms per update
+            hip.check(hip.lib().st5_gemm_set_deep_ring(0, 2), "st5_gemm_set_deep_ring")
         while len(self._fwd_streams) < n - 1:
             self._fwd_streams.append(torch.cuda.Stream(device=self.flat.device))
         for st in self._fwd_streams[: n - 1]:
@@ -313,6 +317,8 @@ class FlatGradDataParallel:
         if self.flat.is_cuda:
             Fn.set_wgrad_stream(None)
             Fn.set_attention_stream(None)
+            if self._fwd_streams:
+                hip.check(hip.lib().st5_gemm_set_deep_ring(256, 4), "st5_gemm_set_deep_ring")   # (the library default)
             hip.check(hip.lib().st5_layernorm_defer(0, hip.stream()), "st5_layernorm_defer")
             hip.check(hip.lib().st5_gemm_defer_splitk(0, hip.stream()), "st5_gemm_defer_splitk")
         Fn.set_layer_boundary_hook(None)
