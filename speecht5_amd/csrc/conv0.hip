@@ -261,16 +261,17 @@ __global__ __launch_bounds__(256) void conv0_bwd_reduce_kernel(const float* __re
   }
 }
 // dw[c][j] += gscale sum_b rstd gamma [A_j - S1 M_j / L - S2 rstd ((R w)_j - mean M_j) / L];
-// dgamma[c] += gscale sum_b S2;  dbeta[c] += gscale sum_b S1          (one thread per channel)
-__global__ __launch_bounds__(64) void conv0_bwd_final_kernel(const double* __restrict__ sums, const double* __restrict__ mom,
+// dgamma[c] += gscale sum_b S2;  dbeta[c] += gscale sum_b S1
+// One thread per (channel, tap) -- 16 tap lanes per channel, lane k..15 idle, lane 0 also owns dgamma / dbeta.  (One thread
+// per channel walked B x k x k fp64 terms alone: 124 us for 8 waves of dependent double arithmetic.)
+__global__ __launch_bounds__(256) void conv0_bwd_final_kernel(const double* __restrict__ sums, const double* __restrict__ mom,
                                                              const float* __restrict__ w, const float* __restrict__ gamma,
                                                              const float* __restrict__ stats, float* __restrict__ dw,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C,
                                                              int k, int L, int nv, float gscale) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double g1 = 0.0, g2 = 0.0, acc[MAXK];
-  for (int j = 0; j < k; ++j) acc[j] = 0.0;
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15;
+  if (c >= C || j >= k) return;
+  double g1 = 0.0, g2 = 0.0, acc = 0.0;
   const double ga = (double)gamma[c], invL = 1.0 / (double)L;
   for (int b = 0; b < B; ++b) {
     const double* sb = sums + ((long long)b * C + c) * nv;
@@ -278,19 +279,18 @@ __global__ __launch_bounds__(64) void conv0_bwd_final_kernel(const double* __res
     const double mu = (double)stats[((long long)b * C + c) * 2], rs = (double)stats[((long long)b * C + c) * 2 + 1];
     const double S1 = sb[nv - 2], S2 = sb[nv - 1];
     g1 += S1; g2 += S2;
-    for (int j = 0; j < k; ++j) {
-      double rw = 0.0;   // (R w)_j
-      for (int jp = 0; jp < k; ++jp) {
-        const int a = j < jp ? j : jp, bq = j < jp ? jp : j;
-        rw += (double)w[c * k + jp] * mb[ridx(k, a, bq)];
-      }
-      acc[j] += rs * ga * (sb[j] - S1 * invL * mb[j] - S2 * invL * rs * (rw - mu * mb[j]));
+    double rw = 0.0;   // (R w)_j
+    for (int jp = 0; jp < k; ++jp) {
+      const int a = j < jp ? j : jp, bq = j < jp ? jp : j;
+      rw += (double)w[c * k + jp] * mb[ridx(k, a, bq)];
     }
+    acc += rs * ga * (sb[j] - S1 * invL * mb[j] - S2 * invL * rs * (rw - mu * mb[j]));
   }
-  if (dw)
-    for (int j = 0; j < k; ++j) dw[c * k + j] += gscale * (float)acc[j];
-  if (dgamma) dgamma[c] += gscale * (float)g2;
-  if (dbeta) dbeta[c] += gscale * (float)g1;
+  if (dw) dw[c * k + j] += gscale * (float)acc;
+  if (j == 0) {
+    if (dgamma) dgamma[c] += gscale * (float)g2;
+    if (dbeta) dbeta[c] += gscale * (float)g1;
+  }
 }
 
 // workspace layout (floats unless noted): [chunk partials: max(B nch nmom, B nch C (KWmax + 2))] [mom: B nmom doubles]
@@ -373,7 +373,7 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
   else { if (k <= 10) BWD(float, 10); else BWD(float, MAXK); }
 #undef BWD
   hipLaunchKernelGGL(conv0_bwd_reduce_kernel, dim3((C * nv + 31) / 32, B), dim3(256), 0, s, W.part, W.sums, C, nch, nv);
-  hipLaunchKernelGGL(conv0_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, W.sums, W.mom, w, gamma, stats, dw, dgamma,
+  hipLaunchKernelGGL(conv0_bwd_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, W.sums, W.mom, w, gamma, stats, dw, dgamma,
                      dbeta, B, C, k, L, nv, gscale);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
