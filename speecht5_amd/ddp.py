@@ -536,11 +536,14 @@ class FusedAdam:
             self.ddp.sum_gradient_buffers()
             if self.clip > 0:
                 hip.check(L.st5_sumsq(g.data_ptr(), self.gnorm_sq.data_ptr(), g.numel(), 1.0, 0, hip.F32, hip.stream()), "st5_sumsq")
-            hip.check(L.st5_adam_step_dev(self.pflat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), g.numel(), self.lr,
-                                          self.betas[0], self.betas[1], self.eps, self.wd, self.t,
-                                          self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
-                                          self.wflat.data_ptr() if self.mirror is not None else 0, hip.ptr(self.hyper_dev), hip.stream()),
-                      "st5_adam_step_dev")
+            # (one buffer; the kernel leaves it zeroed in passing -- the second buffer, if there is one, is zero whenever no sum
+            # is pending -- so the next zero_grad() has no fill to launch)
+            hip.check(L.st5_adam_step_pair(self.pflat.data_ptr(), g.data_ptr(), 0, 1, self.m.data_ptr(), self.v.data_ptr(), g.numel(),
+                                           self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                           self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
+                                           self.wflat.data_ptr() if self.mirror is not None else 0, hip.ptr(self.hyper_dev), hip.stream()),
+                      "st5_adam_step_pair")
+            self.ddp._grads_zeroed = True
         # parameters changed in place through the flat view: invalidate the compute-dtype weight cache (entries that do
         # not come from the bf16 image: conv / fp32 / non-adjacent stacks) and refresh the transposed copies
         Fn.weight_cache.clear()
