@@ -11,11 +11,15 @@
  *     statistics, softmax, accumulators, biases, LayerNorm affine params and weight gradients are fp32;
  *   - return value 0 = ok, non-zero = ST5_ERR_* (argument / alignment / launch error);
  *   - threading / devices: the library is built for ONE process per GPU driven by ONE host thread (the reference's
- *     execution model).  It keeps process-global mutable state -- the deferred split-K queue and
- *     its slab arena (st5_gemm_defer_splitk / _flush_splitk; the arena is hipFree'd and re-allocated when it must
- *     grow, which synchronises the device), per-stream split-K workspaces, the deferred LayerNorm reductions
- *     (st5_layernorm_defer / _flush), the stream-fork event ring and the A/B switches (st5_gemm_set_*).  Calling it
- *     from two host threads, or for two devices from one process, is NOT supported.
+ *     execution model).  It keeps process-global mutable state -- the stream-fork event ring, the
+ *     A/B switches (st5_gemm_set_*, st5_layernorm_set_max_blocks) and tables of PER-STREAM state: the deferred split-K
+ *     queue with its slab arena (st5_gemm_defer_splitk / _flush_splitk; an arena is hipFree'd and re-allocated when it
+ *     must grow, which synchronises the device), the split-K slab workspaces, the deferred LayerNorm reductions
+ *     (st5_layernorm_defer / _flush) and the workspace of the ordered row scatter.  One host thread may therefore keep
+ *     several streams busy at once (the two micro-batches of an update side by side; up to 4 streams with deferred
+ *     reductions, 8 with split-K workspaces -- further streams recycle an entry after a device synchronisation), and a
+ *     flush only folds what was queued on the stream it is given.  Calling the library from two host threads, or for
+ *     two devices from one process, is NOT supported.
  */
 #ifndef SPEECHT5_HIP_H
 #define SPEECHT5_HIP_H
