@@ -1157,8 +1157,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   const int lchunk = (lane & 15) ^ (4 * lrow);
   const bool a_col_ok = m0 + lchunk * 8 < p.M, b_col_ok = n0 + lchunk * 8 < p.N;
   const T* const zero = reinterpret_cast<const T*>(g_zero_page) + (lane & 15) * 8;
-  const T* abase = Ap + m0 + lchunk * 8;
-  const T* bbase = Bp + n0 + lchunk * 8;
+  // (segmented inner index -- grouped convolution windows: column i lives at (i / seg) * seg_stride + i % seg; a lane's 8-column
+  // chunk never straddles a segment because the host requires seg % 8 == 0, and the column is fixed for the whole k-loop)
+  auto inner_off = [](int i, int seg, long long ss) { return seg ? (long long)(i / seg) * ss + (i % seg) : (long long)i; };
+  const T* abase = Ap + inner_off(m0 + lchunk * 8, p.A.seg, p.A.seg_stride);
+  const T* bbase = Bp + inner_off(n0 + lchunk * 8, p.B.seg, p.B.seg_stride);
   // Source pointers advance by a per-lane constant stride (64 k-rows; 0 for the lanes that read the zero page because their
   // 16-byte column chunk lies past M / N), so a k-step issues its 8 LDS-DMA loads with two adds each.  (The first version
   // recomputed base + k * ld per load: 64-bit multiplies and two exec-masked branches per load, ~150 VALU instructions in
@@ -1294,7 +1297,7 @@ int launch_tn_glds(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream
 bool tn_glds_ok(const st5_gemm_params& p, int dtype) {
   if (dtype != ST5_BF16) return false;
   if (!(p.flags & ST5_GEMM_A_KSTRIDED) || !(p.flags & ST5_GEMM_B_KSTRIDED)) return false;
-  if (p.A.seg || p.B.seg) return false;
+  if ((p.A.seg && (p.A.seg % 8 || p.A.seg_stride % 8)) || (p.B.seg && (p.B.seg % 8 || p.B.seg_stride % 8))) return false;
   if ((p.A.rpb && (p.A.rpb < 64 || p.A.bstride % 8)) || (p.B.rpb && (p.B.rpb < 64 || p.B.bstride % 8))) return false;
   if (p.M % 8 || p.N % 8 || p.A.ld % 8 || p.B.ld % 8 || p.A.zs0 % 8 || p.A.zs1 % 8 || p.B.zs0 % 8 || p.B.zs1 % 8) return false;
   return aligned(p.A.ptr, 16) && aligned(p.B.ptr, 16);

@@ -721,3 +721,36 @@ def test_guided_attention_loss_matches_formula(cuda):
     (got * 0.5).backward()
     assert abs(float(got) - float(ref)) <= 2e-6 * abs(float(ref)), (float(got), float(ref))
     assert float((x.grad.cpu().double() - a.grad).abs().max()) <= 2e-6 * float(a.grad.abs().max())
+
+
+def test_pos_conv_grouped_bf16_matches_torch(cuda):
+    """Positional convolution (speech_encoder_prenet.py:107-118: grouped Conv1d k = 128, 16 groups, SamePad, GELU, residual) in bf16:
+    forward, data gradient and -- through the LDS-DMA TN kernel with a SEGMENTED operand (the haloed activations read as
+    [tap][channel-in-group] windows) -- the weight gradient, against torch on the same bf16-rounded inputs."""
+    from speecht5_amd import functional as Fn
+    torch.manual_seed(11)
+    B, T, d, groups, k = 3, 200, 768, 16, 128
+    cg = d // groups
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        x = (torch.randn(B, T, d, device=cuda) * 0.5).to(torch.bfloat16).requires_grad_(True)
+        w = (torch.randn(d, cg, k, device=cuda) * 0.02).requires_grad_(True)
+        bias = (torch.randn(d, device=cuda) * 0.1).requires_grad_(True)
+        dy = torch.randn(B, T, d, device=cuda).to(torch.bfloat16)
+        y = Fn.pos_conv(x, w, bias, groups)
+        y.backward(dy)
+        xr = x.detach().float().requires_grad_(True)
+        wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+        br = bias.detach().clone().requires_grad_(True)
+        conv = F.conv1d(xr.transpose(1, 2), wr, br, padding=k // 2, groups=groups)[:, :, :T]
+        yr = xr + F.gelu(conv).transpose(1, 2)
+        yr.backward(dy.float())
+        def rel(a, b):
+            return float((a.detach().float() - b.detach()).norm() / b.detach().norm())
+        assert rel(y, yr) < 1e-2, rel(y, yr)
+        assert rel(x.grad, xr.grad) < 2e-2, rel(x.grad, xr.grad)
+        assert rel(w.grad, wr.grad) < 2e-2, rel(w.grad, wr.grad)
+        assert rel(bias.grad, br.grad) < 2e-2, rel(bias.grad, br.grad)
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.weight_cache.clear()
