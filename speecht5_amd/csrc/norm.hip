@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
 // wave's rows, reduced over the block through LDS into a [blocks][2][cols] workspace; a tiny second kernel folds the
 // workspace into dgamma/dbeta (+=).
 // ------------------------------------------------------------------------------------------------
-constexpr int RPW = 4;          // rows per wave per iteration
+constexpr int RPW = 4;          // rows per wave per iteration (forward)
+constexpr int BRPW = 4;         // rows per wave and register set of the backward (two sets in flight)
 int g_ln_max_blocks = 256;     // blocks of the single-pass LayerNorm backward (A/B: st5_layernorm_set_max_blocks)
 
 template <typename T> __device__ __forceinline__ void load4f(const T* p, float (&v)[4]);
@@ -237,36 +238,42 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
     for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
   }
   const float inv_n = 1.f / (float)cols;
-  for (long long row0 = ((long long)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * 4 * RPW) {
-    float xv[RPW][NV][4], gv[RPW][NV][4], mu[RPW], rs[RPW];
+  // Two register sets in ping-pong: the loads of the wave's NEXT rows are issued before the reductions and stores of the current
+  // ones (a wave is alone on its SIMD here -- one block per CU -- so nothing else would cover the HBM latency of a trip).
+  // (operands are kept as loaded -- 8 bytes per 4 bf16 -- and converted when used: two sets of BRPW rows fit in ~100 registers)
+  struct alignas(sizeof(T) * 4) Raw4 { T v[4]; };
+  struct Set { Raw4 xv[BRPW][NV], gv[BRPW][NV]; float mu[BRPW], rs[BRPW]; };
+  auto load_set = [&](Set& S, long long row0) {
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
+    for (int r = 0; r < BRPW; ++r) {
       const long long row = row0 + r < rows ? row0 + r : rows - 1;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
-        if (c < cols) { load4f<T>(x + row * cols + c, xv[r][i]); load4f<T>(dy + row * cols + c, gv[r][i]); }
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { xv[r][i][e] = 0.f; gv[r][i][e] = 0.f; }
+        if (c < cols) {
+          S.xv[r][i] = *reinterpret_cast<const Raw4*>(x + row * cols + c);
+          S.gv[r][i] = *reinterpret_cast<const Raw4*>(dy + row * cols + c);
         }
       }
-      mu[r] = mean[row]; rs[r] = rstd[row];
+      S.mu[r] = mean[row]; S.rs[r] = rstd[row];
     }
+  };
+  auto finish_set = [&](Set& S, long long row0) {
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
+    for (int r = 0; r < BRPW; ++r) {
       const bool live = row0 + r < rows;
       float s1 = 0.f, s2 = 0.f;
+      float xh_[NV][4], gg_[NV][4];
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const bool in = (i * 64 + lane) * 4 < cols;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float xh = in ? (xv[r][i][e] - mu[r]) * rs[r] : 0.f;
-          const float d = gv[r][i][e];
+          const float xh = in ? (Elem<T>::to_f(S.xv[r][i].v[e]) - S.mu[r]) * S.rs[r] : 0.f;
+          const float d = in ? Elem<T>::to_f(S.gv[r][i].v[e]) : 0.f;
           if (PG && live) { dg[i][e] = fmaf(d, xh, dg[i][e]); db[i][e] += d; }
           const float gg = d * g[i][e];
-          xv[r][i][e] = xh; gv[r][i][e] = gg;
+          xh_[i][e] = xh; gg_[i][e] = gg;
           s1 += gg; s2 = fmaf(gg, xh, s2);
         }
       }
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
           if (c < cols) {
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = rs[r] * (gv[r][i][e] - s1 - xv[r][i][e] * s2);
+            for (int e = 0; e < 4; ++e) o[e] = S.rs[r] * (gg_[i][e] - s1 - xh_[i][e] * s2);
             store4f<T>(dx + (row0 + r) * cols + c, o);
             if (dxd) {
               float dsc[4];
@@ -290,6 +297,25 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
             }
           }
         }
+      }
+    }
+  };
+  {
+    const long long stride = (long long)gridDim.x * 4 * BRPW;
+    long long row0 = ((long long)blockIdx.x * 4 + wave) * BRPW;
+    Set A, B;
+    if (row0 < rows) {
+      load_set(A, row0);
+      while (true) {
+        const long long r1 = row0 + stride;
+        if (r1 < rows) load_set(B, r1);
+        finish_set(A, row0);
+        if (r1 >= rows) break;
+        const long long r2 = r1 + stride;
+        if (r2 < rows) load_set(A, r2);
+        finish_set(B, r1);
+        if (r2 >= rows) break;
+        row0 = r2;
       }
     }
   }
@@ -389,8 +415,11 @@ int ln_flush_state(LnDeferState* ls) {
 int ln_flush(hipStream_t s) { return ln_flush_state(ln_state(s, false)); }
 
 int ln_blocks(long long rows) {
-  long long n = (rows + 4 * RPW - 1) / (4 * RPW);
-  return (int)(n < g_ln_max_blocks ? (n < 1 ? 1 : n) : g_ln_max_blocks);
+  long long n = (rows + 4 * BRPW - 1) / (4 * BRPW);   // blocks at one trip per wave
+  if (n < 1) n = 1;
+  if (n <= g_ln_max_blocks) return (int)n;
+  const long long trips = (n + g_ln_max_blocks - 1) / g_ln_max_blocks;   // same number of trips for every wave
+  return (int)((n + trips - 1) / trips);
 }
 
 // ---- column reductions: out[c] (+)= scale * sum_r f(r, c) --------------------------------------
