@@ -217,6 +217,8 @@ def main():
         run()
     barrier()
     dt = time.perf_counter() - t0
+    if use_graph:
+        sg.drain()   # (the helper thread preparing a step that will not run)
     hip.profiler.enabled = False
     if use_graph:
         # roofline leg of the graph mode: the replayed launches carry no events, so the SAME update is enqueued once more

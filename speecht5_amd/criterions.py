@@ -6,6 +6,8 @@ outputs (masked L1/MSE/BCE, guided attention, NCE/label-smoothed CE, CTC) is eva
 device ops in this round -- SURVEY.md 8(f) ranks fusing it as the next row after the model path.
 `sync_logging=False` keeps the logged scalars as device tensors (no `.item()` host syncs inside a timed
 step); the default mirrors the reference and returns Python floats."""
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -19,6 +21,24 @@ def _item(x, sync):
     if not torch.is_tensor(x):
         return x
     return x.detach().item() if sync else x.detach()
+
+
+@contextlib.contextmanager
+def alignment_weights(model, wanted):
+    """The decoder hands back the last layer's head-averaged cross-attention weights with every forward (reference
+    decoder.py:171-269, `alignment_layer`), which costs an unfused attention pass (scores, softmax and probabilities in HBM) in
+    that layer.  Only the guided-attention term of the speech-decoder loss reads them; a criterion that does not says so here
+    and, while training, the layer stays on the fused kernel and the `attn` entry of the output is None.  Loss and gradients are
+    unchanged (tests/test_criterions_gpu.py pins them against the reference's)."""
+    dec = getattr(model, "decoder", None)
+    old = getattr(dec, "materialise_alignment", True)
+    if dec is not None:
+        dec.materialise_alignment = bool(wanted)
+    try:
+        yield
+    finally:
+        if dec is not None:
+            dec.materialise_alignment = old
 
 
 def make_non_pad_mask(lengths, maxlen=None, device=None):
@@ -98,7 +118,8 @@ class TexttoSpeechLoss(nn.Module):
         self.sync_logging = sync_logging
 
     def forward(self, model, sample):
-        net_output = model(**sample["net_input"])
+        with alignment_weights(model, self.use_guided_attn_loss):
+            net_output = model(**sample["net_input"])
         loss, l1, l2, bce, ga = self.compute_loss(model, net_output, sample)
         s = self.sync_logging
         log = {"loss": _item(loss, s), "l1_loss": _item(l1, s), "l2_loss": _item(l2, s), "bce_loss": _item(bce, s),
@@ -171,7 +192,8 @@ class SpeechPretrainCriterion(nn.Module):
         s = self.sync_logging
         if self.dec_weight == 0:
             sample["net_input"]["only_hubert"] = True
-        net_output, net_output_dec = model(target_list=sample["target_list"], **sample["net_input"])
+        with alignment_weights(model, getattr(self.speech_criterion, "use_guided_attn_loss", False)):
+            net_output, net_output_dec = model(target_list=sample["target_list"], **sample["net_input"])
         loss, sample_size, log = 0.0, 0, {}
         reduction = "sum" if reduce else "none"
         logp_m_list = model.get_logits(net_output, True)
@@ -232,7 +254,8 @@ class TextPretrainCriterion(nn.Module):
 
     def forward(self, model, sample, reduce=True):
         s = self.sync_logging
-        net_output, codebook_out, encoder_output = model(**sample["net_input"])
+        with alignment_weights(model, False):
+            net_output, codebook_out, encoder_output = model(**sample["net_input"])
         if reduce:   # fused log-softmax + NLL + logit gradient on the decoder logits (one kernel)
             logits = net_output[0]
             bart_loss = Fn.cross_entropy_sum(logits.reshape(-1, logits.size(-1)), sample["target"].view(-1), 0.0, self.padding_idx)[0]
@@ -297,7 +320,8 @@ class SpeechtoTextLoss(nn.Module):
         s = self.sync_logging
         if self.ce_weight == 0 and self.ctc_weight > 0:
             sample["only_ctc"] = True
-        net_output_decoder, net_output = model(**sample["net_input"])
+        with alignment_weights(model, False):
+            net_output_decoder, net_output = model(**sample["net_input"])
         loss_ce = nll = loss_ctc = None
         if self.ce_weight > 0:
             if reduce:

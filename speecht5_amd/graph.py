@@ -155,6 +155,12 @@ class StepGraph:
         elif self.opt is not None:
             self.opt.t += 1
 
+    def drain(self):
+        """Wait for the helper thread that prepares the next step (prefetch_host): after the last replay it has drawn one unused
+        step's worth of host random numbers; whoever re-seeds the CPU generators afterwards must not race with it."""
+        if self._ahead is not None:
+            self._ahead[0].join()
+
     def __call__(self):
         if self.graph is None:
             self.record()

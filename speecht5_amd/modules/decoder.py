@@ -25,6 +25,7 @@ class TransformerDecoder(FairseqIncrementalDecoder):
         assert not self.cross_self_attention
         self.layers = nn.ModuleList([self.build_decoder_layer(args, no_encoder_attn) for _ in range(args.decoder_layers)])
         self.num_layers = len(self.layers)
+        self.materialise_alignment = True   # criterions.alignment_weights(): whether a training forward returns `attn`
         if args.decoder_normalize_before and not getattr(args, "no_decoder_final_norm", False):
             self.layer_norm = LayerNorm(args.decoder_embed_dim, eps=args.layer_norm_eps)
         else:
@@ -85,7 +86,7 @@ class TransformerDecoder(FairseqIncrementalDecoder):
             if self.training and self.decoder_layerdrop > 0 and float(torch.empty(1).uniform_()) <= self.decoder_layerdrop:
                 x = Fn.layer_boundary(x, layer)   # skipped layer: its (zero) gradient bucket still reports ready here
                 continue  # LayerDropModuleList semantics (torch RNG)
-            want = bool(idx == alignment_layer or alignment_layer == -1)
+            want = bool(idx == alignment_layer or alignment_layer == -1) and (self.materialise_alignment or not self.training)
             x, layer_attn = layer.forward_rows(x, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want,
                                                kv_all=(kv_all, idx * 2 * C, share) if kv_all is not None else None)
             inner_states.append(x.view(B, T, C).transpose(0, 1))

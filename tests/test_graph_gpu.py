@@ -90,6 +90,7 @@ def _run(cuda, dtype, mode, nsteps=3, seed_offset=0):
             sg.record(); sg.record(); sg.capture()
             for _ in range(nsteps - 2):
                 sg.replay()
+            sg.drain()
         else:
             Fn._S.force_static = mode.startswith("static")
             for _ in range(nsteps):
