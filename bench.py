@@ -5,15 +5,16 @@
 
 One step = what one optimizer update of the reference recipe does with --update-freq 2 (SURVEY.md 3.1-3.2,
 8d cfg 2): forward+backward of ONE speech micro-batch (8 x 10 s synthetic 16 kHz clips, HuBERT-mask + NCE +
-mel decoder branch) and ONE text micro-batch (16 x 512 tokens, BART infilling), gradient all-reduce over the
-ranks (RCCL, overlapped with backward), global-norm clip and the fused Adam update.  bf16 compute, fp32
+mel decoder branch) and ONE text micro-batch (16 x 512 tokens, BART infilling) -- side by side on two streams, replayed
+as one HIP graph -- the gradient all-reduce over the ranks (RCCL: one message behind every replay; `--no-graph`: bucketed and
+overlapped with an eagerly enqueued backward), global-norm clip and the fused Adam update.  bf16 compute, fp32
 master weights / statistics; dropout active as in t5_transformer_base (0.1, attention 0.1, pre-net 0.5,
 post-net 0.5); LayerDrop is set to 0 so that every step does the full work.  Inputs are resident in HBM.
 
 value = audio seconds of the speech micro-batches processed per wall second by the whole job.
 Extra objects: `roofline` for the dominant kernel (bf16 NT MFMA GEMM; algorithmic FLOPs of its launches /
-their HIP-event time inside the timed region) and `cpu_baseline` (the CPU oracle, fp32, host cores, one
-10 s clip forward+backward)."""
+their HIP-event time: one eagerly enqueued update right after the timed region when the timed steps are graph replays, which
+carry no events) and `cpu_baseline` (the CPU oracle, fp32, host cores, one 4 s clip forward+backward, median of 5)."""
 import argparse
 import json
 import os
