@@ -47,3 +47,25 @@ def test_draw_outside_a_recorded_step_is_a_plain_call():
     a = st.draw(np.random.random)
     np.random.seed(0)
     assert a == np.random.random() and not st.entries
+
+
+def test_alignment_weights_context_sets_and_restores_the_decoder_flag():
+    """criterions.alignment_weights: a criterion's statement whether it reads the decoder's alignment weights lives only for
+    its model(...) call (also when that call raises); models without a decoder are left alone."""
+    from types import SimpleNamespace
+    from speecht5_amd.criterions import alignment_weights
+    model = SimpleNamespace(decoder=SimpleNamespace(materialise_alignment=True))
+    with alignment_weights(model, False):
+        assert model.decoder.materialise_alignment is False
+        with alignment_weights(model, True):
+            assert model.decoder.materialise_alignment is True
+        assert model.decoder.materialise_alignment is False
+    assert model.decoder.materialise_alignment is True
+    try:
+        with alignment_weights(model, False):
+            raise RuntimeError("forward failed")
+    except RuntimeError:
+        pass
+    assert model.decoder.materialise_alignment is True
+    with alignment_weights(SimpleNamespace(), False):   # (e.g. an encoder-only wrapper)
+        pass
