@@ -16,9 +16,12 @@
  *     queue with its slab arena (st5_gemm_defer_splitk / _flush_splitk; an arena is hipFree'd and re-allocated when it
  *     must grow, which synchronises the device), the split-K slab workspaces, the deferred LayerNorm reductions
  *     (st5_layernorm_defer / _flush) and the workspace of the ordered row scatter.  One host thread may therefore keep
- *     several streams busy at once (the two micro-batches of an update side by side; up to 4 streams with deferred
- *     reductions, 8 with split-K workspaces -- further streams recycle an entry after a device synchronisation), and a
- *     flush only folds what was queued on the stream it is given.  Calling the library from two host threads, or for
+ *     several streams busy at once (the two micro-batches of an update side by side).  Table sizes: 32 streams with
+ *     deferred LayerNorm reductions (a 33rd, e.g. in a test session that keeps creating streams, restarts the table after a
+ *     device synchronisation, provided nothing is queued); 4 with deferred split-K reductions (a 5th takes over an IDLE state:
+ *     fine for streams that are gone, NOT safe between two live streams that run concurrently -- a training process uses
+ *     three); 8 with split-K slab workspaces (taken over after a device synchronisation).  A flush only folds what was
+ *     queued on the stream it is given.  Calling the library from two host threads, or for
  *     two devices from one process, is NOT supported.
  */
 #ifndef SPEECHT5_HIP_H

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_final_multi_kernel(const LnFinalA
 bool g_ln_defer = false;
 // deferred-reduction state, one per stream (as the split-K states of gemm.hip: two backward passes may run on two streams)
 struct LnDeferState { hipStream_t stream; LnFinalArgs pending; int blocks; float* arena; size_t arena_bytes, arena_used; };
-constexpr int LN_DEFER_STREAMS = 4;
+constexpr int LN_DEFER_STREAMS = 32;
 LnDeferState g_lnstates[LN_DEFER_STREAMS] = {};
 int g_nlnstates = 0;
 LnDeferState* ln_state(hipStream_t s, bool create) {
@@ -392,12 +392,16 @@ LnDeferState* ln_state(hipStream_t s, bool create) {
     if (g_lnstates[i].stream == s) return &g_lnstates[i];
   if (!create) return nullptr;
   if (g_nlnstates == LN_DEFER_STREAMS) {
+    // Stream churn (test sessions): start the table over -- only when nothing is queued anywhere and after the device has
+    // drained.  (Handing an idle state from one LIVE stream to another, as the first version did, let the second micro-batch of
+    // a side-by-side update write its partials into the arena the first one's queued reduction still had to read.)
     for (int i = 0; i < g_nlnstates; ++i)
-      if (g_lnstates[i].pending.n == 0) { g_lnstates[i].stream = s; return &g_lnstates[i]; }
-    return nullptr;
+      if (g_lnstates[i].pending.n != 0) return nullptr;
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    g_nlnstates = 0;   // (the slots keep their arenas)
   }
   LnDeferState* d = &g_lnstates[g_nlnstates++];
-  d->stream = s; d->pending.n = 0; d->blocks = 0; d->arena = nullptr; d->arena_bytes = d->arena_used = 0;
+  d->stream = s; d->pending.n = 0; d->blocks = 0; d->arena_used = 0;
   return d;
 }
 #define g_ln_pending (ls->pending)
