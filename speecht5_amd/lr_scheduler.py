@@ -2,8 +2,10 @@
 :188-191 ASR/TTS fine-tuning `tri_stage`, :305-307 `inverse_sqrt`), host-side scalars fed to `ddp.FusedAdam.lr`.
 
 The schedulers themselves live in fairseq (third party, un-vendored, version unpinned: SURVEY.md 8c), so these are
-restatements of fairseq's published definitions, not of code under /root/reference -- "parity unpinned" for this file;
-tests/test_lr_scheduler.py checks the defining properties (end points, continuity, the README flag values).
+restatements of fairseq's published definitions, not of code under /root/reference.  tests/test_lr_scheduler.py checks the
+defining properties (end points, continuity, the README flag values) and, for `polynomial_decay` and `inverse_sqrt`, agreement
+with an independent installed implementation of the same schedules (HuggingFace transformers) to fp64 round-off; `tri_stage` has
+no second implementation here and stays "parity unpinned".
 
 Usage:  sched = PolynomialDecaySchedule(2e-4, warmup_updates=64000, total_num_update=800000)
         opt.lr = sched.step_update(num_updates)      # once per optimizer step, before opt.step()

@@ -54,3 +54,44 @@ def test_build_from_flags():
     assert build_lr_scheduler(b).step_update(80000) == pytest.approx(3e-6)
     with pytest.raises(ValueError):
         build_lr_scheduler(Namespace(lr=1.0, lr_scheduler="cosine"))
+
+
+def _hf_curve(make, lr, steps):
+    """Learning rates an independent, installed implementation of the same published schedule yields (HuggingFace transformers
+    `optimization.py`: a LambdaLR over a dummy optimizer), at the given update counts."""
+    import torch
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=lr)
+    sched = make(opt)
+    out, n = {}, 0
+    want = set(steps)
+    while n <= max(steps):
+        if n in want:
+            out[n] = opt.param_groups[0]["lr"]
+        opt.step()
+        sched.step()
+        n += 1
+    return out
+
+
+def test_polynomial_decay_and_inverse_sqrt_agree_with_an_independent_implementation():
+    """fairseq is un-vendored (the schedules here are restatements of its definitions), but the two published schedules
+    `polynomial_decay` (with warm-up) and `inverse_sqrt` also exist in HuggingFace transformers, written independently: same curve
+    to fp64 round-off at the README's hyper-parameters (scaled down 100x in length so that the loop stays short)."""
+    from transformers import get_inverse_sqrt_schedule, get_polynomial_decay_schedule_with_warmup
+    lr, warm, total = 2e-4, 640, 8000           # README.md:114-119 has 64000 / 800000
+    steps = [0, 1, 2, 100, 639, 640, 641, 1000, 4000, 7999, 8000]
+    ours = PolynomialDecaySchedule(lr, warmup_updates=warm, total_num_update=total, end_learning_rate=0.0, power=1.0)
+    hf = _hf_curve(lambda o: get_polynomial_decay_schedule_with_warmup(o, warm, total, lr_end=0.0, power=1.0), lr, steps)
+    for n in steps:
+        assert abs(ours.step_update(n) - hf[n]) <= 1e-12 * lr + 1e-18, ("polynomial_decay", n, ours.lr, hf[n])
+    ours = PolynomialDecaySchedule(lr, warmup_updates=warm, total_num_update=total, end_learning_rate=1e-6, power=2.0)
+    hf = _hf_curve(lambda o: get_polynomial_decay_schedule_with_warmup(o, warm, total, lr_end=1e-6, power=2.0), lr, steps)
+    for n in steps:
+        assert abs(ours.step_update(n) - hf[n]) <= 1e-12 * lr + 1e-18, ("polynomial_decay power 2", n, ours.lr, hf[n])
+    lr, warm = 1e-3, 400                           # README.md:305-307 has 4000
+    steps = [0, 1, 100, 399, 400, 401, 1600, 6400]
+    ours = InverseSqrtSchedule(lr, warmup_updates=warm)
+    hf = _hf_curve(lambda o: get_inverse_sqrt_schedule(o, warm), lr, steps)
+    for n in steps:
+        assert abs(ours.step_update(n) - hf[n]) <= 1e-12 * lr + 1e-18, ("inverse_sqrt", n, ours.lr, hf[n])
