@@ -1,15 +1,17 @@
 #!/usr/bin/env python
 """SpeechT5-Base pre-training step benchmark on MI355X (BASELINE.json metric: audio-sec/s forward+backward).
 
-  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W      (N>1: one rank per GPU; launched by torch.distributed.run, or -- from a
+                                                      bare shell, WORLD_SIZE unset -- bench.py re-executes itself under it)
 
 One step = what one optimizer update of the reference recipe does with --update-freq 2 (SURVEY.md 3.1-3.2,
 8d cfg 2): forward+backward of ONE speech micro-batch (8 x 10 s synthetic 16 kHz clips, HuBERT-mask + NCE +
 mel decoder branch) and ONE text micro-batch (16 x 512 tokens, BART infilling) -- side by side on two streams, replayed
 as one HIP graph -- the gradient all-reduce over the ranks (RCCL: one message behind every replay; `--no-graph`: bucketed and
 overlapped with an eagerly enqueued backward), global-norm clip and the fused Adam update.  bf16 compute, fp32
-master weights / statistics; dropout active as in t5_transformer_base (0.1, attention 0.1, pre-net 0.5,
-post-net 0.5); LayerDrop is set to 0 so that every step does the full work.  Inputs are resident in HBM.
+master weights / statistics; dropout and LayerDrop active as t5_transformer_base ships them (0.1, attention 0.1, pre-net 0.5,
+post-net 0.5; encoder / decoder LayerDrop 0.05, models/speecht5.py:1397-1398 -- inside the replayed graph a dropped layer is
+selected away on the device, i.e. it still runs: no work is skipped in the timed region).  Inputs are resident in HBM.
 
 value = audio seconds of the speech micro-batches processed per wall second by the whole job.
 Extra objects: `roofline` for the dominant kernel (bf16 NT MFMA GEMM; algorithmic FLOPs of its launches /
@@ -35,17 +37,16 @@ sys.path.insert(0, ROOT)
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 
 
-def build(device, compute_dtype, arch="base"):
+def build(device, compute_dtype, arch="base", layerdrop=0.05):
     from speecht5_amd import functional as Fn
     from speecht5_amd.criterions import SpeechT5Criterion
     from speecht5_amd.speecht5 import t5_transformer_base, t5_transformer_large
     from speecht5_amd.task import SpeechT5Task
     Fn.set_compute_dtype(compute_dtype)
     args = Namespace(label_rates=50, sample_rate=16000, speech_odim=80, bert_init=True, use_codebook=True,
-                     share_input_output_embed=True, encoder_layerdrop=0.0, decoder_layerdrop=0.0)
+                     share_input_output_embed=True, encoder_layerdrop=layerdrop, decoder_layerdrop=layerdrop)
     (t5_transformer_large if arch == "large" else t5_transformer_base)(args)
-    if arch == "large":   # (the architecture function leaves the LayerDrop default of 0.05 in: not replayable, see graph.py)
-        args.encoder_layerdrop = args.decoder_layerdrop = 0.0
+    args.encoder_layerdrop = args.decoder_layerdrop = layerdrop
     task = SpeechT5Task.synthetic(args)
     torch.manual_seed(1337)
     model = task.build_model(args).to(device)
@@ -53,7 +54,8 @@ def build(device, compute_dtype, arch="base"):
     return args, task, model, crit
 
 
-PMC_TRAFFIC_FILE = "r2_pmc_traffic.json"   # written by tools/pmc_traffic.sh
+PMC_TRAFFIC_FILE = "r3_pmc_traffic.json"   # written by tools/pmc_traffic.sh
+NT_KERNEL_NAME = "gemm_nt_glds_kernel"      # the dominant kernel of the update (most NT launches)
 
 
 def cpu_baseline(model, args, seconds=4.0, runs=5):
@@ -87,6 +89,40 @@ def cpu_baseline(model, args, seconds=4.0, runs=5):
                       f"{t:.2f} s per run (min {ts[0]:.2f}, max {ts[-1]:.2f})"}
 
 
+def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, graph=True, micro="side_by_side", layerdrop=0.05,
+                wgrad_stream=None, prefetch_host=True, text_batch=16, text_len=512, seconds=10.0):
+    """The update bench.py times, as an object (speecht5_amd/update.py): model, criterion, the two synthetic micro-batches of
+    BASELINE.json cfg 2, FlatGradDataParallel + FusedAdam with the recipe's hyper-parameters.  tests/test_bench_update_gpu.py
+    builds its runs from this function too."""
+    import numpy as np
+    from speecht5_amd import functional as Fn
+    from speecht5_amd.synthetic import speech_pretrain_sample, text_pretrain_sample
+    from speecht5_amd.update import PretrainUpdate
+    args, task, model, crit = build(device, dtype, arch, layerdrop)
+    Fn.manual_seed(1337 + rank)
+    np.random.seed(1337 + rank)
+    torch.manual_seed(1337 + rank)
+    vocab = len(task.dicts["text"])
+    speech = speech_pretrain_sample(B=batch, seconds=seconds, device=device, seed=1337 + rank)
+    text = text_pretrain_sample(B=text_batch, T=text_len, vocab=vocab, mask_idx=task.dicts["text"].index("<mask>"), device=device, seed=2337 + rank)
+    upd = PretrainUpdate(task, model, crit, [speech, text], lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0,
+                         graph=graph, micro=micro, wgrad_stream=wgrad_stream, prefetch_host=prefetch_host, device=device)
+    return args, task, model, upd
+
+
+def respawn(a):
+    """`python bench.py --gpus N` from a bare shell: run N ranks of this script under torch.distributed.run (one per GPU; when
+    the box has fewer GPUs than ranks -- a functional check on a 1-GPU box -- the ranks share devices and talk over gloo)."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", 29500 + os.getpid() % 400))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,115 +135,67 @@ def main():
                     help="large = t5_transformer_large (24 + 6 layers, d = 1024, pre-LN), same two micro-batches, bf16 GEMMs: a side "
                          "measurement (BASELINE.json cfg 5 asks for fp8 GEMMs, which do not exist here); the headline is base")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying a captured HIP graph")
+    ap.add_argument("--layerdrop", type=float, default=0.05, help="encoder / decoder LayerDrop (t5_transformer_base: 0.05)")
+    ap.add_argument("--micro", default="side_by_side", choices=["side_by_side", "in_turn_2buf", "in_turn"],
+                    help="how the update's two micro-batches are enqueued (speecht5_amd/update.py)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    ndev = torch.cuda.device_count()
+    assert ndev >= 1, "bench.py needs a GPU"
+    shared = ndev < world          # functional check only: several ranks per device, gloo instead of RCCL
+    local = local % ndev
+    torch.cuda.set_device(local)
+    device = torch.device(f"cuda:{local}")
     if world > 1 or os.environ.get("ST5_DDP_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    device = torch.device(f"cuda:{local}")
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from speecht5_amd import functional as Fn, hip
-    from speecht5_amd.ddp import FlatGradDataParallel, FusedAdam
-    from speecht5_amd.synthetic import speech_pretrain_sample, text_pretrain_sample
+    from speecht5_amd import hip
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    args, task, model, crit = build(device, dtype, a.arch)
     # The update is captured into a HIP graph after the warm-up steps and REPLAYED in the timed region (fresh dropout
-    # seeds / span masks / lr per replay: speecht5_amd/graph.py).  ST5_GRAPH=0 or --no-graph: eager enqueue (with the bucketed
-    # all-reduces overlapped with the backward when there are several ranks).
+    # seeds / span masks / LayerDrop flags / lr per replay: speecht5_amd/graph.py).  ST5_GRAPH=0 or --no-graph: eager enqueue
+    # (with the bucketed all-reduces overlapped with the backward when there are several ranks).
     use_graph = not a.no_graph and os.environ.get("ST5_GRAPH", "1") == "1"
-    overlap_fwd = use_graph and os.environ.get("ST5_OVERLAP_FWD", "1") == "1"   # (eager enqueue is host-bound: nothing to gain)
-    # several ranks: the captured part is the local phase (both micro-batches, no collectives); ONE all-reduce of the flat
-    # gradient buffer and the Adam step follow every replay eagerly (ddp.local_phase / all_reduce_gradients)
-    split_update = use_graph and dist.is_initialized()
-    assert overlap_fwd or not split_update, "replayed multi-rank update: needs the side-by-side micro-batches (ST5_OVERLAP_FWD=1)"
-    wgrad_env = os.environ.get("ST5_WGRAD_STREAM")
-    # replayed step: forward passes of the two micro-batches side by side, no weight-gradient stream (see ddp.py); eager step:
-    # the weight-gradient stream hides ~3.5 ms of dW GEMMs behind the data-gradient chain
+    micro_mode = a.micro if use_graph else ("in_turn" if a.micro == "side_by_side" else a.micro)   # (eager enqueue is host-bound: nothing to gain)
+    if os.environ.get("ST5_OVERLAP_FWD", "1") != "1":
+        micro_mode = "in_turn"
     if os.environ.get("ST5_NT_TILE"):   # A/B: 1 = 128x128 always, 2 = 256x256 always (default: per problem)
         hip.lib().st5_gemm_set_nt_tile(int(os.environ["ST5_NT_TILE"]))
     if os.environ.get("ST5_DEEP_RING"):   # A/B: "max_blocks,nbuf" of the 128x128 NT kernel's deep operand ring (nbuf 2 = off)
         hip.lib().st5_gemm_set_deep_ring(*[int(v) for v in os.environ["ST5_DEEP_RING"].split(",")])
     if os.environ.get("ST5_SPLITK_TARGET"):   # A/B: block count the weight-gradient split-K aims for
         hip.lib().st5_gemm_set_splitk_target(int(os.environ["ST5_SPLITK_TARGET"]))
-    ddp = FlatGradDataParallel(model, wgrad_stream=(wgrad_env == "1") if wgrad_env is not None else not (use_graph and overlap_fwd))
-    opt = FusedAdam(ddp, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0)
-    Fn.manual_seed(1337 + rank)
-    import numpy as np
-    np.random.seed(1337 + rank)
-    torch.manual_seed(1337 + rank)
-    vocab = len(task.dicts["text"])
-    speech = speech_pretrain_sample(B=a.batch, seconds=10.0, device=device, seed=1337 + rank)
-    text = text_pretrain_sample(B=16, T=512, vocab=vocab, mask_idx=task.dicts["text"].index("<mask>"), device=device, seed=2337 + rank)
-    micro = [speech, text]
-
-    def local_part(i):   # (split_update) what the graph holds: gradients of this rank's two micro-batches, summed into ddp.flat
-        ddp.zero_grad()
-        with ddp.local_phase():
-            ddp.accumulate_overlapped(micro, lambda s: task.forward_loss(s, model, crit, i))
-        ddp.sum_gradient_buffers()
-
-    def exchange_and_update():   # (split_update) eager tail: sum over ranks, then mean over ranks and micro-batches inside Adam
-        ddp.all_reduce_gradients(average=False)
-        opt.step(grad_scale=1.0 / (len(micro) * world))
-
-    def step(i):
-        if split_update:
-            local_part(i)
-            exchange_and_update()
-            return
-        ddp.zero_grad()
-        # --update-freq 2: gradients of the first micro-batch only accumulate (no_sync); the bucket all-reduces are
-        # launched from the backward of the LAST micro-batch, each bucket once, after its last local contribution
-        if overlap_fwd:   # the two micro-batches side by side on two streams, forward and backward (two gradient buffers)
-            ddp.accumulate_overlapped(micro, lambda s: task.forward_loss(s, model, crit, i))
-        else:
-            ddp.accumulate(micro, lambda s: task.train_step(s, model, crit, None, i, sync=False))
-        ddp.finish()
-        opt.step(grad_scale=1.0 / len(micro))
+    wgrad_env = os.environ.get("ST5_WGRAD_STREAM")
+    args, task, model, upd = make_update(device, dtype, a.arch, a.batch, rank, graph=use_graph, micro=micro_mode, layerdrop=a.layerdrop,
+                                         wgrad_stream=(wgrad_env == "1") if wgrad_env is not None else None,
+                                         prefetch_host=os.environ.get("ST5_PREFETCH_HOST", "1") == "1")
+    split_update = upd.split
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    counter = [0]
-
-    def one_update():
-        (local_part if split_update else step)(counter[0])
-
-    def advance():   # host-side state a replayed step does not touch: the update counter behind the quantizer temperature etc.
-        counter[0] += 1
-        model.set_num_updates(counter[0])
-
     if use_graph:
-        from speecht5_amd.graph import StepGraph
-        sg = StepGraph(one_update, opt=opt, model=model, device=device, on_step=advance, prefetch_host=os.environ.get("ST5_PREFETCH_HOST", "1") == "1",
-                       after_fn=exchange_and_update if split_update else None)
-        # untimed: eager steps, the two recording steps, and ONE replay (the first launch of a graph uploads it to the device:
-        # ~150 ms that belong to set-up, not to the steady state) -- W updates in all when W >= 4, else 4
-        n_eager = max(a.warmup - 3, 1)
-        for i in range(n_eager):
-            step(i)
-        counter[0] = n_eager - 1
-        sg.record()
-        sg.record()
-        sg.capture()
-        cap_stream = sg.stream
-
-        def run():
-            with torch.cuda.stream(cap_stream):
-                sg.replay()
-        run()
+        # untimed: eager updates, the two recording updates, and ONE replay (the first launch of a graph uploads it to the
+        # device: ~150 ms that belong to set-up, not to the steady state) -- W updates in all when W >= 4, else 4
+        for _ in range(max(a.warmup - 3, 1)):
+            upd.eager_update()
+        upd.prepare_graph()
+        upd.update()
     else:
-        for i in range(a.warmup):
-            step(i)
-        run = lambda: step(a.warmup)
+        for _ in range(a.warmup):
+            upd.eager_update()
     barrier()
     hip.profiler.reset()
     t0 = time.perf_counter()
@@ -215,21 +203,24 @@ def main():
         # eager mode: HIP events around every st5_gemm launch of the LAST timed step (recording them on all K steps costs
         # ~10 % of the step in host time: two events per launch, ~750 launches per step)
         hip.profiler.enabled = (not use_graph) and (i == a.steps - 1)
-        run()
+        upd.update()
     barrier()
     dt = time.perf_counter() - t0
-    if use_graph:
-        sg.drain()   # (the helper thread preparing a step that will not run)
+    upd.finish()
     hip.profiler.enabled = False
     if use_graph:
         # roofline leg of the graph mode: the replayed launches carry no events, so the SAME update is enqueued once more
-        # eagerly, outside the timed region, with HIP events around every st5_gemm launch (same kernels, shapes, streams)
+        # eagerly, outside the timed region, with HIP events around every st5_gemm launch (same kernels, shapes, streams; the
+        # fixed-shape / device-side-LayerDrop forms the graph is made of)
+        from speecht5_amd import functional as Fn
         hip.profiler.enabled = True
-        step(a.warmup)
+        Fn._S.force_static = True
+        upd.eager_update()
+        Fn._S.force_static = False
         torch.cuda.synchronize()
         hip.profiler.enabled = False
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -249,7 +240,7 @@ def main():
         import hashlib
         cur = hashlib.sha1(open(os.path.join(here, "speecht5_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:12]
         if pm.get("gemm_hip_sha1") == cur and a.dtype == "bf16":
-            cand = [v for kname, v in pm["kernels"].items() if "gemm_nt_glds_kernel" in kname]
+            cand = [v for kname, v in pm["kernels"].items() if NT_KERNEL_NAME in kname]
             if cand:
                 v = max(cand, key=lambda v: v["launches"])   # (the bf16 instantiation; the fp32 one serves the NCE head)
                 traffic = v["hbm_corrected_bytes_per_launch"]
@@ -257,9 +248,8 @@ def main():
     except Exception:
         traffic = None
     alg_bytes = hip.profiler.nt_bytes_per_launch() if hasattr(hip.profiler, "nt_bytes_per_launch") else None
-    roof = {"bound": "mfma", "kernel": f"NT-form st5_gemm launches <{a.dtype}>: gemm_nt_glds_kernel (128x128 tiles: Linear / attention-projection "
-                      "forward and data-gradient GEMMs) + gemm_nt256_kernel (256x256 tiles: the long conv feature-extractor GEMMs); "
-                      "`traffic` is per launch of gemm_nt_glds_kernel",
+    roof = {"bound": "mfma", "kernel": f"NT-form st5_gemm launches <{a.dtype}> (Linear / attention-projection / conv forward and data-gradient GEMMs; "
+                      f"`traffic` is per launch of {NT_KERNEL_NAME})",
             "note": ("launch durations: HIP events around every st5_gemm launch of ONE eagerly enqueued update after the timed region "
                      "(replayed launches carry no events), micro-batches side by side on two streams as in the timed steps"
                      if use_graph else
@@ -272,24 +262,46 @@ def main():
             "launches_per_step": n, "sampled_steps": 1, "avg_launch_us": round(secs / max(n, 1) * 1e6, 2),
             "all_variants": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None,
                                  "ms_per_step": round(v[2] * 1e3, 3)} for k, v in sorted(prof.items())}}
-    # HBM-bound leg ("HBM GB/s (conv frontend)"): conv layer 0 + GroupNorm + GELU, same HIP-event method
-    hbm = {}
+    # whole update against the MFMA peak: algorithmic FLOPs of every st5_gemm launch of the sampled update (fwd + bwd,
+    # all variants; attention-core FLOPs are not GEMM launches and are left out) / the step time
+    all_flops = sum(v[1] for v in prof.values())
+    roof["step"] = {"gemm_tflop_per_update": round(all_flops / 1e12, 3), "ms": round(dt / a.steps * 1e3, 3),
+                    "tflops": round(all_flops / (dt / a.steps) / 1e12, 1), "frac_of_peak": round(all_flops / (dt / a.steps) / 1e12 / peak, 4)}
+    # HBM-bound leg ("HBM GB/s (conv frontend)"): conv layer 0 + GroupNorm + GELU, and the frontend as a unit
+    # (7 conv layers: 324.8 MB per 10 s clip fwd + bwd in bf16), same HIP-event method
+    hbm, rfl = {}, hip.profiler.region_flops()
     for name, (n_, b_, t_) in sorted(hip.profiler.region_summary().items()):
-        hbm[name] = {"launches": n_, "algorithmic_MB": round(b_ / n_ / 1e6, 1), "achieved_GBps": round(b_ / t_ / 1e9, 1) if t_ > 0 else None,
+        hbm[name] = {"launches": n_, "algorithmic_MB": round(b_ / n_ / 1e6, 1), "ms": round(t_ / n_ * 1e3, 4), "achieved_GBps": round(b_ / t_ / 1e9, 1) if t_ > 0 else None,
                      "frac_of_8TBps": round(b_ / t_ / 8e12, 4) if t_ > 0 else None}
+        if rfl.get(name):
+            hbm[name]["tflops"] = round(rfl[name] / t_ / 1e12, 1) if t_ > 0 else None
+    front = [hbm.pop(k) for k in ("conv_frontend_fwd", "conv_frontend_bwd") if k in hbm]
+    if len(front) == 2:
+        fb, ft = sum(f["algorithmic_MB"] for f in front), sum(f["ms"] for f in front)
+        ffl = rfl.get("conv_frontend_fwd", 0.0) + rfl.get("conv_frontend_bwd", 0.0)
+        roof["frontend"] = {"what": "conv feature extractor as a unit (7 layers, GroupNorm + GELU fused), forward + backward of the speech micro-batch; "
+                                    "HIP events around the whole launch sequence of the sampled update",
+                            "bytes": int(fb * 1e6), "ms": round(ft, 4), "GBps": round(fb / ft, 1), "frac_of_8TBps": round(fb / ft / 8e3, 4),
+                            "tflops": round(ffl / (ft * 1e-3) / 1e12, 1), "fwd": front[0], "bwd": front[1]}
     roof["hbm_bound_kernels"] = hbm
     if rank == 0:
-        out = {"metric": "audio-sec/s fwd+bwd SpeechT5-" + ("Large" if a.arch == "large" else "Base"), "value": round(audio_seconds / dt, 2), "unit": "audio-sec/s",
+        nm = "Large" if a.arch == "large" else "Base"
+        out = {"metric": f"audio-sec/s fwd+bwd SpeechT5-{nm}", "value": round(audio_seconds / dt, 2), "unit": "audio-sec/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "SpeechT5-" + ("Large" if a.arch == "large" else "Base") + " pretrain step (speech 8x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
+               "config": {"workload": f"SpeechT5-{nm} pretrain step (speech {a.batch}x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
                                       "fwd+bwd+allreduce+clip+Adam, per GPU", "arch": ("t5_transformer_large (24 enc + 6 dec, d=1024, pre-LN, layer-norm feature extractor)" if a.arch == "large"
                                    else "t5_transformer_base (12 enc + 6 dec, d=768)"),
                           "enqueue": ("hip-graph replay of the local phase + eager all-reduce (one message) + Adam" if split_update else
-                                      "hip-graph replay" if use_graph else "eager"), "micro_batches": "forward and backward side by side on two streams, two gradient buffers" if overlap_fwd else "in turn",
+                                      "hip-graph replay" if use_graph else "eager"),
+                          "micro_batches": {"side_by_side": "forward and backward side by side on two streams, two gradient buffers",
+                                            "in_turn_2buf": "in turn, two gradient buffers", "in_turn": "in turn"}[micro_mode],
                           "global_speech_batch": a.batch * world, "clip_seconds": 10, "parallelism": f"dp{world}",
-                          "dropout": 0.1, "layerdrop": 0.0},
+                          "dropout": 0.1, "layerdrop": a.layerdrop,
+                          "layerdrop_form": ("device-side select (every layer runs)" if use_graph else "host skip") if a.layerdrop > 0 else "off"},
                "roofline": roof}
+        if shared:
+            out["config"]["note"] = f"FUNCTIONAL CHECK ONLY: {world} ranks share {ndev} GPU(s), gradients exchanged over gloo"
         if world == 1 and not a.no_cpu_baseline and a.arch == "base":
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out))

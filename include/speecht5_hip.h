@@ -17,10 +17,10 @@
  *     must grow, which synchronises the device), the split-K slab workspaces, the deferred LayerNorm reductions
  *     (st5_layernorm_defer / _flush) and the workspace of the ordered row scatter.  One host thread may therefore keep
  *     several streams busy at once (the two micro-batches of an update side by side).  Table sizes: 32 streams with
- *     deferred LayerNorm reductions (a 33rd, e.g. in a test session that keeps creating streams, restarts the table after a
- *     device synchronisation, provided nothing is queued); 4 with deferred split-K reductions (a 5th takes over an IDLE state:
- *     fine for streams that are gone, NOT safe between two live streams that run concurrently -- a training process uses
- *     three); 8 with split-K slab workspaces (taken over after a device synchronisation).  A flush only folds what was
+ *     deferred LayerNorm reductions and 32 with deferred split-K reductions (a 33rd, e.g. in a test session that keeps
+ *     creating streams, restarts the table after a device synchronisation, provided nothing is queued on any state -- a
+ *     state is never handed from one live stream to another); 8 with split-K slab workspaces (taken over after a device
+ *     synchronisation).  A flush only folds what was
  *     queued on the stream it is given.  Calling the library from two host threads, or for
  *     two devices from one process, is NOT supported.
  */
@@ -219,6 +219,12 @@ int64_t st5_colsum_ws_bytes(int64_t rows, int32_t cols);
 int st5_sumsq(const void* x, float* out, int64_t n, float scale, int32_t accumulate, int dtype, void* stream);
 /* y = a*x + b*y */
 int st5_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, void* stream);
+/* LayerDrop inside a replayed (HIP-graph) step, where the host's per-layer draw cannot steer control flow
+ * (modules/encoder.py:251-257 `if not self.training or (dropout_probability > self.encoder_layerdrop)`, modules/decoder.py:64-67
+ * LayerDropModuleList): every layer runs and  y = keep ? b (layer output) : a (layer input),  keep = one float in device memory
+ * written from the host draw before the replay; backward (ga, gb) = keep ? (0, g) : (g, 0).  Raw 16-byte chunks, any dtype. */
+int st5_select(const float* keep_dev, const void* a, const void* b, void* y, int64_t nbytes, void* stream);
+int st5_select_bwd(const float* keep_dev, const void* g, void* ga, void* gb, int64_t nbytes, void* stream);
 /* y = act(x) ; dx = dy * act'(x) */
 int st5_act_fwd(const void* x, void* y, int64_t n, int32_t act, int dtype, void* stream);
 int st5_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int32_t act, int dtype, void* stream);

@@ -94,6 +94,25 @@ struct Drop {
   __device__ float operator()(float x, long long i) const { return x * dropout_scale(seed, (unsigned long long)i, thresh, inv_keep); }
 };
 
+// ---- LayerDrop as a device-side select (a captured step cannot branch on the host draw; encoder.py:251-257, decoder.py:64-67) ----
+// y = keep ? layer_out : layer_in, bytes moved untouched (16-byte chunks); backward: (g_in, g_out) = keep ? (0, g) : (g, 0).
+// `keep` is ONE float in device memory, refreshed before every replay from the host draw of that layer.
+__global__ __launch_bounds__(256) void select_fwd_kernel(const float* __restrict__ keep, const u32x4* __restrict__ a, const u32x4* __restrict__ b,
+                                                         u32x4* __restrict__ y, long long nv) {
+  const u32x4* __restrict__ src = keep[0] != 0.f ? b : a;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) y[i] = src[i];
+}
+__global__ __launch_bounds__(256) void select_bwd_kernel(const float* __restrict__ keep, const u32x4* __restrict__ g, u32x4* __restrict__ ga,
+                                                         u32x4* __restrict__ gb, long long nv) {
+  const bool k = keep[0] != 0.f;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    const u32x4 v = g[i];
+    ga[i] = k ? z : v;
+    gb[i] = k ? v : z;
+  }
+}
+
 // ---- sum of squares ----
 template <typename T>
 __global__ void sumsq_kernel(const T* __restrict__ x, float* __restrict__ part, long long n) {
@@ -612,6 +631,24 @@ extern "C" int st5_axpby(const void* x, void* y, int64_t n, float a, float b, in
   Axpby f{a, b};
   DISPATCH(dtype, hipLaunchKernelGGL((map2_kernel<bf16_t, Axpby>), grid_for(n / 8 + 1), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)y, (long long)n, f),
            hipLaunchKernelGGL((map2_kernel<float, Axpby>), grid_for(n / 8 + 1), dim3(256), 0, s, (const float*)x, (const float*)y, (float*)y, (long long)n, f));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_select(const float* keep_dev, const void* a, const void* b, void* y, int64_t nbytes, void* stream) {
+  if (!keep_dev || !a || !b || !y || nbytes < 0 || nbytes % 16) return ST5_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) % 16) return ST5_ERR_ALIGN;
+  if (nbytes == 0) return ST5_OK;
+  hipLaunchKernelGGL(select_fwd_kernel, grid_for(nbytes / 16), dim3(256), 0, (hipStream_t)stream, keep_dev, (const u32x4*)a, (const u32x4*)b,
+                     (u32x4*)y, (long long)(nbytes / 16));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_select_bwd(const float* keep_dev, const void* g, void* ga, void* gb, int64_t nbytes, void* stream) {
+  if (!keep_dev || !g || !ga || !gb || nbytes < 0 || nbytes % 16) return ST5_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(ga) | reinterpret_cast<uintptr_t>(gb)) % 16) return ST5_ERR_ALIGN;
+  if (nbytes == 0) return ST5_OK;
+  hipLaunchKernelGGL(select_bwd_kernel, grid_for(nbytes / 16), dim3(256), 0, (hipStream_t)stream, keep_dev, (const u32x4*)g, (u32x4*)ga,
+                     (u32x4*)gb, (long long)(nbytes / 16));
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

@@ -608,20 +608,25 @@ struct DeferState {
   float* arena;              // slab arena for deferred reductions (grown between flushes only)
   size_t arena_bytes, arena_used;
 };
-constexpr int DEFER_STREAMS = 4;
+constexpr int DEFER_STREAMS = 32;
 DeferState g_dstates[DEFER_STREAMS] = {};
 int g_ndstates = 0;
 DeferState* defer_state(hipStream_t s, bool create) {
   for (int i = 0; i < g_ndstates; ++i)
     if (g_dstates[i].stream == s) return &g_dstates[i];
   if (!create) return nullptr;
-  if (g_ndstates == DEFER_STREAMS) {   // stream churn (tests): recycle an idle state
+  if (g_ndstates == DEFER_STREAMS) {
+    // Stream churn (a test session that keeps creating streams): start the table over -- only when nothing is queued on
+    // any state and after the device has drained, the rule of the LayerNorm table (norm.hip).  A state is never handed from
+    // one stream to another while either may still have work in flight: the second micro-batch of a side-by-side update
+    // would otherwise write its slabs into the arena the first one's queued reduction still has to read.
     for (int i = 0; i < g_ndstates; ++i)
-      if (g_dstates[i].pending.n == 0) { g_dstates[i].stream = s; return &g_dstates[i]; }
-    return nullptr;
+      if (g_dstates[i].pending.n != 0) return nullptr;
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    g_ndstates = 0;   // (the slots keep their arenas)
   }
   DeferState* d = &g_dstates[g_ndstates++];
-  d->stream = s; d->pending.n = 0; d->pending_blocks = 0; d->arena = nullptr; d->arena_bytes = d->arena_used = 0;
+  d->stream = s; d->pending.n = 0; d->pending_blocks = 0; d->arena_used = 0;
   return d;
 }
 #define g_pending (ds->pending)

@@ -150,6 +150,9 @@ class FlatGradDataParallel:
 
     # -- hooks -------------------------------------------------------------------------------------
     def _boundary(self, x, module, tag=None):
+        # a forward through the model precedes every backward that writes the gradient buffers: whatever FusedAdam.step left
+        # zeroed is not known to be zero any more (zero_grad() must fill again unless another step() intervenes)
+        self._grads_zeroed = False
         bi = self.module_bucket.get((id(module), tag))
         if bi is None or not self.collectives or self._local_phase or not x.requires_grad:
             return x
@@ -295,6 +298,7 @@ class FlatGradDataParallel:
     @contextlib.contextmanager
     def _grad_slot(self, slot):
         """param.grad -> views of gradient buffer `slot` (0 = the flat buffer, 1 = its twin) while a backward is enqueued."""
+        self._grads_zeroed = False
         if slot == 0:
             yield
             return
@@ -454,7 +458,10 @@ def default_buckets(model):
     ehead = [m for m in (getattr(model, n, None) for n in ("hubert_layer", "quantizer")) if m is not None]
     if dec is not None and hasattr(dec, "layers") and len(dec.layers) > 1 and all(getattr(l, "encoder_attn", None) is not None for l in dec.layers):
         ehead.append(_CrossKV(dec.layers))   # (listed after the decoder layers: this group owns these projections)
-    if ehead and enc is not None:
+    # --unb-enc-layer >= 0: the decoder (cross-attention K/V) and the quantizer read an INTERMEDIATE encoder state taken before
+    # the (enc, "out") boundary (speecht5.py: decoder_input), so that boundary's backward does not imply their gradients are
+    # complete: those parameters then stay in the final bucket, which only finish() reduces
+    if ehead and enc is not None and getattr(enc, "unb_enc_layer", -1) < 0:
         groups.append(BucketGroup(ehead, triggers=[(enc, "out")]))
     if enc is not None and hasattr(enc, "layers"):
         groups += [BucketGroup([l]) for l in reversed(list(enc.layers))]
@@ -515,10 +522,15 @@ class FusedAdam:
         loss.backward()
 
     def step(self, grad_scale=1.0):
+        """One update; CONSUMES the gradients (both buffers are left zeroed by the kernel).  The device copy of (lr, step) is
+        read only by a step that is being captured into a HIP graph (its kernel arguments are frozen; graph.StepGraph refreshes
+        the two floats before every replay): an eagerly enqueued step -- warm-up, a batch that cannot be replayed, the eager tail
+        of a several-rank replay -- passes them by value, so it can never run with a stale or never-pushed device image."""
         from . import hip
         self.t += 1
         L = hip.lib()
         g = self.ddp.flat
+        hyper = hip.ptr(self.hyper_dev) if (self.hyper_dev is not None and g.is_cuda and torch.cuda.is_current_stream_capturing()) else 0
         if self.ddp._pair_pending and self.ddp.world == 1:
             # two gradient buffers (ddp.accumulate_overlapped): norm and update over g + g2 in the kernels themselves, both
             # buffers left zeroed -- no "g += g2" pass, no fills before the next update
@@ -528,7 +540,7 @@ class FusedAdam:
             hip.check(L.st5_adam_step_pair(self.pflat.data_ptr(), g.data_ptr(), g2.data_ptr(), 1, self.m.data_ptr(), self.v.data_ptr(), g.numel(),
                                            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
                                            self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
-                                           self.wflat.data_ptr() if self.mirror is not None else 0, hip.ptr(self.hyper_dev), hip.stream()),
+                                           self.wflat.data_ptr() if self.mirror is not None else 0, hyper, hip.stream()),
                       "st5_adam_step_pair")
             self.ddp._pair_pending = False
             self.ddp._grads_zeroed = True
@@ -541,7 +553,7 @@ class FusedAdam:
             hip.check(L.st5_adam_step_pair(self.pflat.data_ptr(), g.data_ptr(), 0, 1, self.m.data_ptr(), self.v.data_ptr(), g.numel(),
                                            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
                                            self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
-                                           self.wflat.data_ptr() if self.mirror is not None else 0, hip.ptr(self.hyper_dev), hip.stream()),
+                                           self.wflat.data_ptr() if self.mirror is not None else 0, hyper, hip.stream()),
                       "st5_adam_step_pair")
             self.ddp._grads_zeroed = True
         # parameters changed in place through the flat view: invalidate the compute-dtype weight cache (entries that do

@@ -1452,6 +1452,42 @@ def dropout(x, p, training):
     return DropoutFunction.apply(x.contiguous(), float(p))
 
 
+class LayerDropSelectFunction(torch.autograd.Function):
+    """LayerDrop inside a step that is recorded for HIP-graph replay: the host's per-layer draw cannot steer control flow in a
+    captured graph, so the layer always runs and its output is SELECTED on the device -- y = keep ? layer(x) : x with `keep` a
+    one-float device tensor staged from the host draw (stage_host) -- and the backward routes the gradient accordingly
+    (a dropped layer receives zeros: its parameters get exactly zero gradients, as when it is skipped).  Same loss and
+    gradients as skipping (modules/encoder.py:251-257, decoder.py:64-67 of the reference); the dropped layer's work is not saved."""
+
+    @staticmethod
+    def forward(ctx, x_in, x_out, keep):
+        assert x_in.shape == x_out.shape and x_in.dtype == x_out.dtype and x_in.is_contiguous() and x_out.is_contiguous()
+        y = torch.empty_like(x_in)
+        nbytes = y.numel() * y.element_size()
+        assert nbytes % 16 == 0, "layerdrop_select: row size must be a multiple of 16 bytes"
+        hip.check(hip.lib().st5_select(keep.data_ptr(), x_in.data_ptr(), x_out.data_ptr(), y.data_ptr(), nbytes, hip.stream()), "st5_select")
+        ctx.keep = keep
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        ga, gb = torch.empty_like(g), torch.empty_like(g)
+        hip.check(hip.lib().st5_select_bwd(ctx.keep.data_ptr(), g.data_ptr(), ga.data_ptr(), gb.data_ptr(), g.numel() * g.element_size(),
+                                           hip.stream()), "st5_select_bwd")
+        return ga, gb, None
+
+
+def layerdrop_select(x_in, x_out, keep):
+    return LayerDropSelectFunction.apply(x_in.contiguous(), x_out.contiguous(), keep)
+
+
+def layerdrop_on_device(x):
+    """True when LayerDrop decisions must be device-side selects: while a step is recorded / captured for replay (and in the
+    eager fixed-shape form the replay is compared against)."""
+    return x.is_cuda and static_shapes()
+
+
 class AddScaledFunction(torch.autograd.Function):
     """y = a + s * b (same shapes, compute dtype); s is a python float."""
 
@@ -1809,6 +1845,19 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
         stats = torch.empty(B, C0, 2, dtype=torch.float32, device=dev)
         wsb = hip.workspace(L.st5_conv0_ws_bytes(B, S, C0, k0, s0), dev)
         w0f = w0.detach().reshape(C0, k0).contiguous()
+        # the frontend AS A UNIT: algorithmic bytes = sum over layers of (input + output) once, GroupNorm / GELU
+        # counted as fused (fwd 130.2 MB per 10 s clip in bf16); flops = sum 2 Cout Cin k Lout
+        es_ = y.element_size()
+        lens_, Lc_ = [], S
+        for (C_, k_, s_) in layers:
+            Lc_ = (Lc_ - k_) // s_ + 1
+            lens_.append(Lc_)
+        xb_ = [B * S * 4] + [B * lens_[i] * layers[i][0] * es_ for i in range(len(layers) - 1)]
+        yb_ = [B * lens_[i] * layers[i][0] * es_ for i in range(len(layers))]
+        fl_ = [2.0 * B * lens_[i] * layers[i][0] * (layers[i - 1][0] if i else 1) * layers[i][1] for i in range(len(layers))]
+        ctx.front = (sum(yb_) + 2 * sum(xb_) - xb_[0], 2 * sum(fl_) - fl_[0])   # backward: Y + 2X (layer 0: Y + X), 2x flops (layer 0: 1x)
+        front_region = hip.profiler.region("conv_frontend_fwd", sum(xb_) + sum(yb_), flops=sum(fl_))
+        front_region.__enter__()
         # algorithmic HBM bytes: waveform in (fp32) + channels-last output once
         with hip.profiler.region("conv0_gn_gelu_fwd", B * S * 4 + B * L0 * C0 * y.element_size()):
             hip.check(L.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), y.data_ptr(),
@@ -1825,6 +1874,7 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
                      B * Lo, C, k * Cin, _dt(dtype), Cpre=hip.operand(pre, C), act=ACT_GELU)
             acts.append(out); pres.append(pre); lens.append(Lo)
             x, Lin, Cin = out, Lo, C
+        front_region.__exit__(None, None, None)
         ctx.save_for_backward(wav, stats, *acts[:-1], *pres[1:])
         ctx.meta = (layers, gscale, w0, gn_w, gn_b, ws, lens, B, S)
         return x
@@ -1841,6 +1891,8 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
         dev = dy.device
         L = hip.lib()
         C = layers[-1][0]
+        front_region = hip.profiler.region("conv_frontend_bwd", ctx.front[0], flops=ctx.front[1])
+        front_region.__enter__()
         # top gradient: scale by feature_grad_mult (GradMultiply, :158-160) and apply GELU' of the last layer,
         # written into the interior of a time-padded buffer (one zero row each side, used by the k=3 layers)
         Ln = lens[-1]
@@ -1927,6 +1979,7 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
             for p in (w0, gn_w, gn_b):
                 if p.requires_grad:
                     _grad_done(p)
+        front_region.__exit__(None, None, None)   # (weight-gradient GEMMs on the side stream, if any, are not inside the events)
         return (None, None, None, None, None, None) + (None,) * len(ws)
 
 

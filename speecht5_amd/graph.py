@@ -11,8 +11,10 @@ What makes a training step replayable:
   * data-dependent shapes are replaced by fixed-shape forms while recording (functional.static_shapes(): the NCE head scores
     every frame and passes selection masks; the sample size becomes a device scalar);
   * the optimizer reads the learning rate and step count from device memory (FusedAdam.enable_device_hyper).
-Not supported in a captured step (asserted): LayerDrop (host-side control flow would be frozen), host reads of device values,
-collectives.  Several ranks: the captured part is the LOCAL phase of the update (zero_grad, forward / backward of every
+  * LayerDrop: the per-layer host draws are staged to the device as keep flags and the layer outputs are selected on the
+    device (functional.layerdrop_select; modules/encoder.py, modules/decoder.py), so the recipe's --encoder-layerdrop /
+    --decoder-layerdrop 0.05 replays (a dropped layer still runs; its output and gradients are discarded).
+Not supported in a captured step: host reads of device values, collectives.  Several ranks: the captured part is the LOCAL phase of the update (zero_grad, forward / backward of every
 micro-batch: ddp.local_phase()), and `after_fn` -- gradient all-reduce + optimizer step -- is enqueued eagerly behind every
 replay (a handful of launches)."""
 import torch
@@ -32,6 +34,7 @@ class StepGraph:
         self.opt = opt
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.graph = None
+        self._assumes_zeroed = False
         # prefetch_host: hipGraphLaunch keeps the calling thread until the previous launch of the same graph has drained (measured:
         # graph.replay() returns after 40-60 ms), so the host part of the NEXT step's preparation (on_step, seed values, the CPU
         # producers of the staged inputs: ~1.2 ms) would sit between two replays with the GPU idle.  With prefetch_host it runs on
@@ -44,10 +47,6 @@ class StepGraph:
         self._uploaded = [None, None]   # event after the last upload from each pinned slot (the slot may be rewritten only after it)
         self.slots = Fn.SeedSlots(seed_slots, self.device)
         self.stream = torch.cuda.Stream(device=self.device)
-        if model is not None:
-            for m in model.modules():
-                assert getattr(m, "encoder_layerdrop", 0.0) in (0, 0.0) and getattr(m, "decoder_layerdrop", 0.0) in (0, 0.0), \
-                    "LayerDrop decisions are host control flow: not replayable"
         if opt is not None and opt.hyper_dev is None:
             opt.enable_device_hyper()
 
@@ -90,6 +89,11 @@ class StepGraph:
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
         t0 = self.opt.t if self.opt is not None else 0
+        # does the captured zero_grad() contain the fills, or does it rely on the previous optimizer step having left the
+        # gradient buffers zeroed (ddp._grads_zeroed at this moment)?  replay() re-establishes that precondition when the host
+        # flag says the buffers were written in between (an eager backward without a step, a failed step ...)
+        ddp = getattr(self.opt, "ddp", None)
+        self._assumes_zeroed = bool(ddp is not None and ddp._grads_zeroed)
         with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
             self._run("capture")
         # the capture pass itself executed nothing: the host-side step counter it advanced is rolled back
@@ -149,11 +153,19 @@ class StepGraph:
             th = threading.Thread(target=work, daemon=True)
             th.start()
             self._ahead = (th, self._slot)
+        ddp = getattr(self.opt, "ddp", None)
+        if self._assumes_zeroed and ddp is not None and not ddp._grads_zeroed:
+            ddp.flat.zero_()
+            if ddp.flat2 is not None:
+                ddp.flat2.zero_()
+            ddp._pair_pending = False
         self.graph.replay()
         if self.after_fn is not None:
             self.after_fn()          # (its optimizer step advances opt.t itself)
         elif self.opt is not None:
             self.opt.t += 1
+            if ddp is not None:
+                ddp._grads_zeroed = True     # the replayed Adam kernel left both buffers zeroed
 
     def drain(self):
         """Wait for the helper thread that prepares the next step (prefetch_host): after the last replay it has drawn one unused

@@ -89,6 +89,8 @@ _SIGS = {
     "st5_colsum_ws_bytes": (c_int64, [c_int64, c_int32]),
     "st5_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int32, c_int, c_void_p]),
     "st5_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
+    "st5_select": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "st5_select_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "st5_act_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "st5_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "st5_channel_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),
@@ -239,7 +241,7 @@ class GemmProfiler:
         self.records = []
         self.regions = []
 
-    def region(self, name, nbytes):
+    def region(self, name, nbytes, flops=0.0):
         """Context manager: HIP events around a launch sequence on the current stream (no-op unless enabled)."""
         prof = self
 
@@ -253,15 +255,21 @@ class GemmProfiler:
             def __exit__(self_, *exc):
                 if prof.enabled:
                     self_.e1.record()
-                    prof.regions.append((name, float(nbytes), self_.e0, self_.e1))
+                    prof.regions.append((name, float(nbytes), self_.e0, self_.e1, float(flops)))
                 return False
         return _R()
 
     def region_summary(self):
         out = {}
-        for name, nbytes, e0, e1 in self.regions:
+        for name, nbytes, e0, e1, _fl in self.regions:
             n, b, t = out.get(name, (0, 0.0, 0.0))
             out[name] = (n + 1, b + nbytes, t + e0.elapsed_time(e1) * 1e-3)
+        return out
+
+    def region_flops(self):
+        out = {}
+        for name, _b, _e0, _e1, fl in self.regions:
+            out[name] = out.get(name, 0.0) + fl
         return out
 
     def summary(self):

@@ -82,13 +82,24 @@ class TransformerDecoder(FairseqIncrementalDecoder):
                 share = Fn.KVShare(len(cross), 2 * C, self.training and self.decoder_layerdrop > 0)
         attn_list, attn = [], None
         inner_states = [x.view(B, T, C).transpose(0, 1)]
+        # LayerDrop (decoder.py:64-67 of the reference: LayerDropModuleList draws torch.empty(L).uniform_() once per pass over
+        # the layers, a layer runs when its draw exceeds --decoder-layerdrop).  Recorded for graph replay: keep flags staged to
+        # the device, every layer runs, outputs selected on the device (see the encoder).
+        drops, keep_dev = None, None
+        if self.decoder_layerdrop > 0:
+            L_, p_drop = len(self.layers), float(self.decoder_layerdrop)
+            if self.training and Fn.layerdrop_on_device(x):
+                keep_dev = Fn.stage_host(lambda: (torch.empty(L_).uniform_() > p_drop).float(), x.device)
+            else:
+                drops = Fn.host_draw(lambda: torch.empty(L_).uniform_()) <= p_drop
         for idx, layer in enumerate(self.layers):
-            if self.training and self.decoder_layerdrop > 0 and float(torch.empty(1).uniform_()) <= self.decoder_layerdrop:
+            if self.training and drops is not None and bool(drops[idx]):
                 x = Fn.layer_boundary(x, layer)   # skipped layer: its (zero) gradient bucket still reports ready here
-                continue  # LayerDropModuleList semantics (torch RNG)
+                continue
             want = bool(idx == alignment_layer or alignment_layer == -1) and (self.materialise_alignment or not self.training)
-            x, layer_attn = layer.forward_rows(x, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want,
+            y, layer_attn = layer.forward_rows(x, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want,
                                                kv_all=(kv_all, idx * 2 * C, share) if kv_all is not None else None)
+            x = y if keep_dev is None else Fn.layerdrop_select(x, y, keep_dev[idx:idx + 1])
             inner_states.append(x.view(B, T, C).transpose(0, 1))
             if layer_attn is not None and want:
                 attn = layer_attn.transpose(0, 1)       # [H,B,T,S] as the reference's per-head weights

@@ -100,11 +100,24 @@ class TransformerEncoder(FairseqEncoder):
                 encoder_states.append(x.view(B, T, C).transpose(0, 1))
             pos_k = self.pos_emb()[0] if self.args.relative_position_embedding else None
         r, d = None, None
+        # LayerDrop (encoder.py:251-257 of the reference: one numpy draw per layer, the layer runs when the draw exceeds
+        # --encoder-layerdrop).  In a step recorded for graph replay the decision cannot be host control flow: the draws of the
+        # whole stack are made at once (same positions of the numpy stream as the per-layer draws), staged to the device as
+        # keep flags, every layer runs and its output is selected on the device (Fn.layerdrop_select).
+        keep_dev = None
+        if self.training and self.encoder_layerdrop > 0 and Fn.layerdrop_on_device(x):
+            n_draw = len(self.layers) if tgt_layer is None else min(len(self.layers), tgt_layer + 1)
+            p_drop = float(self.encoder_layerdrop)
+            keep_dev = Fn.stage_host(lambda: torch.from_numpy((np.random.random(n_draw) > p_drop).astype(np.float32)), x.device)
         for i, layer in enumerate(self.layers):
-            dropout_probability = Fn.host_draw(np.random.random)   # (drawn per layer even at LayerDrop 0, as the reference does)
+            if keep_dev is None:
+                dropout_probability = Fn.host_draw(np.random.random)   # (drawn per layer even at LayerDrop 0, as the reference does)
             frozen = (not ft) and i not in self.no_freeze_encoder_layer
             with torch.no_grad() if frozen else contextlib.ExitStack():
-                if not self.training or (dropout_probability > self.encoder_layerdrop) or i == self.unb_enc_layer:
+                if keep_dev is not None:
+                    y = layer.forward_rows(x, B, T, padding_mask=encoder_padding_mask, pos_bias=pos_k)
+                    x = y if i == self.unb_enc_layer else Fn.layerdrop_select(x, y, keep_dev[i:i + 1])
+                elif not self.training or (dropout_probability > self.encoder_layerdrop) or i == self.unb_enc_layer:
                     x = layer.forward_rows(x, B, T, padding_mask=encoder_padding_mask, pos_bias=pos_k)
                 else:   # LayerDrop: the layer's (zero) gradient bucket still reports ready at this point of backward
                     x = Fn.layer_boundary(x, layer)

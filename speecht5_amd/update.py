@@ -1,0 +1,127 @@
+"""One optimizer update of the pre-training recipe (`--update-freq 2`: a speech micro-batch and a text micro-batch, SURVEY.md
+3.1-3.2) the way bench.py times it: forward + backward of both micro-batches (side by side on two streams, two gradient
+buffers), the gradient exchange over the ranks, global-norm clip and the fused Adam step -- enqueued eagerly or replayed as a
+HIP graph.  bench.py and tests/test_bench_update_gpu.py build their step from THIS class, so the thing that is timed is the
+thing whose results are checked.
+
+Modes (what the reference's trainer does in turn -- tasks/speecht5.py:519-556 called once per micro-batch by fairseq's
+Trainer.train_step, gradients summed, one optimizer step -- is `micro="in_turn"`; the other modes reorder execution, never
+arithmetic):
+
+  micro      "side_by_side"  both micro-batches on two streams, forward and backward, second gradient buffer
+             "in_turn_2buf"  the same two-buffer arithmetic with the second backward ordered behind the first (bit-identical
+                             to side_by_side in bf16: the race detector)
+             "in_turn"       one buffer, ddp.accumulate (the reference trainer's order)
+  graph      True: the update (one rank) or its local phase (several ranks) is captured once and replayed
+  several ranks, graph: the captured part is the LOCAL phase (zero_grad, both micro-batches, buffer sum); the gradient
+             all-reduce and the Adam step follow every replay eagerly (ddp.local_phase / all_reduce_gradients)
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+
+
+class PretrainUpdate:
+    def __init__(self, task, model, criterion, micro_batches, *, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0,
+                 graph=True, micro="side_by_side", wgrad_stream=None, prefetch_host=True, device=None, lr_fn=None):
+        from .ddp import FlatGradDataParallel, FusedAdam
+        assert micro in ("side_by_side", "in_turn_2buf", "in_turn")
+        self.task, self.model, self.crit, self.micro = task, model, criterion, list(micro_batches)
+        self.mode = micro
+        self.use_graph = graph
+        self.device = device if device is not None else next(model.parameters()).device
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        overlapped = micro != "in_turn"
+        # inside a replayed graph a third long-lived branch (the weight-gradient stream) serialises one of the micro-batch
+        # branches: off when both micro-batches are replayed side by side
+        if wgrad_stream is None:
+            wgrad_stream = not (graph and overlapped)
+        self.ddp = FlatGradDataParallel(model, wgrad_stream=wgrad_stream)
+        self.opt = FusedAdam(self.ddp, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_norm=clip_norm)
+        self.lr_fn = lr_fn
+        self.prefetch_host = prefetch_host
+        # several ranks + graph: graph = local phase, eager tail = all-reduce + Adam
+        self.split = graph and self.ddp.collectives
+        assert overlapped or not self.split, "replayed several-rank update: needs the two-buffer micro-batch modes"
+        self.n = 0            # update counter (fairseq's num_updates)
+        self.sg = None
+
+    # -- pieces ---------------------------------------------------------------------------------------------------------
+    def _fwd(self, s):
+        return self.task.forward_loss(s, self.model, self.crit, self.n)
+
+    def local_part(self):
+        """(several ranks, graph) what the graph holds: gradients of this rank's micro-batches, summed into ddp.flat."""
+        self.ddp.zero_grad()
+        with self.ddp.local_phase():
+            self.ddp.accumulate_overlapped(self.micro, self._fwd, backward="in_turn" if self.mode == "in_turn_2buf" else "side_by_side")
+        self.ddp.sum_gradient_buffers()
+
+    def exchange_and_update(self):
+        """(several ranks, graph) eager tail: sum over ranks, then mean over ranks and micro-batches inside Adam."""
+        self.ddp.all_reduce_gradients(average=False)
+        self.opt.step(grad_scale=1.0 / (len(self.micro) * self.world))
+
+    def step(self):
+        """One update enqueued on the current stream (no host synchronisation)."""
+        if self.split:
+            self.local_part()
+            self.exchange_and_update()
+            return
+        ddp = self.ddp
+        ddp.zero_grad()
+        if self.mode == "in_turn":
+            # --update-freq 2: gradients of the first micro-batch only accumulate (no_sync); the bucket all-reduces are launched
+            # from the backward of the LAST micro-batch, each bucket once, after its last local contribution
+            ddp.accumulate(self.micro, lambda s: self.task.train_step(s, self.model, self.crit, None, self.n, sync=False))
+        else:
+            ddp.accumulate_overlapped(self.micro, self._fwd, backward="in_turn" if self.mode == "in_turn_2buf" else "side_by_side")
+        ddp.finish()
+        self.opt.step(grad_scale=1.0 / len(self.micro))
+
+    def advance(self):
+        """Host-side state a replayed step does not touch: the update counter (quantizer temperature, freeze counters), lr."""
+        self.n += 1
+        self.model.set_num_updates(self.n)
+        if self.lr_fn is not None:
+            self.opt.lr = self.lr_fn(self.n)
+
+    # -- driving --------------------------------------------------------------------------------------------------------
+    def eager_update(self):
+        self.advance()
+        self.step()
+
+    def prepare_graph(self):
+        """Two recording updates + capture (three updates' worth of host random draws; two of them executed)."""
+        from .graph import StepGraph
+        self.sg = StepGraph(self.local_part if self.split else self.step, opt=self.opt, model=self.model, device=self.device,
+                            on_step=self.advance, prefetch_host=self.prefetch_host,
+                            after_fn=self.exchange_and_update if self.split else None)
+        self.sg.record()
+        self.sg.record()
+        self.sg.capture()
+        return self.sg
+
+    def update(self):
+        """The next update: a replay when a graph exists, else eager."""
+        if self.sg is not None:
+            with torch.cuda.stream(self.sg.stream):
+                self.sg.replay()
+        else:
+            self.eager_update()
+
+    def finish(self):
+        if self.sg is not None:
+            self.sg.drain()
+            torch.cuda.current_stream(self.device).wait_stream(self.sg.stream)
+
+    def close(self):
+        self.finish()
+        self.ddp.close()
+
+    def state(self):
+        torch.cuda.synchronize(self.device)
+        return self.opt.pflat.clone(), self.opt.m.clone(), self.opt.v.clone(), self.opt.t

@@ -16,7 +16,7 @@ from tests.util import Task, load_golden, to_dev
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cuda, dtype):
+def _setup(cuda, dtype, layerdrop=0.0):
     from argparse import Namespace
     from speecht5_amd import functional as Fn
     from speecht5_amd.criterions import SpeechT5Criterion
@@ -30,6 +30,7 @@ def _setup(cuda, dtype):
         setattr(args, k, 0.1)
     args.dprenet_dropout_rate = 0.5
     args.postnet_dropout_rate = 0.5
+    args.encoder_layerdrop = args.decoder_layerdrop = layerdrop
     Fn.set_compute_dtype(dtype)
     task = SpeechT5Task(args, Task().dicts)
     model = T5TransformerModel.build_model(args, task)
@@ -42,8 +43,8 @@ def _setup(cuda, dtype):
     return Fn, task, model, crit, ddp, opt, micro
 
 
-def _run(cuda, dtype, mode, nsteps=3, seed_offset=0):
-    Fn, task, model, crit, ddp, opt, micro = _setup(cuda, dtype)
+def _run(cuda, dtype, mode, nsteps=3, seed_offset=0, layerdrop=0.0):
+    Fn, task, model, crit, ddp, opt, micro = _setup(cuda, dtype, layerdrop)
     try:
         Fn.manual_seed(99 + seed_offset)
         np.random.seed(5 + seed_offset)
@@ -83,7 +84,22 @@ def _run(cuda, dtype, mode, nsteps=3, seed_offset=0):
             model.set_num_updates(n[0])
             opt.lr = 1e-3 * (1 + 0.1 * n[0])          # a schedule: the replayed step must follow the host's learning rate
 
-        if mode in ("graph", "graph_prefetch", "graph_overlap", "graph_split"):
+        if mode == "graph_overlap_mixed":   # replays with one eagerly enqueued update in between
+            from speecht5_amd.graph import StepGraph
+            sg = StepGraph(step, opt=opt, model=model, device=cuda, on_step=advance)
+            sg.record(); sg.record(); sg.capture()
+            with torch.cuda.stream(sg.stream):
+                sg.replay()
+                # eager update on the same stream, fixed-shape form (what the replay is made of); the replay prepared nothing for it
+                Fn._S.force_static = True
+                advance()
+                step()
+                Fn._S.force_static = False
+                sg.replay()
+            for _ in range(nsteps - 5):
+                sg.replay()
+            sg.drain()
+        elif mode in ("graph", "graph_prefetch", "graph_overlap", "graph_split"):
             from speecht5_amd.graph import StepGraph
             sg = StepGraph(local_part if split else step, opt=opt, model=model, device=cuda, on_step=advance,
                            prefetch_host=mode == "graph_prefetch", after_fn=exchange_and_update if split else None)
@@ -132,6 +148,32 @@ def test_graph_replay_equals_eager_fixed_shape(cuda, dtype, seed_offset):
     for a, b, name in ((pg, ps, "parameters"), (mg, ms, "first moment"), (vg, vs, "second moment")):
         d = float((a - b).abs().max())
         assert d <= tol * max(1.0, float(b.abs().max())), f"{name}: max difference {d:.3e} (tolerance {tol:.1e})"
+
+
+def test_graph_replay_with_layerdrop_equals_eager_fixed_shape(cuda):
+    """The recipe's LayerDrop (t5_transformer_base: 0.05 on both stacks; here 0.3 so that the 4 + 4 tiny layers really drop within
+    a few updates) inside a replayed update: the per-layer host draws are staged to the device as keep flags and the layer
+    outputs are selected there (functional.layerdrop_select).  7 updates (2 recorded + 5 replayed, side by side) == the same 7
+    enqueued eagerly in the fixed-shape form with the micro-batches in turn, bit for bit in bf16 -- and the drops did happen
+    (the run differs from the LayerDrop-0 run)."""
+    ref = _run(cuda, torch.bfloat16, "static_overlap_turn", 7, layerdrop=0.3)
+    got = _run(cuda, torch.bfloat16, "graph_overlap", 7, layerdrop=0.3)
+    nodrop = _run(cuda, torch.bfloat16, "static_overlap_turn", 7, layerdrop=0.0)
+    assert ref[3] == got[3] == 7
+    for x, y, name in zip(ref[:3], got[:3], ("parameters", "first moment", "second moment")):
+        assert torch.equal(x, y), name
+    assert not torch.equal(ref[0], nodrop[0])
+
+
+def test_eager_adam_step_between_replays_uses_host_hyper(cuda):
+    """ADVICE r2 (ddp.py:517): once a StepGraph exists the optimizer owns a device copy of (lr, step) that only replays refresh.
+    An EAGER update between replays (an odd-shaped batch, a resumed run) must not read it: 2 recorded + 1 replayed + 1 eager + 1
+    replayed update == 5 eager updates, bit for bit (bf16), with a learning-rate schedule that changes every update."""
+    ref = _run(cuda, torch.bfloat16, "static_overlap", 5)
+    got = _run(cuda, torch.bfloat16, "graph_overlap_mixed", 5)
+    assert ref[3] == got[3] == 5
+    for x, y, name in zip(ref[:3], got[:3], ("parameters", "first moment", "second moment")):
+        assert torch.equal(x, y), name
 
 
 def test_replay_with_host_prefetch_thread_equals_plain_replay(cuda):
