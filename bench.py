@@ -6,8 +6,8 @@
 
 One step = what one optimizer update of the reference recipe does with --update-freq 2 (SURVEY.md 3.1-3.2,
 8d cfg 2): forward+backward of ONE speech micro-batch (8 x 10 s synthetic 16 kHz clips, HuBERT-mask + NCE +
-mel decoder branch) and ONE text micro-batch (16 x 512 tokens, BART infilling) -- side by side on two streams, replayed
-as one HIP graph -- the gradient all-reduce over the ranks (RCCL: one message behind every replay; `--no-graph`: bucketed and
+mel decoder branch) and ONE text micro-batch (16 x 512 tokens, BART infilling) -- in turn on one stream, replayed as one HIP
+graph (`--micro side_by_side`: on two streams, faster but not bit-reproducible on this hardware) -- the gradient all-reduce over the ranks (RCCL: one message behind every replay; `--no-graph`: bucketed and
 overlapped with an eagerly enqueued backward), global-norm clip and the fused Adam update.  bf16 compute, fp32
 master weights / statistics; dropout and LayerDrop active as t5_transformer_base ships them (0.1, attention 0.1, pre-net 0.5,
 post-net 0.5; encoder / decoder LayerDrop 0.05, models/speecht5.py:1397-1398 -- inside the replayed graph a dropped layer is
@@ -89,7 +89,7 @@ def cpu_baseline(model, args, seconds=4.0, runs=5):
                       f"{t:.2f} s per run (min {ts[0]:.2f}, max {ts[-1]:.2f})"}
 
 
-def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, graph=True, micro="side_by_side", layerdrop=0.05,
+def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, graph=True, micro="in_turn", layerdrop=0.05,
                 wgrad_stream=None, prefetch_host=True, text_batch=16, text_len=512, seconds=10.0):
     """The update bench.py times, as an object (speecht5_amd/update.py): model, criterion, the two synthetic micro-batches of
     BASELINE.json cfg 2, FlatGradDataParallel + FusedAdam with the recipe's hyper-parameters.  tests/test_bench_update_gpu.py
@@ -136,8 +136,9 @@ def main():
                          "measurement (BASELINE.json cfg 5 asks for fp8 GEMMs, which do not exist here); the headline is base")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying a captured HIP graph")
     ap.add_argument("--layerdrop", type=float, default=0.05, help="encoder / decoder LayerDrop (t5_transformer_base: 0.05)")
-    ap.add_argument("--micro", default="side_by_side", choices=["side_by_side", "in_turn_2buf", "in_turn"],
-                    help="how the update's two micro-batches are enqueued (speecht5_amd/update.py)")
+    ap.add_argument("--micro", default="in_turn", choices=["side_by_side", "in_turn_2buf", "in_turn"],
+                    help="how the update's two micro-batches are enqueued (speecht5_amd/update.py); in_turn = one stream, "
+                         "bit-reproducible; side_by_side = two streams, faster, not reproducible on this hardware (DESIGN.md 4a)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -166,9 +167,7 @@ def main():
     # seeds / span masks / LayerDrop flags / lr per replay: speecht5_amd/graph.py).  ST5_GRAPH=0 or --no-graph: eager enqueue
     # (with the bucketed all-reduces overlapped with the backward when there are several ranks).
     use_graph = not a.no_graph and os.environ.get("ST5_GRAPH", "1") == "1"
-    micro_mode = a.micro if use_graph else ("in_turn" if a.micro == "side_by_side" else a.micro)   # (eager enqueue is host-bound: nothing to gain)
-    if os.environ.get("ST5_OVERLAP_FWD", "1") != "1":
-        micro_mode = "in_turn"
+    micro_mode = a.micro
     if os.environ.get("ST5_NT_TILE"):   # A/B: 1 = 128x128 always, 2 = 256x256 always (default: per problem)
         hip.lib().st5_gemm_set_nt_tile(int(os.environ["ST5_NT_TILE"]))
     if os.environ.get("ST5_DEEP_RING"):   # A/B: "max_blocks,nbuf" of the 128x128 NT kernel's deep operand ring (nbuf 2 = off)

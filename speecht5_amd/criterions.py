@@ -13,7 +13,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as Fn
-from .fairseq_compat import register_criterion
+from . import fairseq_compat as _fc
+from .fairseq_compat import FairseqCriterion, register_criterion
 from .modules.speech_encoder_prenet import SpeechEncoderPrenet
 
 
@@ -363,15 +364,16 @@ class SpeechtoTextLoss(nn.Module):
 
 
 @register_criterion("speecht5")
-class SpeechT5Criterion(nn.Module):
-    """speecht5_criterion.py:32-120: dispatches on sample['task_name']."""
+class SpeechT5Criterion(FairseqCriterion):
+    """speecht5_criterion.py:32-120: dispatches on sample['task_name'].  A FairseqCriterion (fairseq's register_criterion
+    refuses anything else); `reduce_metrics` below is the trainer-side aggregation hook (:122-437)."""
 
     def __init__(self, task, sentence_avg=False, label_smoothing=0.1, ignore_prefix_size=0, report_accuracy=False,
                  use_masking=True, use_weighted_masking=False, loss_type="L1", bce_pos_weight=5.0, bce_loss_lambda=1.0,
                  use_guided_attn_loss=False, num_heads_applied_guided_attn=2, ce_weight=1.0, ctc_weight=0.0, hubert_weight=1.0,
                  dec_weight=1.0, bart_weight=1.0, pred_masked_weight=1.0, pred_nomask_weight=0.0, loss_weights=None, cfg=None,
                  sync_logging=True, guided_attn_loss_lambda=1.0, guided_attn_loss_sigma=0.4, log_keys=None):
-        super().__init__()
+        super().__init__(task)
         self.speech_criterion = TexttoSpeechLoss(task, sentence_avg, use_masking, use_weighted_masking, loss_type, bce_pos_weight,
                                                  bce_loss_lambda, use_guided_attn_loss, guided_attn_loss_sigma, guided_attn_loss_lambda,
                                                  2, num_heads_applied_guided_attn, sync_logging=sync_logging)
@@ -397,3 +399,112 @@ class SpeechT5Criterion(nn.Module):
     @staticmethod
     def logging_outputs_can_be_summed():
         return False
+
+    @classmethod
+    def reduce_metrics(cls, logging_outputs):
+        """speecht5_criterion.py:122-437: aggregate the per-task logging dicts that `train_step` nests under the task name
+        (one entry per rank and micro-batch) into fairseq's metrics.  Same metric names, values, weights, priorities and
+        rounding as the reference (tests/test_fairseq_surface.py compares the call sequence with the verbatim function's),
+        written as tables: every family of metrics is `sum(key) / denominator [/ ln 2]`."""
+        import math
+        import re
+        M = _fc.metrics
+        ln2 = math.log(2)
+        per_task = {}
+        for out in logging_outputs:
+            for name, log in out.items():
+                if name in _TASK_NAMES:
+                    per_task.setdefault(name, []).append(log)
+
+        def total(logs, key):
+            return sum(log.get(key, 0) for log in logs)
+
+        def ratio_meter(num, den, ndigits, scale=100.0):
+            def fn(meters):
+                return _fc.safe_round(meters[num].sum * scale / meters[den].sum, ndigits) if meters[den].sum > 0 else float("nan")
+            return fn
+
+        def accuracy(prefix, logs):
+            tot = _fc.utils_item(total(logs, "total"))
+            if tot > 0:
+                M.log_scalar(prefix + "_total", tot)
+                M.log_scalar(prefix + "_n_correct", _fc.utils_item(total(logs, "n_correct")))
+                num, den = prefix + "_n_correct", prefix + "_total"
+                M.log_derived(prefix + "_accuracy",
+                              lambda meters: round(meters[num].sum * 100.0 / meters[den].sum, 3) if meters[den].sum > 0 else float("nan"), 2)
+
+        def perplexities(prefix, logs):
+            pp = [(log["loss_prob_perplexity"], log["sample_size"]) for log in logs if "loss_prob_perplexity" in log]
+            cp = [log["code_perplexity"] for log in logs if "code_perplexity" in log]
+            if pp and sum(v for v, _ in pp) > 0:
+                M.log_scalar(prefix + "_loss_prob_perplexity", sum(v for v, _ in pp) / sum(n for _, n in pp) / ln2, round=3)
+            if cp and sum(cp) > 0:
+                M.log_scalar(prefix + "_code_perplexity", sum(cp) / len(cp), round=3)
+
+        def nll_or_loss_ppl(prefix, value_sum, ntokens, ss, nll_key, loss_key):
+            if ss != ntokens:
+                M.log_scalar(nll_key, value_sum / ntokens / ln2, ntokens, round=3)
+                M.log_derived(prefix + "_ppl", lambda meters: _fc.get_perplexity(meters[nll_key].avg))
+            else:
+                M.log_derived(prefix + "_ppl", lambda meters: _fc.get_perplexity(meters[loss_key].avg))
+
+        for name, logs in per_task.items():
+            ss = max(1, total(logs, "sample_size"))
+            ntok = total(logs, "ntokens")
+            if name in ("s2t", "s2c"):
+                M.log_scalar(name + "_loss", total(logs, "loss") / ss / ln2, ss, 1, round=3)
+                M.log_scalar(name + "_nll_loss", total(logs, "nll_loss") / ntok / ln2, ntok, 2, round=3)
+                if name == "s2t":
+                    M.log_derived("s2t_ppl", lambda meters: _fc.get_perplexity(meters["s2t_nll_loss"].avg, 2))
+                    M.log_scalar("ctc_loss", total(logs, "ctc_loss") / ss / ln2, ntok, 2, round=3)
+                    M.log_scalar("ce_loss", total(logs, "ce_loss") / ntok, ntok, 2, round=3)
+                accuracy(name, logs)
+                if name == "s2t":   # error counters of the WER evaluation (speech_to_text_loss.py) and their derived rates
+                    sums = {k: total(logs, k) for k in ("c_errors", "c_total", "w_errors", "wv_errors", "w_total")}
+                    for k, v in sums.items():
+                        M.log_scalar("_" + k, v)
+                    if sums["c_total"] > 0:
+                        M.log_derived("uer", ratio_meter("_c_errors", "_c_total", 3))
+                    if sums["w_total"] > 0:
+                        M.log_derived("wer", ratio_meter("_w_errors", "_w_total", 3))
+                        M.log_derived("raw_wer", ratio_meter("_wv_errors", "_w_total", 3))
+            elif name in ("t2s", "s2s"):
+                M.log_scalar(name + "_loss", total(logs, "loss") / ss, ss, 1, round=5)
+                for k in ("l1_loss", "l2_loss", "bce_loss"):
+                    M.log_scalar(f"{name}_{k}", total(logs, k) / ss, ss, 2, round=5)
+                for k in (("encoder_alpha", "decoder_alpha") if name == "t2s" else ("decoder_alpha",)):
+                    M.log_scalar(f"{name}_{k}", total(logs, k) / ss, ss, round=5)
+                if "enc_dec_attn_loss" in logs[0]:
+                    M.log_scalar(name + "_enc_dec_attn_loss", total(logs, "enc_dec_attn_loss") / ss, ss, round=8)
+            elif name == "text_pretrain":
+                bart = total(logs, "bart_loss")
+                M.log_scalar("text_loss", total(logs, "loss") / ss / ln2, ss, round=3)
+                M.log_scalar("bart_loss", bart / ss / ln2, ntok, 2, round=3)
+                nll_or_loss_ppl("bart", bart, ntok, ss, "bart_nll_loss", "bart_loss")
+                M.log_scalar("bart_wpb", ntok, priority=180, round=1)
+                perplexities("text", logs)
+            elif name == "speech_pretrain":
+                ngpu = total(logs, "ngpu")
+                M.log_scalar("hubert_loss", total(logs, "loss") / ss / ln2, ss, round=3)
+                nll_or_loss_ppl("hubert", total(logs, "loss"), ntok, ss, "hubert_nll_loss", "hubert_loss")
+                counts = {}
+                for k in logs[0]:
+                    if k.startswith("count_"):
+                        counts[k] = sum(log[k] for log in logs)
+                        M.log_scalar("hubert_" + k, counts[k])
+                for k in logs[0]:
+                    if k.startswith("loss_") and k != "loss_prob_perplexity":
+                        M.log_scalar("hubert_" + k, sum(log[k] for log in logs) / ss / ln2, round=3)
+                    elif k.startswith("correct_"):
+                        M.log_scalar("hubert_" + k, sum(log[k] for log in logs) / counts[re.sub("correct", "count", k)])
+                perplexities("hubert", logs)
+                for k in ("dec_loss", "l1_loss", "l2_loss", "bce_loss"):   # decoder-side terms are per-GPU means
+                    M.log_scalar("hubert_" + k, total(logs, k) / ngpu, ss, 2, round=5)
+                if "enc_dec_attn_loss" in logs[0]:
+                    M.log_scalar("hubert_enc_dec_attn_loss", total(logs, "enc_dec_attn_loss") / ngpu, ss, round=8)
+                M.log_scalar("hubert_wpb", ntok, priority=180, round=1)
+        ss = max(1, total(logging_outputs, "sample_size"))
+        M.log_scalar("loss", total(logging_outputs, "loss") / ss, ss, 1, round=5)
+
+
+_TASK_NAMES = ("s2t", "t2s", "s2c", "s2s", "text_pretrain", "speech_pretrain")

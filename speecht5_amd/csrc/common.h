@@ -1,5 +1,6 @@
 // Shared device helpers for the SpeechT5 gfx950 kernels (wave64, CDNA4).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -234,6 +235,26 @@ __device__ __forceinline__ void dropout_scale4(unsigned long long seed, unsigned
   }
 }
 __device__ __forceinline__ long long drop_row_stride(int row_len) { return ((long long)row_len + 63) & ~63ll; }
+
+// Kernels that are built for exactly two waves per SIMD (the 128x128 GEMM family: ~180 VGPRs) declare the WHOLE half of the
+// register file (256 VGPRs), so that no third wave -- of this or of ANY OTHER kernel on another stream -- is placed on a SIMD
+// that already holds two of them.  Measured on MI355X / ROCm 7.2 (tools/diag_order2.py): a wave of an unrelated kernel
+// (conv layer 0's backward: 88 VGPRs, 250 us per block) that shared a SIMD with two ~184-VGPR GEMM waves (general, LDS-DMA
+// NT or TN form alike; never with one such wave, never with a copy kernel) had lanes 48..63 of its registers corrupted in
+// 10-16 of 16 runs -- the source of the run-to-run differences of the side-by-side micro-batches at full size.  With the
+// padding the combination cannot be scheduled; the GEMM kernels' own occupancy (2 waves/SIMD) is unchanged.
+#define ST5_PAD_TO_256_VGPRS() asm volatile("; vgpr allocation padded to 256" ::: "v255")
+
+// Device allocation of the library's own workspaces / arenas.  ST5_POISON=1 (debug, read once) fills every new allocation with
+// 0xFF bytes -- NaN as bf16 and fp32, -1 as an index -- so that a kernel consuming workspace it never wrote shows up as NaN /
+// a fault instead of as a run-to-run difference (tests/test_poison_gpu.py).
+inline hipError_t st5_dev_malloc(void** p, size_t bytes) {
+  static const bool poison = [] { const char* e = getenv("ST5_POISON"); return e && e[0] == '1'; }();
+  hipError_t rc = hipMalloc(p, bytes);
+  if (rc == hipSuccess && poison) rc = hipMemset(*p, 0xFF, bytes);
+  return rc;
+}
+template <typename T> inline hipError_t st5_dev_malloc(T** p, size_t bytes) { return st5_dev_malloc(reinterpret_cast<void**>(p), bytes); }
 
 #define HIP_CHECK_LAUNCH()                                   \
   do {                                                       \

@@ -366,6 +366,11 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
   if (k <= 10) launch_moments<10>(wav, W, B, S, L, k, stride, nch, shm, s);
   else launch_moments<MAXK>(wav, W, B, S, L, k, stride, nch, shm, s);
   const int KWv = k <= 10 ? 10 : MAXK, nv = KWv + 2;
+  {   // ST5_POISON=1 (debug): the partials region is NaN before the backward kernel fills it -- a reduce that ran ahead of a
+      // block of conv0_bwd_kernel, or a block that never stored, then shows as NaN instead of as last step's value
+    static const bool poison = [] { const char* e = getenv("ST5_POISON"); return e && e[0] == '1'; }();
+    if (poison && hipMemsetAsync(W.part, 0xFF, (size_t)B * nch * C * nv * sizeof(float), s) != hipSuccess) return ST5_ERR_LAUNCH;
+  }
 #define BWD(TT, KW)                                                                                               \
   hipLaunchKernelGGL((conv0_bwd_kernel<TT, KW>), dim3(nch, B), dim3(256), shm, s, wav, w, gamma, beta, stats,     \
                      (const TT*)dY, W.part, S, L, C, k, stride, nch)

@@ -550,7 +550,7 @@ __global__ void log10_floor_kernel(const float* __restrict__ x, float* __restric
 
 float* g_scratch = nullptr;  // 2048-float device scratch for block partials (lazily allocated)
 float* scratch() {
-  if (!g_scratch) { if (hipMalloc(&g_scratch, 2048 * sizeof(float)) != hipSuccess) return nullptr; }
+  if (!g_scratch) { if (st5_dev_malloc(&g_scratch, 2048 * sizeof(float)) != hipSuccess) return nullptr; }
   return g_scratch;
 }
 
@@ -718,7 +718,7 @@ extern "C" int st5_masked_fill_rows_bwd(void* dx, const uint8_t* mask, float* dv
     if (want > g_part_n) {
       if (g_part) (void)hipFree(g_part);
       g_part = nullptr; g_part_n = 0;
-      if (hipMalloc(&g_part, want * sizeof(float)) != hipSuccess) return ST5_ERR_LAUNCH;
+      if (st5_dev_malloc(&g_part, want * sizeof(float)) != hipSuccess) return ST5_ERR_LAUNCH;
       g_part_n = want;
     }
     part = g_part;
@@ -799,7 +799,7 @@ extern "C" int st5_embed_rows_bwd_det_w(const void* dy, const int32_t* tok, floa
     if (w->ptr) (void)hipFree(w->ptr);
     w->ptr = nullptr; w->bytes = 0;
     const size_t want = need < (size_t(8) << 20) ? (size_t(8) << 20) : need;
-    if (hipMalloc(&w->ptr, want) != hipSuccess) return ST5_ERR_LAUNCH;
+    if (st5_dev_malloc(&w->ptr, want) != hipSuccess) return ST5_ERR_LAUNCH;
     w->bytes = want;
   }
   char* g_scatter_ws = w->ptr;

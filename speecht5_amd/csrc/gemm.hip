@@ -438,6 +438,7 @@ __device__ __forceinline__ void run_epilogue(const EpiArgs& ea, float* stage, co
 
 template <typename T, bool AKS, bool BKS>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  ST5_PAD_TO_256_VGPRS();
   constexpr int BK = 128 / (int)sizeof(T);
   typedef typename Frag<T>::type frag_t;
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
@@ -678,7 +679,7 @@ float* slab_workspace(size_t bytes, hipStream_t stream) {
     if (w->ptr) (void)hipFree(w->ptr);  // synchronises with in-flight users
     w->ptr = nullptr;
     const size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
-    if (hipMalloc(&w->ptr, want) != hipSuccess) { w->bytes = 0; return nullptr; }
+    if (st5_dev_malloc(&w->ptr, want) != hipSuccess) { w->bytes = 0; return nullptr; }
     w->bytes = want;
   }
   return w->ptr;
@@ -723,6 +724,7 @@ __device__ unsigned long long g_gemm_timing[8];
 
 template <typename T, int NBUF>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  ST5_PAD_TO_256_VGPRS();
 #ifdef GEMM_TIMING
   unsigned int tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -1133,6 +1135,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile_row, int off0, int of
 }
 
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  ST5_PAD_TO_256_VGPRS();
   typedef bf16_t T;
   constexpr int BK = 64;
   extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -1382,7 +1385,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
         if (g_arena) (void)hipFree(g_arena);   // synchronises with in-flight users
         size_t want = g_arena_bytes ? g_arena_bytes * 2 : (size_t(1) << 30);
         while (want < need * 4) want *= 2;
-        if (hipMalloc(&g_arena, want) != hipSuccess) { g_arena = nullptr; g_arena_bytes = 0; return ST5_ERR_LAUNCH; }
+        if (st5_dev_malloc(&g_arena, want) != hipSuccess) { g_arena = nullptr; g_arena_bytes = 0; return ST5_ERR_LAUNCH; }
         g_arena_bytes = want;
       }
       slabs = arena_take(ds, need);

@@ -581,7 +581,7 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
           if (g_ln_arena) (void)hipFree(g_ln_arena);   // synchronises with in-flight users
           size_t want = size_t(128) << 20;
           while (want < need * 4) want *= 2;
-          if (hipMalloc(&g_ln_arena, want) != hipSuccess) { g_ln_arena = nullptr; g_ln_arena_bytes = 0; return ST5_ERR_LAUNCH; }
+          if (st5_dev_malloc(&g_ln_arena, want) != hipSuccess) { g_ln_arena = nullptr; g_ln_arena_bytes = 0; return ST5_ERR_LAUNCH; }
           g_ln_arena_bytes = want;
         }
       }

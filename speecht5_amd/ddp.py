@@ -131,7 +131,11 @@ class FlatGradDataParallel:
             # eagerly; inside a replayed graph it brings nothing (48.05 vs 47.9 ms) and, worse, the graph executor then puts
             # the second micro-batch's forward stream (accumulate_overlapped) behind the whole weight-gradient branch
             # (measured: 48.3 ms with both, 45.0 ms with the forward overlap alone) -- bench.py turns it off for replay.
-            if (os.environ.get("ST5_WGRAD_STREAM", "1") == "1") if wgrad_stream is None else wgrad_stream:
+            # Default OFF since round 3 (like the attention helper stream below and the side-by-side micro-batches of
+            # accumulate_overlapped): on this hardware / runtime, kernels of DIFFERENT streams sharing a CU were measured to
+            # perturb each other's results (tools/diag_order3.py: a VALU kernel beside the register-staged
+            # or TN GEMM kernel computed one time step of 16 lanes wrong in most runs).  The switches stay for measurements.
+            if (os.environ.get("ST5_WGRAD_STREAM", "0") == "1") if wgrad_stream is None else wgrad_stream:
                 from .modules.transformer_layer import TransformerSentenceEncoderLayer, TransformerDecoderLayer
                 from .modules.speech_encoder_prenet import ConvFeatureExtractionModel
                 for m in model.modules():
@@ -144,7 +148,7 @@ class FlatGradDataParallel:
                                 p._st5_side_ok = True
                 self._side = torch.cuda.Stream(device=dev)
                 Fn.set_wgrad_stream(self._side)
-            if os.environ.get("ST5_ATTN_STREAM", "1") == "1":
+            if os.environ.get("ST5_ATTN_STREAM", "0") == "1":
                 self._attn_side = torch.cuda.Stream(device=dev)   # dq / dkv kernels of the attention backward side by side
                 Fn.set_attention_stream(self._attn_side)
 
@@ -229,7 +233,13 @@ class FlatGradDataParallel:
             # ring of csrc/gemm.hip (128 KB of LDS per block) would keep those off the CU: 37.7 vs 38.3 ms per update
             hip.check(hip.lib().st5_gemm_set_deep_ring(0, 2), "st5_gemm_set_deep_ring")
         while len(self._fwd_streams) < n - 1:
-            self._fwd_streams.append(torch.cuda.Stream(device=self.flat.device))
+            # ST5_SERIAL_MICRO=1 (debug): the "second stream" IS the current stream -- same program, same two gradient buffers,
+            # no concurrency at all (the reference point when hunting a race between the micro-batches' kernels)
+            self._fwd_streams.append(cur if os.environ.get("ST5_SERIAL_MICRO") == "1" else torch.cuda.Stream(device=self.flat.device))
+        if n > 1 and self.flat2 is None:
+            # the second gradient buffer is created (and zero-filled) HERE, on the current stream, before the streams fork: created
+            # lazily inside the second backward it was zero-filled on this stream while the other stream already accumulated into it
+            self._make_flat2()
         for st in self._fwd_streams[: n - 1]:
             st.wait_stream(cur)          # every forward starts from here (what precedes: zero_grad, the previous update)
         losses = []
@@ -303,9 +313,7 @@ class FlatGradDataParallel:
             yield
             return
         if self.flat2 is None:
-            self.flat2 = torch.zeros_like(self.flat)
-            self._views2 = [self.flat2[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
-            self._views1 = [p.grad for p in self.params]
+            self._make_flat2()
         for p, v in zip(self.params, self._views2):
             p.grad = v
         try:
@@ -313,6 +321,11 @@ class FlatGradDataParallel:
         finally:
             for p, v in zip(self.params, self._views1):
                 p.grad = v
+
+    def _make_flat2(self):
+        self.flat2 = torch.zeros_like(self.flat)
+        self._views2 = [self.flat2[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
+        self._views1 = [p.grad for p in self.params]
 
     # -- step API ----------------------------------------------------------------------------------
     def close(self):

@@ -12,6 +12,8 @@ Row convention: activations are 2-D `[rows, channels]` with rows ordered batch-m
 import math
 from types import SimpleNamespace
 
+import os
+
 import torch
 
 from . import hip
@@ -95,6 +97,10 @@ class HostStaging:
         self.i = 0
 
     def begin_step(self, mode):
+        if mode == "record" and self.entries and torch.cuda.is_available():
+            # a second recording step rewrites the pinned images of the first one: their asynchronous uploads (enqueued on the
+            # micro-batches' streams, possibly still queued behind the previous step's kernels) must have executed
+            torch.cuda.synchronize()
         self.mode = mode
         self.i = 0
 
@@ -266,6 +272,7 @@ class _Bf16Mirror:
         self.tcap = 0
         self.tused = 0
         self.jobs = {}          # (src_off, rows, cols) -> (dst_off, view [cols, rows])
+        self.first = {}         # key -> (event, stream) of a copy produced by a first-use transpose since the last batched refresh
         self.jobs_dev = None
         self.ntiles = 0
         self.dirty = False      # job table changed since it was last uploaded
@@ -300,6 +307,13 @@ class _Bf16Mirror:
         key = (off, rows, cols)
         hit = self.jobs.get(key)
         if hit is not None:
+            ev = self.first.get(key)
+            if ev is not None and ev[1] != hip.stream():
+                # produced by a single-job transpose on ANOTHER stream earlier in this very step (the two micro-batches of an
+                # update backward side by side: the second stream's data-gradient GEMM must not read the copy before the first
+                # stream's transpose kernel has written it); from the next optimizer step on the batched refresh produces
+                # every copy on the main stream before the streams fork
+                torch.cuda.current_stream().wait_event(ev[0])
             return hit[1]
         n = rows * cols
         need = (self.tused + n + 63) // 64 * 64
@@ -311,9 +325,13 @@ class _Bf16Mirror:
         self.dirty = True
         # first use: produce this copy now (the batched refresh only runs after optimizer steps)
         _cast_free_transpose(self.flat[off:off + n].view(rows, cols), view)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.first[key] = (ev, hip.stream())
         return view
 
     def refresh_transposes(self):
+        self.first = {}         # (the caller -- the optimizer step -- runs after the micro-batch streams have joined)
         if not self.jobs:
             return
         if self.dirty or self.jobs_dev is None:

@@ -23,7 +23,8 @@ from . import functional as Fn
 
 
 class StepGraph:
-    def __init__(self, step_fn, opt=None, model=None, device=None, seed_slots=1024, on_step=None, prefetch_host=False, after_fn=None):
+    def __init__(self, step_fn, opt=None, model=None, device=None, seed_slots=1024, on_step=None, prefetch_host=False, after_fn=None,
+                 stream=None):
         """step_fn(): one full update on the current stream -- zero_grad, forward/backward of every micro-batch, finish,
         optimizer step -- without host synchronisation.  `opt`: the FusedAdam whose (lr, step) must follow the host.
         after_fn(): optional eager tail of the update, NOT captured (then step_fn must not contain the optimizer step: after_fn
@@ -46,19 +47,22 @@ class StepGraph:
         self._slot = 0
         self._uploaded = [None, None]   # event after the last upload from each pinned slot (the slot may be rewritten only after it)
         self.slots = Fn.SeedSlots(seed_slots, self.device)
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.staging = Fn.HostStaging()   # per graph: two graphs (two tests, two shapes) never share a staging sequence
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)   # (never the NULL stream)
         if opt is not None and opt.hyper_dev is None:
             opt.enable_device_hyper()
 
     # -- one step in a given staging mode ------------------------------------------------------------------------------
     def _run(self, mode):
         Fn._S.slots = self.slots
-        Fn.staging.begin_step(mode)
+        prev, Fn.staging = Fn.staging, self.staging     # this graph's own sequence of staged inputs / host draws
+        self.staging.begin_step(mode)
         try:
             self.step_fn()
         finally:
             Fn._S.slots = None
-            Fn.staging.mode = None
+            self.staging.mode = None
+            Fn.staging = prev
 
     def record(self):
         """Eager step that allocates the static buffers and counts the seed slots (also the last warm-up step)."""
@@ -87,6 +91,8 @@ class StepGraph:
         with torch.cuda.stream(self.stream):
             self._pre_replay()
         torch.cuda.synchronize(self.device)
+        import gc
+        gc.collect()    # (a graph object freed by the cyclic collector DURING a capture aborts the process)
         self.graph = torch.cuda.CUDAGraph()
         t0 = self.opt.t if self.opt is not None else 0
         # does the captured zero_grad() contain the fills, or does it rely on the previous optimizer step having left the
@@ -94,8 +100,17 @@ class StepGraph:
         # flag says the buffers were written in between (an eager backward without a step, a failed step ...)
         ddp = getattr(self.opt, "ddp", None)
         self._assumes_zeroed = bool(ddp is not None and ddp._grads_zeroed)
-        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
-            self._run("capture")
+        try:
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+                self._run("capture")
+        except BaseException:
+            # a failed capture usually ends the process in the graph's destructor ("operation not permitted when stream is
+            # capturing") before Python prints the cause: show it here, while the graph object is still referenced
+            import sys
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            raise
         # the capture pass itself executed nothing: the host-side step counter it advanced is rolled back
         if self.opt is not None and self.after_fn is None:
             self.opt.t = t0
@@ -107,11 +122,11 @@ class StepGraph:
         if self.on_step is not None:
             self.on_step()
         self.slots.produce(slot)
-        Fn.staging.produce(slot)
+        self.staging.produce(slot)
 
     def _upload(self, slot):
         self.slots.upload(slot)
-        Fn.staging.upload(slot)
+        self.staging.upload(slot)
         if self.opt is not None:
             self.opt.push_hyper(slot)
         # the uploads are asynchronous reads of pinned host images: remember when this slot's have executed (a host that runs

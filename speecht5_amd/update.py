@@ -8,10 +8,12 @@ Modes (what the reference's trainer does in turn -- tasks/speecht5.py:519-556 ca
 Trainer.train_step, gradients summed, one optimizer step -- is `micro="in_turn"`; the other modes reorder execution, never
 arithmetic):
 
-  micro      "side_by_side"  both micro-batches on two streams, forward and backward, second gradient buffer
-             "in_turn_2buf"  the same two-buffer arithmetic with the second backward ordered behind the first (bit-identical
-                             to side_by_side in bf16: the race detector)
-             "in_turn"       one buffer, ddp.accumulate (the reference trainer's order)
+  micro      "in_turn"       (default) one stream, one gradient buffer, ddp.accumulate: the reference trainer's order.  Results are
+                             reproducible bit for bit and replay == eager enqueue (tests/test_bench_update_gpu.py, full size)
+             "in_turn_2buf"  two streams / two gradient buffers, the second backward ordered behind the first
+             "side_by_side"  both micro-batches on two streams, forward and backward.  ~25 % faster on one rank, but NOT
+                             reproducible on this hardware: kernels of the two streams that share a CU perturb each other
+                              -- kept as a measurement mode
   graph      True: the update (one rank) or its local phase (several ranks) is captured once and replayed
   several ranks, graph: the captured part is the LOCAL phase (zero_grad, both micro-batches, buffer sum); the gradient
              all-reduce and the Adam step follow every replay eagerly (ddp.local_phase / all_reduce_gradients)
@@ -26,7 +28,7 @@ from . import functional as Fn
 
 class PretrainUpdate:
     def __init__(self, task, model, criterion, micro_batches, *, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0,
-                 graph=True, micro="side_by_side", wgrad_stream=None, prefetch_host=True, device=None, lr_fn=None):
+                 graph=True, micro="in_turn", wgrad_stream=None, prefetch_host=True, device=None, lr_fn=None):
         from .ddp import FlatGradDataParallel, FusedAdam
         assert micro in ("side_by_side", "in_turn_2buf", "in_turn")
         self.task, self.model, self.crit, self.micro = task, model, criterion, list(micro_batches)
@@ -35,10 +37,10 @@ class PretrainUpdate:
         self.device = device if device is not None else next(model.parameters()).device
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         overlapped = micro != "in_turn"
-        # inside a replayed graph a third long-lived branch (the weight-gradient stream) serialises one of the micro-batch
-        # branches: off when both micro-batches are replayed side by side
+        # every form of cross-stream kernel concurrency is OFF by default: the micro-batches in turn, no
+        # weight-gradient stream, no attention helper stream -- one stream, results reproducible bit for bit, replay == eager
         if wgrad_stream is None:
-            wgrad_stream = not (graph and overlapped)
+            wgrad_stream = False
         self.ddp = FlatGradDataParallel(model, wgrad_stream=wgrad_stream)
         self.opt = FusedAdam(self.ddp, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_norm=clip_norm)
         self.lr_fn = lr_fn
@@ -48,6 +50,13 @@ class PretrainUpdate:
         assert overlapped or not self.split, "replayed several-rank update: needs the two-buffer micro-batch modes"
         self.n = 0            # update counter (fairseq's num_updates)
         self.sg = None
+        # Every update is enqueued on a stream of its own, never on the legacy NULL stream: on this runtime (ROCm 7.2) work issued
+        # to the NULL stream from two host threads (the forward from the caller's thread, the backward from autograd's worker
+        # thread) is NOT kept in issue order once another stream is busy -- measured: with the speech micro-batch on the NULL
+        # stream and the text micro-batch beside it, the reduction kernel of conv layer 0's backward read partials its
+        # predecessor in the same stream had not written yet (tools/diag_nan2.py: NaN-poisoned partials came through in 4 of 4
+        # updates; 0 of 4 on an explicit stream).
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
     # -- pieces ---------------------------------------------------------------------------------------------------------
     def _fwd(self, s):
@@ -92,14 +101,20 @@ class PretrainUpdate:
     # -- driving --------------------------------------------------------------------------------------------------------
     def eager_update(self):
         self.advance()
-        self.step()
+        if self.stream is None:
+            self.step()
+            return
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.step()
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     def prepare_graph(self):
         """Two recording updates + capture (three updates' worth of host random draws; two of them executed)."""
         from .graph import StepGraph
         self.sg = StepGraph(self.local_part if self.split else self.step, opt=self.opt, model=self.model, device=self.device,
                             on_step=self.advance, prefetch_host=self.prefetch_host,
-                            after_fn=self.exchange_and_update if self.split else None)
+                            after_fn=self.exchange_and_update if self.split else None, stream=self.stream)
         self.sg.record()
         self.sg.record()
         self.sg.capture()
@@ -121,6 +136,10 @@ class PretrainUpdate:
     def close(self):
         self.finish()
         self.ddp.close()
+        if self.sg is not None:      # break the cycle update -> graph -> bound step function -> update: a HIP graph object must
+            self.sg.step_fn = self.sg.after_fn = self.sg.on_step = None   # not wait for the cyclic collector (a collection
+            self.sg.graph = None                                          # during a LATER capture destroys it mid-capture)
+            self.sg = None
 
     def state(self):
         torch.cuda.synchronize(self.device)

@@ -134,3 +134,25 @@ def check_grads(model, fx, tol):
         checked += 1
     assert checked > 40
     return checked
+
+
+@contextlib.contextmanager
+def poisoned_allocations():
+    """Every GPU buffer handed out by torch.empty / torch.empty_like / Tensor.new_empty (what speecht5_amd allocates its outputs,
+    scratch tensors and workspaces with) is filled with 0xFF bytes first: NaN as bf16 / fp32, -1 as an index.  A kernel that
+    consumes memory it (or its producer) never wrote then yields NaN / a fault instead of a silent run-to-run difference.
+    (Together with ST5_POISON=1 for the library's own hipMalloc'ed arenas, read when the library first allocates.)"""
+    o_empty, o_like, o_new = torch.empty, torch.empty_like, torch.Tensor.new_empty
+
+    def poison(t):
+        if t.is_cuda and t.numel() and t.is_contiguous():
+            t.view(-1).view(torch.uint8).fill_(0xFF)
+        return t
+
+    torch.empty = lambda *a, **k: poison(o_empty(*a, **k))
+    torch.empty_like = lambda *a, **k: poison(o_like(*a, **k))
+    torch.Tensor.new_empty = lambda self, *a, **k: poison(o_new(self, *a, **k))
+    try:
+        yield
+    finally:
+        torch.empty, torch.empty_like, torch.Tensor.new_empty = o_empty, o_like, o_new

@@ -1,0 +1,63 @@
+import os, sys
+os.environ.setdefault("ST5_POISON", "0")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from speecht5_amd import hip
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+B, S, C, k, s = 8, 160000, 512, 10, 5
+L = (S - k) // s + 1
+nch = (L + 255) // 256
+wav = torch.randn(B, S, device=dev); w = torch.randn(C, k, device=dev) * 0.3
+gamma = torch.rand(C, device=dev) + 0.5; beta = torch.randn(C, device=dev) * 0.1
+Lb = hip.lib()
+y = torch.empty(B, L, C, dtype=torch.bfloat16, device=dev); stats = torch.empty(B, C, 2, device=dev)
+ws = torch.zeros(Lb.st5_conv0_ws_bytes(B, S, C, k, s), dtype=torch.uint8, device=dev)
+hip.check(Lb.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), ws.data_ptr(), B, S, C, k, s, 1e-5, hip.BF16, hip.stream()), "fwd")
+dY = (torch.randn(B, L, C, device=dev) * 0.01).to(torch.bfloat16)
+torch.cuda.synchronize()
+main, noise = torch.cuda.Stream(), torch.cuda.Stream()
+def bwd():
+    dw = torch.zeros(C, k, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    with torch.cuda.stream(main):
+        hip.check(Lb.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), dY.data_ptr(),
+                                           dw.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), B, S, C, k, s, 1.0, hip.BF16, hip.stream()), "bwd")
+    torch.cuda.synchronize()
+    return dw, dg, db, ws.clone()
+ref = bwd()
+a = torch.randn(8192, 768, device=dev, dtype=torch.bfloat16); b = torch.randn(3072, 768, device=dev, dtype=torch.bfloat16); c = torch.empty(8192, 3072, device=dev, dtype=torch.bfloat16)
+at = torch.randn(8192, 768, device=dev, dtype=torch.bfloat16); bt = torch.randn(8192, 3072, device=dev, dtype=torch.bfloat16); ct = torch.empty(768, 3072, device=dev, dtype=torch.float32)
+big = torch.randn(64 << 20, device=dev); big2 = torch.empty_like(big)
+nfl = B * nch * C * 12
+def noise_fn(kind):
+    if kind == "nt128": hip.gemm(hip.operand(a, 768), hip.operand(b, 768), hip.operand(c, 3072), 8192, 3072, 768, hip.BF16)
+    elif kind == "nt128_deep4": Lb.st5_gemm_set_deep_ring(1000000, 4); hip.gemm(hip.operand(a, 768), hip.operand(b, 768), hip.operand(c, 3072), 8192, 3072, 768, hip.BF16); Lb.st5_gemm_set_deep_ring(256, 4)
+    elif kind == "general": Lb.st5_gemm_set_glds(0); hip.gemm(hip.operand(a, 768), hip.operand(b, 768), hip.operand(c, 3072), 8192, 3072, 768, hip.BF16); Lb.st5_gemm_set_glds(1)
+    elif kind == "tn": hip.gemm(hip.operand(at, 768), hip.operand(bt, 3072), hip.operand(ct, 3072), 768, 3072, 8192, hip.BF16, flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
+    elif kind == "copy": big2.copy_(big)
+    elif kind == "ln":
+        pass
+def sums():
+    torch.cuda.synchronize()
+    return [int(t.contiguous().view(-1).view(torch.uint8).to(torch.int64).sum()) for t in (wav, w, gamma, beta, stats, dY)]
+s0 = sums()
+for kind in ("general", "tn", "nt128"):
+    bad, lanes = 0, set()
+    for rep in range(16):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(noise):
+            for _ in range(40):
+                noise_fn(kind)
+        got = bwd()
+        pr, pg = ref[3].view(torch.float32)[:nfl].view(B, nch, C, 12), got[3].view(torch.float32)[:nfl].view(B, nch, C, 12)
+        diff = (pr != pg)
+        if int(diff.sum()):
+            bad += 1
+            for i in diff.nonzero():
+                lanes.add((int(i[2]) // 2) % 64)
+    s1 = sums()
+    print(f"noise={kind:12s}: {bad} of 16 runs with wrong partials; lanes hit: {sorted(lanes)}; victim inputs unchanged: {[a == b for a, b in zip(s0, s1)]}", flush=True)
+    # victim alone afterwards
+    got = bwd()
+    pr, pg = ref[3].view(torch.float32)[:nfl], got[3].view(torch.float32)[:nfl]
+    print(f"      victim alone right after: differing partial floats {int((pr != pg).sum())}", flush=True)

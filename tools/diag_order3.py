@@ -1,0 +1,68 @@
+import os, sys
+os.environ.setdefault("ST5_POISON", "0")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from speecht5_amd import hip
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+B, S, C, k, s = 8, 160000, 512, 10, 5
+L = (S - k) // s + 1
+nch = (L + 255) // 256
+wav = torch.randn(B, S, device=dev); w = torch.randn(C, k, device=dev) * 0.3
+gamma = torch.rand(C, device=dev) + 0.5; beta = torch.randn(C, device=dev) * 0.1
+Lb = hip.lib()
+y = torch.empty(B, L, C, dtype=torch.bfloat16, device=dev); stats = torch.empty(B, C, 2, device=dev)
+ws = torch.zeros(Lb.st5_conv0_ws_bytes(B, S, C, k, s), dtype=torch.uint8, device=dev)
+hip.check(Lb.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), ws.data_ptr(), B, S, C, k, s, 1e-5, hip.BF16, hip.stream()), "fwd")
+dY = (torch.randn(B, L, C, device=dev) * 0.01).to(torch.bfloat16)
+torch.cuda.synchronize()
+main, noise = torch.cuda.Stream(), torch.cuda.Stream()
+def bwd():
+    with torch.cuda.stream(main):
+        dw = torch.zeros(C, k, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+        hip.check(Lb.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), dY.data_ptr(),
+                                           dw.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), B, S, C, k, s, 1.0, hip.BF16, hip.stream()), "bwd")
+    torch.cuda.synchronize()
+    return ws.clone()
+nfl = B * nch * C * 12
+ref = bwd().view(torch.float32)[:nfl].view(B, nch, C, 12).double()
+at = torch.randn(8192, 768, device=dev, dtype=torch.bfloat16); bt = torch.randn(8192, 3072, device=dev, dtype=torch.bfloat16); ct = torch.empty(768, 3072, device=dev, dtype=torch.float32)
+# per-step reference quantities on the host side (fp64) for one (b, chunk, channel)
+def steps(b, ch, c):
+    t0 = ch * 256; nt = min(256, L - t0)
+    x = torch.stack([wav[b, (t0 + torch.arange(nt, device=dev)) * s + j] for j in range(k)], 1).double()   # [nt, k]
+    yv = x @ w[c].double()
+    mu, rs = stats[b, c, 0].double(), stats[b, c, 1].double()
+    xh = (yv - mu) * rs
+    z = xh * gamma[c].double() + beta[c].double()
+    cdf = 0.5 * (1 + torch.erf(z / 2 ** 0.5)); pdf = torch.exp(-z * z / 2) / (2 * 3.141592653589793) ** 0.5
+    dz = dY[b, t0:t0 + nt, c].double() * (cdf + z * pdf)
+    return x, xh, dz
+done = 0
+for rep in range(12):
+    torch.cuda.synchronize()
+    with torch.cuda.stream(noise):
+        for _ in range(40):
+            hip.gemm(hip.operand(at, 768), hip.operand(bt, 3072), hip.operand(ct, 3072), 768, 3072, 8192, hip.BF16, flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
+    got = bwd().view(torch.float32)[:nfl].view(B, nch, C, 12).double()
+    diff = (ref != got).any(-1)
+    idx = diff.nonzero()
+    if len(idx) == 0:
+        continue
+    blocks = sorted({(int(i[0]), int(i[1])) for i in idx})
+    print(f"rep {rep}: corrupted (b, chunk) blocks: {blocks}", flush=True)
+    b_, ch_ = blocks[0]
+    chans = sorted(int(i[2]) for i in idx if (int(i[0]), int(i[1])) == (b_, ch_))
+    for c in chans[:6] + chans[-2:]:
+        d = got[b_, ch_, c] - ref[b_, ch_, c]
+        x, xh, dz = steps(b_, ch_, c)
+        # single-step model: d[:10] = e * x[t], d[10] = e, d[11] = e * xh[t]
+        e = d[10]
+        r = d[:10] / e
+        errs = ((x - r[None]) ** 2).sum(1)
+        t = int(errs.argmin())
+        print(f"   channel {c:3d}: dS1 {float(e):+.4e}; best single-step t = {t:3d} (fit residual {float(errs[t]):.2e}, runner-up {float(errs.topk(2, largest=False).values[1]):.2e});"
+              f" true dz[t] {float(dz[t]):+.4e}; dS2/dS1 {float(d[11] / e):+.4f} vs xh[t] {float(xh[t]):+.4f}", flush=True)
+    done += 1
+    if done >= 3:
+        break
