@@ -21,7 +21,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 REL_TOL, COS_TOL = 1e-3, 0.99999
-BF16_COS, BF16_REL, BF16_POST_COS = 0.999, 5e-2, 0.93
+BF16_COS, BF16_REL, BF16_POST_COS = 0.999, 5e-2, 0.98   # (measured at this shape: post-net >= 0.9934, everything else >= 0.99948)
 BF16_LOOSE = {"quantizer.vars", "speech_decoder_postnet.feat_out.weight", "speech_decoder_postnet.feat_out.bias"}
 
 
@@ -102,6 +102,14 @@ def oracle_run(model, args, speech, mask, mix_s, text, mix_t):
     lt, st, logt = O.text_pretrain_loss(to, text, loss_weights=(0.1,))
     (lt / st).backward()
     grads = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    # the text embedding is ONE parameter under three names (tied input / output embeddings): the oracle's state-dict entries
+    # are independent leaves, so the parameter's gradient is the sum over its aliases
+    from tests.util import TIED
+    tied = [grads[a] for a in TIED if a in grads]
+    if tied:
+        total = sum(tied)
+        for a in TIED:
+            grads[a] = total
     return dict(ls=float(ls.detach()), ss=ss, lt=float(lt.detach()), st=st, logs={k: float(torch.as_tensor(v).detach()) for k, v in logs.items() if v is not None},
                 bart=float(logt["bart_loss"].detach()), grads=grads)
 
@@ -143,7 +151,7 @@ def test_cfg2_shape_padded_speech_and_text_match_oracle(cuda):
             a_, b_ = float(torch.as_tensor(got["logs"][k]).detach()), ref["logs"][rk]
             if abs(a_ - b_) > 5e-4 * max(abs(b_), 1e-3):
                 bad.append((k, a_, b_))
-        rnorm = sum(float(g.double().pow(2).sum()) for g in ref["grads"].values()) ** 0.5
+        rnorm = sum(float(ref["grads"][n].double().pow(2).sum()) for n in got["grads"] if n in ref["grads"]) ** 0.5   # (one alias per tied weight)
         gnorm = sum(float(g.pow(2).sum()) for g in got["grads"].values()) ** 0.5
         if abs(gnorm - rnorm) > 5e-3 * rnorm:
             bad.append(("grad norm", gnorm, rnorm))
