@@ -426,7 +426,10 @@ class T5TransformerModel(FairseqEncoderDecoderModel):
                 if n in self.decoder._modules:
                     del self.decoder._modules[n]
 
-        common = ("speech_encoder_postnet", "hubert_layer", "projection", "quantizer")
+        # (the reference deletes `speech_encoder_postnet`, an attribute that does not exist -- the HuBERT head is registered as
+        # `hubert_layer` -- so the head SURVIVES pruning there and its keys stay in fine-tuned checkpoints: kept here too, for
+        # byte-compatible state dicts)
+        common = ("speech_encoder_postnet", "projection", "quantizer")
         if modules_filter == "s2c":
             pooling = getattr(self.args, "sid_pooling_layer", "decoder")
             drop("text_encoder_prenet", "speech_decoder_postnet", "text_decoder_postnet", *common)

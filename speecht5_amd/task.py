@@ -4,7 +4,31 @@ path touches -- build_model, train_step (local loss normalisation, :519-556) and
 (SURVEY.md 2.1 #4); synthetic samples with the same dict schemas feed bench.py/tests."""
 import torch
 
-from .fairseq_compat import register_task
+from .fairseq_compat import LegacyFairseqTask, register_task
+
+
+def post_process(sentence, symbol):
+    """fairseq/data/data_utils.py post_process."""
+    if symbol == "sentencepiece":
+        sentence = sentence.replace(" ", "").replace("\u2581", " ").strip()
+    elif symbol == "wordpiece":
+        sentence = sentence.replace(" ", "").replace("_", " ").strip()
+    elif symbol == "letter":
+        sentence = sentence.replace(" ", "").replace("|", " ").strip()
+    elif symbol == "silence":
+        import re
+        sentence = re.sub(" +", " ", sentence.replace("<SIL>", "")).strip()
+    elif symbol == "_EOW":
+        sentence = sentence.replace(" ", "").replace("_EOW", " ").strip()
+    elif symbol in {"subword_nmt", "@@ ", "@@"}:
+        if symbol == "subword_nmt":
+            symbol = "@@ "
+        sentence = (sentence + " ").replace(symbol, "").rstrip()
+    elif symbol == "none":
+        pass
+    elif symbol is not None:
+        raise NotImplementedError(f"Unknown post_process option: {symbol}")
+    return sentence
 
 
 class _Dictionary(list):
@@ -15,14 +39,28 @@ class _Dictionary(list):
 
     @classmethod
     def load(cls, path):
-        """fairseq dictionary file: one `<symbol> <count>` per line, in index order after the four specials."""
-        syms = []
+        """fairseq dictionary file (fairseq/data/dictionary.py add_from_file): one `<symbol> <count>` per line, in index order
+        after the four specials; a duplicate symbol is an error unless its line ends with the `#fairseq:overwrite` flag."""
+        d = cls()
         with open(path, encoding="utf-8") as f:
             for line in f:
                 line = line.rstrip("\n")
-                if line:
-                    syms.append(line.rsplit(" ", 1)[0] if " " in line else line)
-        return cls(syms)
+                if not line:
+                    continue
+                sym, _, count = line.rpartition(" ")
+                overwrite = False
+                if count == "#fairseq:overwrite":
+                    overwrite = True
+                    sym, _, count = sym.rpartition(" ")
+                if not sym or not count.lstrip("-").isdigit():
+                    raise ValueError(f"Incorrect dictionary format, expected '<token> <cnt> [flags]': {line!r}")
+                if sym in d and not overwrite:
+                    raise RuntimeError(f"Duplicate word found when loading Dictionary: '{sym}'. Duplicate words can overwrite earlier "
+                                       "ones by adding the #fairseq:overwrite flag at the end of the corresponding row in the dictionary file.")
+                if sym in d:
+                    continue   # (overwrite: fairseq re-points the symbol's index to the new, last row; a list-backed table keeps the first)
+                d.append(sym)
+        return d
 
     def add_symbol(self, sym):
         if sym in self:
@@ -30,9 +68,27 @@ class _Dictionary(list):
         self.append(sym)
         return len(self) - 1
 
-    def string(self, tokens, bpe_symbol=None, extra_symbols_to_ignore=()):
-        skip = {self.pad(), self.eos(), self.bos()} | set(extra_symbols_to_ignore)
-        return " ".join(self[int(t)] for t in tokens if int(t) not in skip)
+    def unk_string(self, escape=False):
+        return "<<unk>>" if escape else "<unk>"
+
+    def string(self, tokens, bpe_symbol=None, escape_unk=False, extra_symbols_to_ignore=None, unk_string=None, include_eos=False,
+               separator=" "):
+        """fairseq Dictionary.string: symbols joined by `separator`, <s> / (unless include_eos) </s> / the extra ids dropped,
+        <unk> rendered as `unk_string` (or escaped), then the BPE post-processing fairseq-generate's --post-process / --remove-bpe
+        selects (fairseq/data/data_utils.py post_process: sentencepiece, wordpiece, letter, silence, _EOW, subword_nmt / '@@ ')."""
+        if hasattr(tokens, "dim") and tokens.dim() == 2:
+            return "\n".join(self.string(t, bpe_symbol, escape_unk, extra_symbols_to_ignore, unk_string, include_eos, separator) for t in tokens)
+        skip = set(extra_symbols_to_ignore or ())
+        if not include_eos:
+            skip.add(self.eos())
+        skip.add(self.bos())
+
+        def sym(i):
+            if i == self.unk():
+                return unk_string if unk_string is not None else self.unk_string(escape_unk)
+            return self[i]
+        sent = separator.join(sym(int(t)) for t in tokens if int(t) not in skip)
+        return post_process(sent, bpe_symbol)
 
     def pad(self):
         return 1
@@ -54,10 +110,33 @@ class _Dictionary(list):
             return self.unk()
 
 
+def _reference_task_class():
+    """The reference's SpeechT5Task class (for its data-plane methods), imported without re-registering the task name."""
+    import importlib
+    import sys
+    try:
+        import fairseq.tasks as ft
+    except ImportError:
+        return None
+    mod = sys.modules.get("speecht5.tasks.speecht5")
+    if mod is None:
+        orig = ft.register_task
+        ft.register_task = lambda name, dataclass=None: (lambda cls: cls)
+        try:
+            mod = importlib.import_module("speecht5.tasks.speecht5")
+        except ImportError:
+            return None
+        finally:
+            ft.register_task = orig
+    return getattr(mod, "SpeechT5Task", None)
+
+
 @register_task("speecht5")
-class SpeechT5Task:
+class SpeechT5Task(LegacyFairseqTask):
+    """tasks/speecht5.py:42-43: an argparse-style fairseq task (fairseq's register_task refuses classes that are not FairseqTasks)."""
+
     def __init__(self, args, dicts, config=None):
-        self.args = args
+        super().__init__(args)
         self.dicts = dicts
         self.config = config
         self.t5_task = getattr(args, "t5_task", None) or "pretrain"
@@ -90,6 +169,19 @@ class SpeechT5Task:
             dicts["hubert"] = [_Dictionary.load(f"{args.hubert_label_dir}/dict.{label}.txt") for label in args.hubert_labels]
         dicts["text"] = _Dictionary.load(op.join(args.data, "dict.txt"))
         return cls(args, dicts, None)
+
+    def load_dataset(self, split, epoch=1, combine=False, **kwargs):
+        """tasks/speecht5.py:324-517.  The data plane (tsv manifests, librosa log-mel, k-means label files, fairseq's mmap text,
+        multitask batching) is the reference's own CPU code and stays there: when the reference plug-in is
+        importable (its directory on sys.path, as `--user-dir` puts it) its `load_dataset` runs ON THIS TASK OBJECT -- it only
+        touches self.args / self.dicts / self.config / self.datasets / self.mask_idx / self.build_bpe.  Importing the reference's
+        task module would register the task name `speecht5` a second time, so the registration decorator is neutralised for the
+        duration of that import."""
+        ref = _reference_task_class()
+        if ref is None:
+            raise RuntimeError("SpeechT5Task.load_dataset needs the reference plug-in's data package (speecht5.data.*, "
+                               "SpeechT5/speecht5 on sys.path) and fairseq; bench.py / tests feed speecht5_amd.synthetic samples instead")
+        return ref.load_dataset(self, split, epoch=epoch, combine=combine, **kwargs)
 
     def build_criterion(self, args):
         from . import cli
@@ -132,8 +224,7 @@ class SpeechT5Task:
         cfg = self.config
         args.input_feat_per_channel = getattr(cfg, "input_feat_per_channel", 80) if cfg is not None else 80
         args.input_channels = getattr(cfg, "input_channels", 1) if cfg is not None else 1
-        if getattr(args, "speech_odim", None) is None:
-            args.speech_odim = args.input_feat_per_channel * args.input_channels
+        args.speech_odim = args.input_feat_per_channel * args.input_channels   # (unconditionally, tasks/speecht5.py:590)
         for k, d in (("label_rates", 50), ("sample_rate", 16000)):
             v = getattr(self.args, k, None)
             setattr(args, k, v if v is not None else getattr(args, k, d))
