@@ -170,8 +170,11 @@ def test_prune_modules_and_upgrade_state_dict():
     model.load_state_dict(sd2)
     assert torch.equal(model.text_decoder_postnet.output_projection.weight, before)
     model.prune_modules("t2s")
-    for n in ("speech_encoder_prenet", "text_decoder_prenet", "text_decoder_postnet", "hubert_layer", "quantizer"):
+    for n in ("speech_encoder_prenet", "text_decoder_prenet", "text_decoder_postnet", "quantizer"):
         assert not hasattr(model, n), n
+    # the reference's prune_modules deletes `speech_encoder_postnet`, which is not the attribute the HuBERT head lives under
+    # (`hubert_layer`, speecht5.py:1070/1084/1093): the head survives pruning and stays in fine-tuned checkpoints
+    assert hasattr(model, "hubert_layer")
     assert model.encoder.proj is None and hasattr(model, "speech_decoder_postnet") and hasattr(model, "text_encoder_prenet")
     with pytest.raises(ValueError):
         model.prune_modules("nope")
