@@ -223,6 +223,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if os.environ.get("ST5_BENCH_SHAPES") and rank == 0:   # per-shape table of the sampled update's GEMM launches (stderr)
+        rows = sorted(hip.profiler.by_shape().items(), key=lambda kv: -kv[1][2])
+        tot = sum(v[2] for _, v in rows)
+        print(f"# GEMM launches of the sampled update by (variant, M, N, K, batch): {len(rows)} shapes, {tot * 1e3:.2f} ms", file=sys.stderr)
+        for k, (n_, f_, t_) in rows[:60]:
+            print(f"#  {k[0]:8s} M={k[1]:7d} N={k[2]:6d} K={k[3]:7d} b={k[4]:4d}  x{n_:3d}  {t_ * 1e3:7.3f} ms  {t_ / n_ * 1e6:7.1f} us/launch  {f_ / t_ / 1e12:6.1f} TFLOP/s", file=sys.stderr)
     audio_seconds = a.batch * 10.0 * world * a.steps
     prof = hip.profiler.summary()
     key = "bf16_NT" if a.dtype == "bf16" else "f32_NT"
