@@ -47,7 +47,6 @@ class PretrainUpdate:
         self.prefetch_host = prefetch_host
         # several ranks + graph: graph = local phase, eager tail = all-reduce + Adam
         self.split = graph and self.ddp.collectives
-        assert overlapped or not self.split, "replayed several-rank update: needs the two-buffer micro-batch modes"
         self.n = 0            # update counter (fairseq's num_updates)
         self.sg = None
         # Every update is enqueued on a stream of its own, never on the legacy NULL stream: on this runtime (ROCm 7.2) work issued
@@ -66,7 +65,10 @@ class PretrainUpdate:
         """(several ranks, graph) what the graph holds: gradients of this rank's micro-batches, summed into ddp.flat."""
         self.ddp.zero_grad()
         with self.ddp.local_phase():
-            self.ddp.accumulate_overlapped(self.micro, self._fwd, backward="in_turn" if self.mode == "in_turn_2buf" else "side_by_side")
+            if self.mode == "in_turn":
+                self.ddp.accumulate(self.micro, lambda s: self.task.train_step(s, self.model, self.crit, None, self.n, sync=False))
+            else:
+                self.ddp.accumulate_overlapped(self.micro, self._fwd, backward="in_turn" if self.mode == "in_turn_2buf" else "side_by_side")
         self.ddp.sum_gradient_buffers()
 
     def exchange_and_update(self):
