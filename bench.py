@@ -90,7 +90,7 @@ def cpu_baseline(model, args, seconds=4.0, runs=5):
 
 
 def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, graph=True, micro="in_turn", layerdrop=0.05,
-                wgrad_stream=None, prefetch_host=True, text_batch=16, text_len=512, seconds=10.0):
+                wgrad_stream=None, prefetch_host=True, text_batch=16, text_len=512, seconds=10.0, exchange="phased"):
     """The update bench.py times, as an object (speecht5_amd/update.py): model, criterion, the two synthetic micro-batches of
     BASELINE.json cfg 2, FlatGradDataParallel + FusedAdam with the recipe's hyper-parameters.  tests/test_bench_update_gpu.py
     builds its runs from this function too."""
@@ -106,7 +106,7 @@ def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, grap
     speech = speech_pretrain_sample(B=batch, seconds=seconds, device=device, seed=1337 + rank)
     text = text_pretrain_sample(B=text_batch, T=text_len, vocab=vocab, mask_idx=task.dicts["text"].index("<mask>"), device=device, seed=2337 + rank)
     upd = PretrainUpdate(task, model, crit, [speech, text], lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0,
-                         graph=graph, micro=micro, wgrad_stream=wgrad_stream, prefetch_host=prefetch_host, device=device)
+                         graph=graph, micro=micro, wgrad_stream=wgrad_stream, prefetch_host=prefetch_host, device=device, exchange=exchange)
     return args, task, model, upd
 
 
@@ -297,7 +297,9 @@ def main():
                "config": {"workload": f"SpeechT5-{nm} pretrain step (speech {a.batch}x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
                                       "fwd+bwd+allreduce+clip+Adam, per GPU", "arch": ("t5_transformer_large (24 enc + 6 dec, d=1024, pre-LN, layer-norm feature extractor)" if a.arch == "large"
                                    else "t5_transformer_base (12 enc + 6 dec, d=768)"),
-                          "enqueue": ("hip-graph replay of the local phase + eager all-reduce (one message) + Adam" if split_update else
+                          "enqueue": ("hip-graph replay of the local phase in 3 graphs cut at bucket boundaries, the bucket range each completes "
+                                      "all-reduced (RCCL, async) under the next graph, then Adam" if getattr(upd, "phased", False) else
+                                      "hip-graph replay of the local phase + eager all-reduce (one message) + Adam" if split_update else
                                       "hip-graph replay" if use_graph else "eager"),
                           "micro_batches": {"side_by_side": "forward and backward side by side on two streams, two gradient buffers",
                                             "in_turn_2buf": "in turn, two gradient buffers", "in_turn": "in turn"}[micro_mode],

@@ -110,6 +110,8 @@ class FlatGradDataParallel:
         # A rank that skipped a layer (LayerDrop, another modality) simply defers from that bucket on; it never reorders.
         self._accumulating = False
         self._local_phase = False   # local_phase(): no bucket triggers, gradients reduced afterwards by all_reduce_gradients()
+        self._cut_set = None        # cut_points(): bucket indices at whose boundary the autograd graph of the forward is cut
+        self._cuts = None
         self._fwd_streams = []   # streams of micro-batches 1.. (accumulate_overlapped)
         self.flat2 = None        # second gradient buffer (accumulate_overlapped), allocated on first use
         self._pair_pending = False   # flat2 holds gradients not yet summed into flat
@@ -157,7 +159,31 @@ class FlatGradDataParallel:
         # a forward through the model precedes every backward that writes the gradient buffers: whatever FusedAdam.step left
         # zeroed is not known to be zero any more (zero_grad() must fill again unless another step() intervenes)
         self._grads_zeroed = False
+        if tag == "shared":
+            # A tensor every layer of a stack reads (the relative-position keys; the caller passes the PRODUCER's output each
+            # time).  Uncut, autograd folds the consumers' gradients one after the other, in arrival order, into the producer's
+            # input buffer.  A backward cut in the middle of the stack would instead push each phase's partial sum through the
+            # producer separately: same gradient, another bf16 summation order (measured: 1 ulp on single elements).  So under
+            # cut_points() the consumers of each REGION (the stretch of forward between two cuts) read a leaf of their own, and
+            # backward_phases() seeds a region's leaf with the sum its successors left behind before that region's gradients
+            # arrive -- the fold continues where it stopped -- and runs the producer's backward once, at the end of its region.
+            if not self._cut_set or not x.requires_grad:
+                return x
+            ent = next((c for c in self._cuts if c[0] == "shared" and c[1] is x), None)
+            if ent is None:
+                ent = ("shared", x, [])
+                self._cuts.append(ent)
+            region = sum(1 for c in self._cuts if c[0] != "shared")
+            if not ent[2] or ent[2][-1][0] != region:
+                ent[2].append((region, x.detach().requires_grad_(True)))
+            return ent[2][-1][1]
         bi = self.module_bucket.get((id(module), tag))
+        if bi is not None and self._cut_set is not None and bi in self._cut_set and x.requires_grad:
+            # phased backward (cut_points): everything BEHIND this point hangs off a fresh leaf, so a backward pass stops here
+            # with bucket bi (and every bucket before it) complete; the next phase continues from (x, leaf.grad)
+            leaf = x.detach().requires_grad_(True)
+            self._cuts.append((bi, x, leaf))
+            return leaf
         if bi is None or not self.collectives or self._local_phase or not x.requires_grad:
             return x
         return _Trigger.apply(x, self, bi)
@@ -275,6 +301,85 @@ class FlatGradDataParallel:
             yield
         finally:
             self._local_phase = old
+
+    @contextlib.contextmanager
+    def cut_points(self, bucket_ids):
+        """Around the forward of the LAST micro-batch of an update (inside local_phase()): the autograd graph is cut at the
+        boundaries that report the given buckets ready, so that the backward can be run -- and captured -- in PHASES, with a
+        bucket range handed to the process group between two phases while the next phase computes (reduce_bucket_range).
+        Yields the list of cuts, filled by the forward in forward order: [(bucket, tensor, leaf)]; run_phases() consumes it."""
+        assert self._cut_set is None
+        self._cut_set, self._cuts = set(bucket_ids), []
+        try:
+            yield self._cuts
+        finally:
+            self._cut_set = None
+
+    @staticmethod
+    def backward_phases(loss, cuts):
+        """The backward of a forward built under cut_points(), as a list of callables in execution order: phase 0 runs from
+        the loss to the LAST cut of the forward, phase k continues behind the k-th cut from the end.  Returns [(fn, bucket)]:
+        after fn() every bucket up to and including `bucket` is complete (None for the final phase: everything is)."""
+        real = [c for c in cuts if c[0] != "shared"]
+        shared = [c for c in cuts if c[0] == "shared"]      # (tag "shared" of _boundary: (_, producer output, [(region, leaf)]))
+        m = len(real)
+        carry = [None] * len(shared)     # per shared tensor: the folded gradient of the regions already run
+
+        def phase(k):
+            r = m - k                    # the region of the forward this phase runs backward through (r cuts precede it)
+
+            def fn():
+                roots, grads = [], []
+                if k > 0:
+                    _, x, leaf = real[r]
+                    if leaf.grad is not None:          # (None: nothing behind this cut needed a gradient)
+                        roots.append(x)
+                        grads.append(leaf.grad)
+                        leaf.grad = None
+                mine = [next((lf for rg, lf in ent[2] if rg == r), None) for ent in shared]
+                for i, lf in enumerate(mine):
+                    if lf is not None and carry[i] is not None:
+                        roots.append(lf)               # a root's gradient reaches the leaf's buffer before anything this phase computes
+                        grads.append(carry[i])
+                        carry[i] = None
+                if k == 0:
+                    assert not roots
+                    loss.backward()
+                elif roots:
+                    torch.autograd.backward(roots, grads)
+                for i, (lf, ent) in enumerate(zip(mine, shared)):
+                    if lf is None or lf.grad is None:
+                        continue
+                    g, lf.grad = lf.grad, None
+                    if lf is ent[2][0][1]:             # the producer's own region: its backward, once, with the complete sum
+                        torch.autograd.backward([ent[1]], [g])
+                    else:
+                        carry[i] = g
+            return fn
+        return [(phase(k), real[m - k - 1][0] if k < m else None) for k in range(m + 1)]
+
+    def flush_deferred(self):
+        """Fold the deferred reductions (split-K slabs, LayerNorm partials) queued on the current stream: gradients written so
+        far are complete in the flat buffer afterwards (call at the end of a phase, inside the capture)."""
+        self._flush_splitk()
+
+    def reduce_bucket_range(self, upto):
+        """Hand buckets [next .. upto] (None: all the rest) to the process group as ONE asynchronous all-reduce of their
+        contiguous range of the flat buffer; the collective is ordered behind the current stream and runs on the group's own
+        stream while the caller enqueues the next phase.  SUM over ranks (fold 1/world into the optimizer's grad_scale)."""
+        nb = len(self.buckets)
+        hi = nb - 1 if upto is None else min(upto, nb - 1)
+        if self._next > hi:
+            return
+        s, e = self.buckets[self._next][0], self.buckets[hi][1]
+        if self.collectives:
+            self._works.append(dist.all_reduce(self.flat[s:e], group=self.pg, async_op=True))
+        self._next = hi + 1
+
+    def wait_reductions(self):
+        for w in self._works:
+            w.wait()
+        self._reset_round()
 
     def all_reduce_gradients(self, average=True):
         """The exchange step after a local_phase(): ONE all-reduce over the whole flat buffer (same call on every rank, so

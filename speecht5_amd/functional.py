@@ -198,7 +198,19 @@ def set_layer_boundary_hook(fn):
 
 
 def layer_boundary(x, module, tag=None):
-    return x if _S.boundary_hook is None else _S.boundary_hook(x, module, tag)
+    """Idempotent per (tensor, module, tag): a caller that needs the post-boundary tensor itself (the LayerDrop select takes the
+    layer's INPUT as its skip operand -- it must be the tensor behind the boundary, or a backward cut at that boundary would leak
+    through the skip path) applies the boundary first; the layer's own call then returns the same tensor."""
+    if _S.boundary_hook is None:
+        return x
+    if tag == "shared":     # (a tensor read by every layer of a stack, asked for once per layer: ddp._boundary)
+        return _S.boundary_hook(x, module, tag)
+    key = (id(module), tag)
+    if getattr(x, "_st5_boundary", None) == key:
+        return x
+    y = _S.boundary_hook(x, module, tag)
+    y._st5_boundary = key
+    return y
 
 
 def _ceil8(n):

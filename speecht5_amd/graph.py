@@ -24,11 +24,19 @@ from . import functional as Fn
 
 class StepGraph:
     def __init__(self, step_fn, opt=None, model=None, device=None, seed_slots=1024, on_step=None, prefetch_host=False, after_fn=None,
-                 stream=None):
+                 stream=None, phases=None, between=None):
         """step_fn(): one full update on the current stream -- zero_grad, forward/backward of every micro-batch, finish,
         optimizer step -- without host synchronisation.  `opt`: the FusedAdam whose (lr, step) must follow the host.
         after_fn(): optional eager tail of the update, NOT captured (then step_fn must not contain the optimizer step: after_fn
         does, after the collectives)."""
+        # phases / between (several ranks, overlapped exchange): the update's local part as a LIST of callables, each captured
+        # into its own graph (one memory pool, replayed in order), and after each of them an eagerly enqueued callable -- the
+        # asynchronous all-reduce of the bucket range that phase completed -- so the collective runs on the process group's
+        # stream while the next phase's graph executes.  step_fn is then None.
+        self.phases = list(phases) if phases is not None else None
+        self.between = list(between) if between is not None else None
+        assert self.phases is None or (step_fn is None and len(self.phases) == len(self.between))
+        self.graphs = None
         self.step_fn = step_fn
         self.after_fn = after_fn
         self.on_step = on_step   # host-side bookkeeping a replay skips (e.g. model.set_num_updates(n)): called before every step
@@ -53,16 +61,28 @@ class StepGraph:
             opt.enable_device_hyper()
 
     # -- one step in a given staging mode ------------------------------------------------------------------------------
-    def _run(self, mode):
+    def _enter(self, mode):
         Fn._S.slots = self.slots
-        prev, Fn.staging = Fn.staging, self.staging     # this graph's own sequence of staged inputs / host draws
+        self._prev_staging, Fn.staging = Fn.staging, self.staging     # this graph's own sequence of staged inputs / host draws
         self.staging.begin_step(mode)
+
+    def _exit(self):
+        Fn._S.slots = None
+        self.staging.mode = None
+        Fn.staging = self._prev_staging
+
+    def _run(self, mode):
+        self._enter(mode)
         try:
-            self.step_fn()
+            if self.phases is None:
+                self.step_fn()
+            else:
+                for fn, bt in zip(self.phases, self.between):
+                    fn()
+                    if mode == "record":
+                        bt()
         finally:
-            Fn._S.slots = None
-            self.staging.mode = None
-            Fn.staging = prev
+            self._exit()
 
     def record(self):
         """Eager step that allocates the static buffers and counts the seed slots (also the last warm-up step)."""
@@ -101,8 +121,21 @@ class StepGraph:
         ddp = getattr(self.opt, "ddp", None)
         self._assumes_zeroed = bool(ddp is not None and ddp._grads_zeroed)
         try:
-            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
-                self._run("capture")
+            if self.phases is None:
+                with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+                    self._run("capture")
+            else:
+                pool = torch.cuda.graph_pool_handle()
+                self.graphs = []
+                self._enter("capture")
+                try:
+                    for fn in self.phases:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=pool, stream=self.stream, capture_error_mode="thread_local"):
+                            fn()
+                        self.graphs.append(g)
+                finally:
+                    self._exit()
         except BaseException:
             # a failed capture usually ends the process in the graph's destructor ("operation not permitted when stream is
             # capturing") before Python prints the cause: show it here, while the graph object is still referenced
@@ -174,7 +207,12 @@ class StepGraph:
             if ddp.flat2 is not None:
                 ddp.flat2.zero_()
             ddp._pair_pending = False
-        self.graph.replay()
+        if self.graphs is not None:
+            for g, bt in zip(self.graphs, self.between):
+                g.replay()
+                bt()
+        else:
+            self.graph.replay()
         if self.after_fn is not None:
             self.after_fn()          # (its optimizer step advances opt.t itself)
         elif self.opt is not None:

@@ -97,6 +97,8 @@ class TransformerDecoder(FairseqIncrementalDecoder):
                 x = Fn.layer_boundary(x, layer)   # skipped layer: its (zero) gradient bucket still reports ready here
                 continue
             want = bool(idx == alignment_layer or alignment_layer == -1) and (self.materialise_alignment or not self.training)
+            if keep_dev is not None:
+                x = Fn.layer_boundary(x, layer)      # (the select's skip operand is the tensor BEHIND the layer's boundary)
             y, layer_attn = layer.forward_rows(x, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want,
                                                kv_all=(kv_all, idx * 2 * C, share) if kv_all is not None else None)
             x = y if keep_dev is None else Fn.layerdrop_select(x, y, keep_dev[idx:idx + 1])

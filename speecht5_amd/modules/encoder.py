@@ -31,9 +31,17 @@ class RelativePositionalEncoding(nn.Module):
         self.maxlen = maxlen
         self.pe_k = nn.Embedding(2 * maxlen, d_model)
         self.embed_v = embed_v
+        self.spans_cuts = False
 
     def forward(self, pos_seq=None):
         return RelPosKeys(Fn.as_compute(self.pe_k.weight), self.maxlen), None
+
+    def for_layer(self, keys):
+        """The keys as the NEXT layer of the stack reads them (call after that layer's own Fn.layer_boundary): the same table,
+        behind the gradient-exchange wrapper's "shared" boundary (ddp._boundary: one leaf per region of a phased backward)."""
+        if keys is None or not self.spans_cuts:
+            return keys
+        return RelPosKeys(Fn.layer_boundary(keys.table, self, "shared"), keys.maxlen)
 
 
 class TransformerEncoder(FairseqEncoder):
@@ -63,6 +71,7 @@ class TransformerEncoder(FairseqEncoder):
         if args.relative_position_embedding:
             self.pos_emb = RelativePositionalEncoding(args.encoder_embed_dim // args.encoder_attention_heads,
                                                       args.encoder_max_relative_position)
+            self.pos_emb.spans_cuts = True
 
     def build_encoder_layer(self, args):
         return TransformerSentenceEncoderLayer(
@@ -115,10 +124,12 @@ class TransformerEncoder(FairseqEncoder):
             frozen = (not ft) and i not in self.no_freeze_encoder_layer
             with torch.no_grad() if frozen else contextlib.ExitStack():
                 if keep_dev is not None:
-                    y = layer.forward_rows(x, B, T, padding_mask=encoder_padding_mask, pos_bias=pos_k)
+                    x = Fn.layer_boundary(x, layer)      # (the select's skip operand is the tensor BEHIND the layer's boundary)
+                    y = layer.forward_rows(x, B, T, padding_mask=encoder_padding_mask, pos_bias=self.pos_emb.for_layer(pos_k) if pos_k is not None else None)
                     x = y if i == self.unb_enc_layer else Fn.layerdrop_select(x, y, keep_dev[i:i + 1])
                 elif not self.training or (dropout_probability > self.encoder_layerdrop) or i == self.unb_enc_layer:
-                    x = layer.forward_rows(x, B, T, padding_mask=encoder_padding_mask, pos_bias=pos_k)
+                    x = Fn.layer_boundary(x, layer)
+                    x = layer.forward_rows(x, B, T, padding_mask=encoder_padding_mask, pos_bias=self.pos_emb.for_layer(pos_k) if pos_k is not None else None)
                 else:   # LayerDrop: the layer's (zero) gradient bucket still reports ready at this point of backward
                     x = Fn.layer_boundary(x, layer)
                 if i == self.unb_enc_layer:

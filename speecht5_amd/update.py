@@ -28,7 +28,7 @@ from . import functional as Fn
 
 class PretrainUpdate:
     def __init__(self, task, model, criterion, micro_batches, *, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0,
-                 graph=True, micro="in_turn", wgrad_stream=None, prefetch_host=True, device=None, lr_fn=None):
+                 graph=True, micro="in_turn", wgrad_stream=None, prefetch_host=True, device=None, lr_fn=None, exchange="phased"):
         from .ddp import FlatGradDataParallel, FusedAdam
         assert micro in ("side_by_side", "in_turn_2buf", "in_turn")
         self.task, self.model, self.crit, self.micro = task, model, criterion, list(micro_batches)
@@ -47,6 +47,14 @@ class PretrainUpdate:
         self.prefetch_host = prefetch_host
         # several ranks + graph: graph = local phase, eager tail = all-reduce + Adam
         self.split = graph and self.ddp.collectives
+        # several ranks + graph + one stream: the exchange is OVERLAPPED with the last micro-batch's backward -- the local phase
+        # is captured as three graphs cut at bucket boundaries (ddp.cut_points), and after each of them the bucket range it
+        # completed goes to the process group as one asynchronous all-reduce (RCCL's stream) while the next graph runs
+        # (exchange="one_message": one graph + one all-reduce of the whole buffer afterwards, the round-2 form)
+        # (ST5_EAGER_PHASED=1: the same three phases enqueued eagerly -- tools/diag_phased.py, the tests' reference point)
+        self.phased = ((self.split or (self.ddp.collectives and os.environ.get("ST5_EAGER_PHASED") == "1"))
+                       and micro == "in_turn" and exchange == "phased" and len(self.micro) >= 1)
+        self._ph = None
         self.n = 0            # update counter (fairseq's num_updates)
         self.sg = None
         # Every update is enqueued on a stream of its own, never on the legacy NULL stream: on this runtime (ROCm 7.2) work issued
@@ -70,6 +78,60 @@ class PretrainUpdate:
             else:
                 self.ddp.accumulate_overlapped(self.micro, self._fwd, backward="in_turn" if self.mode == "in_turn_2buf" else "side_by_side")
         self.ddp.sum_gradient_buffers()
+        # the deferred reductions (split-K slabs, LayerNorm partials) are folded INSIDE the captured part: their descriptors are
+        # host state of the library, consumed by the first flush -- left to the eager tail, the first replay's tail would fold
+        # them and every later replay's slabs would never reach the gradient buffer
+        self.ddp.flush_deferred()
+
+    # -- phased local part (several ranks, overlapped exchange) ------------------------------------------------------------
+    def cut_buckets(self):
+        """Where the last micro-batch's backward is cut: behind the decoder (+ both heads, the shared cross-attention K/V
+        projection: ~60 M parameters complete) and in the middle of the encoder stack."""
+        mb = self.ddp.module_bucket
+        enc = getattr(self.model, "encoder", None)
+        cuts = []
+        if enc is not None:
+            if (id(enc), "out") in mb:
+                cuts.append(mb[(id(enc), "out")])
+            layers = list(getattr(enc, "layers", []))
+            if len(layers) >= 4 and (id(layers[len(layers) // 2]), None) in mb:
+                cuts.append(mb[(id(layers[len(layers) // 2]), None)])
+        return sorted(set(cuts))
+
+    def phase_fns(self):
+        ddp, cuts_b = self.ddp, self.cut_buckets()
+        nph = len(cuts_b) + 1
+
+        def first():
+            ddp.zero_grad()
+            with ddp.local_phase():
+                for mb in self.micro[:-1]:
+                    self.task.train_step(mb, self.model, self.crit, None, self.n, sync=False)
+                with ddp.cut_points(cuts_b) as cuts:
+                    loss = self._fwd(self.micro[-1])
+                self._ph = ddp.backward_phases(loss, cuts)
+                self._ph[0][0]()
+            ddp.flush_deferred()
+
+        def later(k):
+            def fn():
+                if k < len(self._ph):
+                    with ddp.local_phase():
+                        self._ph[k][0]()
+                ddp.flush_deferred()
+            return fn
+
+        def reduce_after(k):
+            def fn():
+                last = k == nph - 1 or k >= len(self._ph) - 1
+                ddp.reduce_bucket_range(None if last else self._ph[k][1])
+            return fn
+        return [first] + [later(k) for k in range(1, nph)], [reduce_after(k) for k in range(nph)]
+
+    def finish_exchange_and_update(self):
+        self.ddp.check_grad_views()
+        self.ddp.wait_reductions()
+        self.opt.step(grad_scale=1.0 / (len(self.micro) * self.world))
 
     def exchange_and_update(self):
         """(several ranks, graph) eager tail: sum over ranks, then mean over ranks and micro-batches inside Adam."""
@@ -78,6 +140,12 @@ class PretrainUpdate:
 
     def step(self):
         """One update enqueued on the current stream (no host synchronisation)."""
+        if self.phased:
+            for fn, bt in zip(*self.phase_fns()):
+                fn()
+                bt()
+            self.finish_exchange_and_update()
+            return
         if self.split:
             self.local_part()
             self.exchange_and_update()
@@ -114,9 +182,15 @@ class PretrainUpdate:
     def prepare_graph(self):
         """Two recording updates + capture (three updates' worth of host random draws; two of them executed)."""
         from .graph import StepGraph
-        self.sg = StepGraph(self.local_part if self.split else self.step, opt=self.opt, model=self.model, device=self.device,
-                            on_step=self.advance, prefetch_host=self.prefetch_host,
-                            after_fn=self.exchange_and_update if self.split else None, stream=self.stream)
+        if self.phased:
+            phases, between = self.phase_fns()
+            self.sg = StepGraph(None, opt=self.opt, model=self.model, device=self.device, on_step=self.advance,
+                                prefetch_host=self.prefetch_host, after_fn=self.finish_exchange_and_update, stream=self.stream,
+                                phases=phases, between=between)
+        else:
+            self.sg = StepGraph(self.local_part if self.split else self.step, opt=self.opt, model=self.model, device=self.device,
+                                on_step=self.advance, prefetch_host=self.prefetch_host,
+                                after_fn=self.exchange_and_update if self.split else None, stream=self.stream)
         self.sg.record()
         self.sg.record()
         self.sg.capture()
@@ -139,8 +213,9 @@ class PretrainUpdate:
         self.finish()
         self.ddp.close()
         if self.sg is not None:      # break the cycle update -> graph -> bound step function -> update: a HIP graph object must
-            self.sg.step_fn = self.sg.after_fn = self.sg.on_step = None   # not wait for the cyclic collector (a collection
-            self.sg.graph = None                                          # during a LATER capture destroys it mid-capture)
+            self.sg.step_fn = self.sg.after_fn = self.sg.on_step = self.sg.phases = self.sg.between = None   # not wait for the cyclic
+            self.sg.graph = self.sg.graphs = None    # collector (a collection during a LATER capture destroys it mid-capture)
+            self._ph = None
             self.sg = None
 
     def state(self):

@@ -15,7 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(cuda, graph, micro, n_updates, layerdrop=0.05, batch=8, poison=False):
+def _run(cuda, graph, micro, n_updates, layerdrop=0.05, batch=8, poison=False, exchange="phased"):
     import contextlib
     import bench
     from speecht5_amd import functional as Fn
@@ -23,7 +23,7 @@ def _run(cuda, graph, micro, n_updates, layerdrop=0.05, batch=8, poison=False):
     upd = None
     try:
         _, _, model, upd = bench.make_update(cuda, torch.bfloat16, "base", batch, 0, graph=graph, micro=micro, layerdrop=layerdrop,
-                                             prefetch_host=False)
+                                             prefetch_host=False, exchange=exchange)
         with poisoned_allocations() if poison else contextlib.nullcontext():
             if graph:
                 upd.prepare_graph()                     # two recorded updates
@@ -85,3 +85,27 @@ def test_side_by_side_measurement_mode_stays_close(cuda):
     d = float((ref[0] - got[0]).abs().max())
     print(f"side_by_side vs in_turn after 4 updates: max parameter difference {d:.3e} (0 = this run happened to be unperturbed)")
     assert d <= 2e-3
+
+
+def test_several_rank_forms_of_the_update_equal_the_one_rank_update(cuda):
+    """What `bench.py --gpus N` runs on several ranks, exercised here in a ONE-rank RCCL group (ST5_DDP_FORCE_COLLECTIVES): the
+    local phase replayed as three graphs cut at bucket boundaries with the completed bucket range all-reduced (async, on RCCL's
+    stream) after each (`exchange="phased"`), and as one graph + one all-reduce of the whole buffer (`"one_message"`); Adam
+    eagerly behind.  A one-rank all-reduce leaves the data unchanged, so both must reproduce the one-rank replayed update bit for
+    bit -- the cuts, the phase order, the collective plumbing and the eager tail change nothing in the arithmetic."""
+    import os
+    import torch.distributed as dist
+    ref = _run(cuda, True, "in_turn", 5)
+    os.environ["ST5_DDP_FORCE_COLLECTIVES"] = "1"
+    os.environ["ST5_EAGER_PHASED"] = "1"
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29700 + os.getpid() % 200}", rank=0, world_size=1, device_id=cuda)
+    try:
+        for exchange in ("phased", "one_message"):
+            got = _run(cuda, True, "in_turn", 5, exchange=exchange)      # (2 recorded + 3 replayed updates)
+            assert got[3] == ref[3] == 5
+            _same(ref, got, f"several-rank form ({exchange}) vs one-rank update")
+        eager = _run(cuda, False, "in_turn", 5, exchange="phased")      # the same phases enqueued eagerly (ST5_EAGER_PHASED)
+        _same(ref, eager, "eager phased vs one-rank replay")
+    finally:
+        dist.destroy_process_group()
+        del os.environ["ST5_DDP_FORCE_COLLECTIVES"], os.environ["ST5_EAGER_PHASED"]

@@ -86,7 +86,23 @@ def _worker(rank, world, port, ret, U, skips, local=False):
         # modality mix: micro-batch (rank + u) odd uses the extra head
         model(_micro(X, rank, u, U), use_extra=((rank + u) % 2 == 1), skip=skips[rank][u]).pow(2).mean().backward()
         during.append(len(launched))
-    if local:
+    if local == "phased":
+        # the several-rank replayed form with overlapped exchange (speecht5_amd/update.py): every micro-batch local; the LAST
+        # one's forward under cut_points, its backward in phases, a contiguous bucket range handed to the group after each
+        with ddp.local_phase():
+            for u in range(U - 1):
+                fwd_bwd(u)
+            with ddp.cut_points([0, 2]) as cuts:
+                loss = model(_micro(X, rank, U - 1, U), use_extra=((rank + U - 1) % 2 == 1), skip=skips[rank][U - 1]).pow(2).mean()
+            assert [c[0] for c in cuts] == [2, 0], cuts          # forward order: the deeper cut first
+            for fn, upto in ddp.backward_phases(loss, cuts):
+                fn()
+                ddp.flush_deferred()
+                ddp.reduce_bucket_range(upto)
+                during.append(len(launched))
+        ddp.wait_reductions()
+        ddp.flat.mul_(1.0 / world)
+    elif local:
         # the replayed-step form (bench.py, N > 1): every micro-batch local, the second one into the twin gradient buffer,
         # then ONE all-reduce over the whole flat buffer
         with ddp.local_phase():
@@ -128,7 +144,7 @@ def _reference(world, U, skips):
 def _run(U, skips, local=False):
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() * 7 + U * 13 + len(str(skips)) + 5 * local) % 2000
+    port = 29500 + (os.getpid() * 7 + U * 13 + len(str(skips)) + 5 * bool(local) + 11 * (local == "phased")) % 2000
     mp.spawn(_worker, args=(2, port, ret, U, skips, local), nprocs=2, join=True)
     return ret, _reference(2, U, skips)
 
@@ -188,3 +204,81 @@ def test_local_phase_then_one_all_reduce():
     _check(ret, ref, one_message=True)
     for r in range(2):
         assert ret[r]["during"] == [0, 0], "a collective was issued inside local_phase()"
+
+
+def test_phased_backward_hands_bucket_ranges_to_the_group_between_phases():
+    """The overlapped exchange of a replayed several-rank update: the last micro-batch's autograd graph is cut at two bucket
+    boundaries (ddp.cut_points), its backward runs in three phases, and after each phase ONE all-reduce over the contiguous
+    range of buckets that just became complete is issued (heads | layers 2-1 | layer 0 + everything else) -- three collectives in
+    the same order on both ranks (LayerDrop-divergent ranks included), same mean as the bucketed path."""
+    skips = [[(), (1,)], [(0,), (2,)]]
+    ret, ref = _run(2, skips, local="phased")
+    for r in range(2):
+        for n, v in ref.items():
+            assert torch.allclose(ret[r]["grads"][n], v, atol=1e-6), (r, n, (ret[r]["grads"][n] - v).abs().max())
+        b = ret[r]["buckets"]
+        assert ret[r]["launched"] == [(b[0][0], b[0][1] - b[0][0]), (b[1][0], b[2][1] - b[1][0]), (b[3][0], b[4][1] - b[3][0])], ret[r]["launched"]
+        assert ret[r]["during"] == [0, 1, 2, 3], ret[r]["during"]      # nothing during the first micro-batch, one range per phase
+    assert torch.equal(ret[0]["flat"], ret[1]["flat"])
+
+
+class _SharedKeyLayer(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.fc = nn.Linear(d, d)
+
+    def forward(self, x, keys):
+        x = Fn.layer_boundary(x, self)
+        return torch.tanh(self.fc(x) + (x.to(torch.bfloat16) @ keys).float())
+
+
+class _SharedKeyStack(nn.Module):
+    """Six layers that all read ONE bf16 tensor derived from a parameter (the encoder's relative-position keys)."""
+
+    def __init__(self, d=16):
+        super().__init__()
+        self.table = nn.Parameter(torch.randn(d, d) * 0.3)
+        self.layers = nn.ModuleList([_SharedKeyLayer(d) for _ in range(6)])
+        self.head = nn.Linear(d, 1)
+
+    def forward(self, x):
+        keys = self.table.to(torch.bfloat16) * 1.0         # (the producer: one node between the parameter and its readers)
+        for l in self.layers:
+            x = Fn.layer_boundary(x, l)
+            x = l(x, Fn.layer_boundary(keys, self, "shared"))
+        return self.head(Fn.layer_boundary(x, self, "out")).sum()
+
+
+def test_tensor_shared_by_a_cut_stack_keeps_its_summation_order():
+    """A phased backward (ddp.cut_points / backward_phases) cuts the stack twice; the gradient of the tensor all layers read
+    is a bf16 sum of six terms.  Its phased value must be THE SAME BITS as the uncut backward's: each region's leaf is seeded
+    with the fold the later regions left, so the sequence of additions is unchanged (ddp._boundary, tag "shared")."""
+    from speecht5_amd.ddp import BucketGroup, FlatGradDataParallel
+    torch.manual_seed(3)
+    model = _SharedKeyStack()
+    ddp = FlatGradDataParallel(model, bucket_groups=[BucketGroup([model.head], triggers=[(model, "out")])] +
+                               [BucketGroup([l]) for l in reversed(list(model.layers))])
+    try:
+        x = torch.randn(64, 16)
+        ddp.zero_grad()
+        model(x).backward()
+        ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+        mb = ddp.module_bucket
+        ddp.zero_grad()
+        with ddp.local_phase():
+            with ddp.cut_points([mb[(id(model.layers[4]), None)], mb[(id(model.layers[2]), None)]]) as cuts:
+                loss = model(x)
+            assert sum(1 for c in cuts if c[0] != "shared") == 2
+            regions = [rg for c in cuts if c[0] == "shared" for rg, _ in c[2]]
+            assert regions == [0, 1, 2], regions
+            phases = ddp.backward_phases(loss, cuts)
+            assert len(phases) == 3
+            for k, (fn, upto) in enumerate(phases):
+                fn()
+                if k < 2:
+                    assert model.table.grad is None or not model.table.grad.any(), "the producer ran before its region"
+        for n, p in model.named_parameters():
+            assert torch.equal(p.grad, ref[n]), (n, float((p.grad - ref[n]).abs().max()))
+        assert ref["table"].abs().max() > 0
+    finally:
+        ddp.close()
