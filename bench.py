@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--micro", default="in_turn", choices=["side_by_side", "in_turn_2buf", "in_turn"],
                     help="how the update's two micro-batches are enqueued (speecht5_amd/update.py); in_turn = one stream, "
                          "bit-reproducible; side_by_side = two streams, faster, not reproducible on this hardware (DESIGN.md 4a)")
+    ap.add_argument("--exchange", default="phased", choices=["phased", "one_message"],
+                    help="several ranks, graph replay: phased = the local phase as 3 graphs, each completed bucket range all-reduced "
+                         "under the next graph; one_message = one graph, then one all-reduce of the whole gradient buffer")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -156,6 +159,10 @@ def main():
     if world > 1 or os.environ.get("ST5_DDP_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
+        # ring all-reduce: RCCL's ring Sum<float> device functions contain no packed-fp32 VALU ops, its tree ones do
+        # (tools/rccl_packed_ops.sh, profiles/r3_rccl_packed_fp32.txt) -- the phased exchange runs them UNDER the backward's
+        # MFMA kernels, where such ops can return stale lanes on this hardware
+        os.environ.setdefault("NCCL_ALGO", "Ring")
         if shared:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -177,7 +184,7 @@ def main():
     wgrad_env = os.environ.get("ST5_WGRAD_STREAM")
     args, task, model, upd = make_update(device, dtype, a.arch, a.batch, rank, graph=use_graph, micro=micro_mode, layerdrop=a.layerdrop,
                                          wgrad_stream=(wgrad_env == "1") if wgrad_env is not None else None,
-                                         prefetch_host=os.environ.get("ST5_PREFETCH_HOST", "1") == "1")
+                                         prefetch_host=os.environ.get("ST5_PREFETCH_HOST", "1") == "1", exchange=a.exchange)
     split_update = upd.split
 
     def barrier():
@@ -256,7 +263,7 @@ def main():
     roof = {"bound": "mfma", "kernel": f"NT-form st5_gemm launches <{a.dtype}> (Linear / attention-projection / conv forward and data-gradient GEMMs; "
                       f"`traffic` is per launch of {NT_KERNEL_NAME})",
             "note": ("launch durations: HIP events around every st5_gemm launch of ONE eagerly enqueued update after the timed region "
-                     "(replayed launches carry no events), micro-batches side by side on two streams as in the timed steps"
+                     "(replayed launches carry no events), micro-batches enqueued as in the timed steps (config.micro_batches)"
                      if use_graph else
                      "launch durations are measured inside the step, i.e. beside the weight-gradient stream's kernels "
                      "(ST5_WGRAD_STREAM=0 gives the isolated rate, ~8 % higher)"),

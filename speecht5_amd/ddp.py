@@ -391,7 +391,11 @@ class FlatGradDataParallel:
         self._flush_splitk()
         self.sum_gradient_buffers()
         if self.collectives:
-            dist.all_reduce(self.flat, group=self.pg)
+            # async_op + wait(): the collective runs on the process group's OWN stream.  A synchronous call is enqueued on the
+            # CURRENT stream and leaves its completion event there; when that stream later begins a graph capture, the group's
+            # watchdog thread polls the event ("operation not permitted on an event last recorded in a capturing stream") and
+            # takes the process down (measured: bench.py --exchange one_message, 1-rank RCCL group)
+            dist.all_reduce(self.flat, group=self.pg, async_op=True).wait()
             if average and self.world > 1:
                 self.flat.mul_(1.0 / self.world)
         self._reset_round()
