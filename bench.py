@@ -123,6 +123,29 @@ def respawn(a):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def config3(a):
+    """`--config 3`: one line in the same contract; `value` = audio-seconds of TTS fine-tuning targets per second of training."""
+    assert a.gpus == 1, "--config 3 is a one-GPU measurement"
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import bench_cfg3
+    r = bench_cfg3.run(steps=a.steps, warmup=a.warmup, graph=not a.no_graph)
+    tts, voc = r["tts_finetune_step"], r["hifigan_forward"]
+    nt = tts["gemm"]["by_variant"].get("bf16_NT", {})
+    out = {"metric": "audio-sec/s fwd+bwd SpeechT5-Base TTS fine-tune", "value": tts["audio_sec_per_s"], "unit": "audio-sec/s", "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": tts["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[2]: SpeechT5-Base TTS fine-tune step (32 texts x 100 tokens -> 32 x 600 mel frames, r = 2, "
+                                  "guided attention, dropout 0.15), fwd+bwd+clip+Adam; + HiFi-GAN (HF SpeechT5HifiGan config) forward on the same 32 x 600 frames",
+                      "enqueue": tts["enqueue"], "utterances_per_s": tts["utterances_per_s"]},
+           "roofline": {"bound": "mfma", "kernel": "NT-form st5_gemm launches <bf16> of the TTS step (HIP events, one eagerly enqueued step)",
+                        "achieved": nt.get("tflops"), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(nt["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4) if nt.get("tflops") else None, "traffic": None,
+                        "step": {"gemm_tflop_per_update": tts["gemm"]["gemm_tflop"], "tflops": tts["step_tflops"], "frac_of_peak": tts["step_frac_of_peak"]},
+                        "all_variants": tts["gemm"]["by_variant"]},
+           "vocoder": voc}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +165,13 @@ def main():
     ap.add_argument("--exchange", default="phased", choices=["phased", "one_message"],
                     help="several ranks, graph replay: phased = the local phase as 3 graphs, each completed bucket range all-reduced "
                          "under the next graph; one_message = one graph, then one all-reduce of the whole gradient buffer")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3],
+                    help="BASELINE.json configs[]: 2 = the pre-training update (the headline metric, default); 3 = TTS fine-tuning step "
+                         "(32 texts x 100 tokens -> 600 mel frames, guided attention, replayed) + full-size HiFi-GAN on the same "
+                         "32 x 600 frames, one GPU")
     a = ap.parse_args()
+    if a.config == 3:
+        return config3(a)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn(a)

@@ -280,6 +280,31 @@ int st5_unfold_rows(const float* wav, void* out, int32_t B, int32_t S, int32_t k
                     void* stream);
 int st5_pad_time(const void* src, void* dst, int32_t B, int32_t T, int32_t C, int32_t pad_l, int32_t pad_r,
                  int dtype, void* stream);
+/* HiFi-GAN generator (HuggingFace SpeechT5HifiGan, modeling_speecht5.py:2887-3066: every convolution is preceded by a LeakyReLU
+ * and zero "same" padding): dst [B, pad_l + T + pad_r, C] = zero-padded act(src [B, T, C]) in ONE pass (16-byte vectors when
+ * C * sizeof(elem) % 16 == 0), act in {ST5_ACT_NONE, ST5_ACT_LRELU_01, ST5_ACT_LRELU_001, ...} with act(0) == 0. */
+int st5_pad_time_act(const void* src, void* dst, int32_t B, int32_t T, int32_t C, int32_t pad_l, int32_t pad_r, int32_t act,
+                     int dtype, void* stream);
+/* Zero the halo rows [0, pad_l) and [pad_l + T, pad_l + T + pad_r) of every batch element of dst [B, pad_l + T + pad_r, C]: a
+ * convolution whose st5_gemm output operand addresses the interior of the padded buffer the NEXT convolution reads. */
+int st5_zero_halo(void* dst, int32_t B, int32_t T, int32_t C, int32_t pad_l, int32_t pad_r, int dtype, void* stream);
+/* Channels-last Conv1d with 32 or 64 OUTPUT channels, bf16, as an MFMA implicit GEMM whose 32 MFMA rows are the output channels and
+ * whose columns are time steps (csrc/conv1d_narrow.hip) -- the 64- and 32-channel stages of the HiFi-GAN generator (HF
+ * modeling_speecht5.py:2920-2960 residual blocks, :3010-3030 upsampler), where the 128-wide tiles of st5_gemm waste 1/2 .. 3/4 of
+ * their MFMAs:
+ *   y[b, t, co] = act(alpha * sum_{tau < taps, c < Cin} w[co, tau * Cin + c] * x[b, t, tau, c] + bias[co]) + residual[b, t, co] + beta * y[b, t, co]
+ * with x[b, t, tau, c] = x[b * x_bs + t * x_ts + tau * tap_stride + c] (all strides in ELEMENTS; the caller's buffer holds the halo rows:
+ * a dilated convolution is tap_stride = dilation * Cin over the zero-padded input, one phase of a stride-s transposed convolution is
+ * taps = 2, tap_stride = Cin), y / residual addressed as base + b * bs + t * ts + co (padded or phase-interleaved layouts without
+ * copies).  Cin in {32, 64, 128}, Cout in {32, 64}; x, w 16-byte aligned, strides multiples of 8 (x) / 4 (y, residual) elements,
+ * else ST5_ERR_ARG / ST5_ERR_ALIGN.  act in {ST5_ACT_NONE, ST5_ACT_LRELU_01, ST5_ACT_LRELU_001}.  bias fp32 or NULL; residual NULL for none. */
+int st5_conv1d_narrow(const void* x, int64_t x_bs, int32_t x_ts, const void* w, const float* bias, void* y, int64_t y_bs, int32_t y_ts,
+                      const void* residual, int64_t r_bs, int32_t r_ts, int32_t B, int32_t L, int32_t Cin, int32_t Cout, int32_t taps,
+                      int32_t tap_stride, float alpha, float beta, int32_t act, void* stream);
+/* The generator's last convolution (HF modeling_speecht5.py:3058-3062: 32 -> 1 channels, k = 7, tanh), bf16:
+ *   y[b * L + t] = act(alpha * sum_{tau, c} w[tau * Cin + c] * x[b * x_bs + t * x_ts + tau * tap_stride + c] + bias[0]). */
+int st5_conv1d_cout1(const void* x, int64_t x_bs, int32_t x_ts, const void* w, const float* bias, void* y, int32_t B, int32_t L, int32_t Cin,
+                     int32_t taps, int32_t tap_stride, float alpha, int32_t act, void* stream);
 
 /* ---- log-mel front end of the input pipeline (data/speech_dataset.py:142-181 `logmelfilterbank`: librosa.stft
  *      n_fft 1024 / hop 256 / periodic Hann / centred with reflect padding, |.|, 80 Slaney mel filters, log10 floor 1e-10).

@@ -1,0 +1,353 @@
+// Channels-last Conv1d with FEW output channels (32 / 64) as an MFMA implicit GEMM -- the late stages of the HiFi-GAN generator
+// (HuggingFace SpeechT5HifiGan, modeling_speecht5.py:2887-3066: resblocks of 64 and 32 channels at 64x / 256x the frame rate hold
+// most of the activation bytes).  The general 128x128-tile GEMM of gemm.hip spends 3/4 (N = 32) or 1/2 (N = 64) of its MFMAs on
+// columns that do not exist; here the MFMA's 32 ROWS are the output channels and its 32 COLUMNS are time steps:
+//
+//   acc[cout, t] += W[cout, tau * Cin + c] * x[b, t + tau * dil, c]        v_mfma_f32_32x32x16_bf16, K = 16 channels of one tap
+//
+//   * weights [Cout, taps * Cin] live in LDS for the life of the block (<= 91 KB), one ds_read_b128 per fragment, reused for the
+//     wave's 4 time blocks;
+//   * activations are read straight from global memory as MFMA B fragments: lane (t = lane & 31, half = lane >> 5) loads the 16
+//     bytes x[t + tau * dil, 16 j + 8 half ..] -- a wave's two loads per tap cover 32 complete 64-byte rows; the taps re-read the
+//     same rows from L1 / L2, HBM sees every input row once (plus the tile halo);
+//   * the accumulator layout gives every lane 4 CONSECUTIVE output channels of its time step per register group: bias, alpha,
+//     LeakyReLU, residual, running sum and the bf16 store are 8-byte operations, no LDS transpose;
+//   * input and output are addressed by (batch stride, time stride), so the padded layouts of hifigan.py (halo rows, interleaved
+//     phases of the transposed convolution) need no copies.
+// Bounds: k = 3 is HBM-bound (6 MFMAs per 2 KB of output), k = 11 is about even between MFMA, L1 fragment traffic and HBM.
+#include "common.h"
+#include "../../include/speecht5_hip.h"
+
+namespace {
+
+constexpr int NW = 8, NTHR = NW * 64, TB = 4;     // 8 waves x 4 time blocks of 32 = 1024 time steps per block tile
+constexpr int TILE_T = NW * TB * 32;
+
+struct NarrowArgs {
+  const bf16_t* x; long long x_bs; int x_ts;
+  const bf16_t* w; const float* bias;
+  bf16_t* y; long long y_bs; int y_ts;
+  const bf16_t* R; long long r_bs; int r_ts;
+  int B, L, Cin, taps, tap_stride, K;
+  int tiles_per_batch, tiles_per_block, blocks_per_batch;
+  float alpha, beta, slope;   // slope: LeakyReLU's negative-side factor (1 = no activation)
+};
+
+template <int CB, int NJ>     // CB: output-channel blocks of 32; NJ: Cin / 16
+__global__ __launch_bounds__(NTHR) void conv1d_narrow_kernel(const NarrowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* const wl = reinterpret_cast<bf16_t*>(smem);      // [CB * 32][Kp]
+  const int Kp = a.K + 8;                                  // (+16 bytes per row: fragment reads of 32 rows spread over the banks)
+  {
+    const int kv = a.K >> 3, nvec = CB * 32 * kv;
+    for (int i = threadIdx.x; i < nvec; i += NTHR) {
+      const int row = i / kv, c = (i - row * kv) << 3;
+      *reinterpret_cast<u32x4*>(wl + row * Kp + c) = *reinterpret_cast<const u32x4*>(a.w + (long long)row * a.K + c);
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tl = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x / a.blocks_per_batch;
+  const int tile0 = (blockIdx.x - b * a.blocks_per_batch) * a.tiles_per_block;
+  const int tile1 = min(tile0 + a.tiles_per_block, a.tiles_per_batch);
+  const bf16_t* const xb = a.x + (long long)b * a.x_bs + 8 * h;
+  const bf16_t* const wrow = wl + tl * Kp + 8 * h;
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int t0 = tile * TILE_T + wave * (TB * 32);
+    if (t0 >= a.L) break;                                  // (wave-uniform; no barrier inside the loop)
+    f32x16 acc[CB][TB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[cb][tb][e] = 0.f;
+    const bf16_t* xr[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) xr[tb] = xb + (long long)min(t0 + 32 * tb + tl, a.L - 1) * a.x_ts;   // (rows past L: clamped, never stored)
+#pragma unroll 1
+    for (int tau = 0; tau < a.taps; ++tau) {
+      const int xo = tau * a.tap_stride, wo = tau * a.Cin;
+      bf16x8 bf[NJ][TB];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) bf[j][tb] = *reinterpret_cast<const bf16x8*>(xr[tb] + xo + 16 * j);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(wrow + cb * 32 * Kp + wo + 16 * j);
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb) acc[cb][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j][tb], acc[cb][tb], 0, 0, 0);
+        }
+      }
+    }
+    // epilogue: register r of a lane = output channel 8 (r >> 2) + 4 half + (r & 3) of time step t0 + 32 tb + (lane & 31)
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+      const int t = t0 + 32 * tb + tl;
+      if (t >= a.L) continue;
+      bf16_t* const yr = a.y + (long long)b * a.y_bs + (long long)t * a.y_ts;
+      const bf16_t* const rr = a.R ? a.R + (long long)b * a.r_bs + (long long)t * a.r_ts : nullptr;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = cb * 32 + 8 * g + 4 * h;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[cb][tb][4 * g + e] * a.alpha;
+            if (a.bias) x += a.bias[c0 + e];
+            v[e] = x > 0.f ? x : x * a.slope;      // (the generic act_f() switch, inlined 64 times, made this kernel I-cache bound)
+          }
+          if (rr) {
+            const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rr + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+          }
+          if (a.beta != 0.f) {
+            const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(yr + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += a.beta * (float)o4[e];
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x4*>(yr + c0) = o;
+        }
+      }
+    }
+  }
+}
+
+// Cout = 32, second form: each wave first copies ITS time range of the input (128 steps + the taps' reach) into LDS with fully
+// coalesced 16-byte loads -- HBM / L2 see every input row once per tile instead of once per tap, and not as 64 separate 16-byte
+// requests per fragment -- and reads the MFMA B fragments from there; the accumulators go back through the same LDS region so that
+// bias / activation / residual / running sum / store work on 16 contiguous bytes per lane (a wave writes 1 KB contiguous).
+// Measured against the first form on the 32-channel stage of the full-size generator: see DESIGN.md.  Requires x_ts == Cin.
+template <int NJ>
+__global__ __launch_bounds__(NTHR) void conv1d_narrow32_kernel(const NarrowArgs a, const int tap_rows, const int rows_w, const int rows_in) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CIN = NJ * 16, ROWB = CIN * 2 + 16;        // bytes per staged input row (+16: fragment reads spread over the banks)
+  constexpr int SLD = 36;                                  // floats per staged accumulator row (32 + 4)
+  bf16_t* const wl = reinterpret_cast<bf16_t*>(smem);      // [32][Kp]
+  const int Kp = a.K + 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* const xs = smem + ((32 * Kp * 2 + 15) & ~15) + (size_t)wave * (((size_t)rows_w * ROWB + 15) & ~(size_t)15);
+  {
+    const int kv = a.K >> 3, nvec = 32 * kv;
+    for (int i = threadIdx.x; i < nvec; i += NTHR) {
+      const int row = i / kv, c = (i - row * kv) << 3;
+      *reinterpret_cast<u32x4*>(wl + row * Kp + c) = *reinterpret_cast<const u32x4*>(a.w + (long long)row * a.K + c);
+    }
+  }
+  const int tl = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x / a.blocks_per_batch;
+  const int tile0 = (blockIdx.x - b * a.blocks_per_batch) * a.tiles_per_block;
+  const bf16_t* const xb = a.x + (long long)b * a.x_bs;
+  const bf16_t* const wrow = wl + tl * Kp + 8 * h;
+  // epilogue roles: lane handles the 16-byte chunks `lane` and `lane + 64` of a [32 t][32 cout] bf16 tile: t = chunk >> 2, 8 couts
+  const int ec = (lane & 3) * 8;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = a.bias ? a.bias[ec + e] : 0.f;
+  for (int it = 0; it < a.tiles_per_block; ++it) {         // (block-uniform trip count: barriers inside)
+    const int t0 = (tile0 + it) * TILE_T + wave * (TB * 32);
+    __syncthreads();                                       // weights visible (first trip); previous trip's staging reads done
+    // ---- stage rows [t0, t0 + rows_w) of the padded input, clamped to the buffer ----
+    {
+      constexpr int CV = CIN / 8;                          // 16-byte chunks per row
+      const int nch = rows_w * CV;
+      for (int i = lane; i < nch; i += 64) {
+        const int r = i / CV, c = i - r * CV;
+        const int gr = min(t0 + r, rows_in - 1);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (long long)max(gr, 0) * CIN + c * 8);
+        *reinterpret_cast<u32x4*>(xs + r * ROWB + c * 16) = v;
+      }
+    }
+    __syncthreads();
+    f32x16 acc[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tb][e] = 0.f;
+    const char* const xl = xs + tl * ROWB + 16 * h;
+#pragma unroll 1
+    for (int tau = 0; tau < a.taps; ++tau) {
+      const char* const xt = xl + tau * tap_rows * ROWB;
+      const int wo = tau * CIN;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(wrow + wo + 16 * j);
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(xt + tb * 32 * ROWB + 32 * j);
+          acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[tb], 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue through the wave's LDS region (now free): [32 t][SLD] floats per time block ----
+    float* const st = reinterpret_cast<float*>(xs);
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {             // (fully unrolled: a dynamic index into acc[] would live in scratch)
+      __syncthreads();                                     // fragment reads (first trip) / previous block's staged reads done
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[tb][4 * g + e];
+        *reinterpret_cast<f32x4*>(st + tl * SLD + 8 * g + 4 * h) = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int tt = (lane >> 2) + 16 * half;
+        const int t = t0 + 32 * tb + tt;
+        if (t >= a.L || t0 >= a.L) continue;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(st + tt * SLD + ec);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(st + tt * SLD + ec + 4);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = s0[e]; v[4 + e] = s1[e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = fmaf(v[e], a.alpha, bias8[e]);
+          v[e] = x > 0.f ? x : x * a.slope;
+        }
+        bf16_t* const yp = a.y + (long long)b * a.y_bs + (long long)t * a.y_ts + ec;
+        if (a.R) {
+          float r8[8];
+          load8f<bf16_t>(a.R + (long long)b * a.r_bs + (long long)t * a.r_ts + ec, r8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r8[e];
+        }
+        if (a.beta != 0.f) {
+          float o8[8];
+          load8f<bf16_t>(yp, o8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += a.beta * o8[e];
+        }
+        store8f<bf16_t>(yp, v);
+      }
+    }
+  }
+}
+
+// One output channel (the generator's conv_post: 32 -> 1, k = 7, tanh): a dot product of taps * Cin values per time step.
+__global__ __launch_bounds__(256) void conv1d_cout1_kernel(const bf16_t* __restrict__ x, long long x_bs, int x_ts, const bf16_t* __restrict__ w,
+                                                           const float* __restrict__ bias, bf16_t* __restrict__ y, int B, int L, int Cin, int taps,
+                                                           int tap_stride, float alpha, int act) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const wf = reinterpret_cast<float*>(smem);
+  const int K = taps * Cin;
+  for (int i = threadIdx.x; i < K; i += 256) wf[i] = (float)w[i];
+  __syncthreads();
+  const long long n = (long long)B * L;
+  const float b0 = bias ? bias[0] : 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / L), t = (int)(i - (long long)b * L);
+    const bf16_t* xr = x + (long long)b * x_bs + (long long)t * x_ts;
+    float s = 0.f;
+    for (int tau = 0; tau < taps; ++tau) {
+      const bf16_t* p = xr + tau * tap_stride;
+      const float* wt = wf + tau * Cin;
+      for (int c = 0; c < Cin; c += 8) {
+        float v[8];
+        load8f<bf16_t>(p + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(v[e], wt[c + e], s);
+      }
+    }
+    y[i] = (bf16_t)act_f(act, fmaf(s, alpha, b0));
+  }
+}
+
+template <int CB, int NJ>
+int launch_narrow(const NarrowArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)CB * 32 * (a.K + 8) * sizeof(bf16_t);
+  static bool attr_done = false;     // (per instantiation; idempotent)
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)conv1d_narrow_kernel<CB, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return ST5_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv1d_narrow_kernel<CB, NJ>), dim3((unsigned)(a.B * a.blocks_per_batch)), dim3(NTHR), lds, s, a);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+template <int NJ>
+int launch_narrow32(const NarrowArgs& a, int tap_rows, hipStream_t s, bool* fits) {
+  constexpr int ROWB = NJ * 32 + 16;
+  const int rows_w = TB * 32 + (a.taps - 1) * tap_rows, rows_in = a.L + (a.taps - 1) * tap_rows;
+  const size_t wbytes = ((size_t)32 * (a.K + 8) * 2 + 15) & ~(size_t)15;
+  const size_t per_wave = ((size_t)rows_w * ROWB + 15) & ~(size_t)15;      // (>= 129 rows: also holds the 32 x 36 float accumulator staging)
+  const size_t lds = wbytes + NW * per_wave;
+  *fits = lds <= 160 * 1024;
+  if (!*fits) return ST5_OK;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)conv1d_narrow32_kernel<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return ST5_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv1d_narrow32_kernel<NJ>), dim3((unsigned)(a.B * a.blocks_per_batch)), dim3(NTHR), lds, s, a, tap_rows, rows_w, rows_in);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+}  // namespace
+
+extern "C" int st5_conv1d_narrow(const void* x, int64_t x_bs, int32_t x_ts, const void* w, const float* bias, void* y, int64_t y_bs,
+                                 int32_t y_ts, const void* residual, int64_t r_bs, int32_t r_ts, int32_t B, int32_t L, int32_t Cin,
+                                 int32_t Cout, int32_t taps, int32_t tap_stride, float alpha, float beta, int32_t act, void* stream) {
+  if (!x || !w || !y || B <= 0 || L <= 0 || taps <= 0) return ST5_ERR_ARG;
+  if ((Cout != 32 && Cout != 64) || (Cin != 32 && Cin != 64 && Cin != 128)) return ST5_ERR_ARG;
+  // 16-byte fragment loads / 8-byte stores: every stride and base a multiple of 8 elements (4 for the outputs)
+  if (x_ts % 8 || x_bs % 8 || tap_stride % 8 || y_ts % 4 || y_bs % 4 || (residual && (r_ts % 4 || r_bs % 4))) return ST5_ERR_ALIGN;
+  if (((uintptr_t)x | (uintptr_t)w) % 16 || (uintptr_t)y % 8 || (residual && (uintptr_t)residual % 8)) return ST5_ERR_ALIGN;
+  NarrowArgs a;
+  a.x = (const bf16_t*)x; a.x_bs = x_bs; a.x_ts = x_ts; a.w = (const bf16_t*)w; a.bias = bias;
+  a.y = (bf16_t*)y; a.y_bs = y_bs; a.y_ts = y_ts; a.R = (const bf16_t*)residual; a.r_bs = r_bs; a.r_ts = r_ts;
+  a.B = B; a.L = L; a.Cin = Cin; a.taps = taps; a.tap_stride = tap_stride; a.K = taps * Cin;
+  a.tiles_per_batch = (L + TILE_T - 1) / TILE_T;
+  // the weight image is loaded once per block: several tiles per block when there are enough tiles to keep > 4 blocks per CU
+  a.tiles_per_block = 1;
+  while (a.tiles_per_block < 8 && (long long)B * (a.tiles_per_batch / (a.tiles_per_block * 2)) >= 1024) a.tiles_per_block *= 2;
+  a.blocks_per_batch = (a.tiles_per_batch + a.tiles_per_block - 1) / a.tiles_per_block;
+  if (act != ACT_NONE && act != ACT_LRELU_01 && act != ACT_LRELU_001) return ST5_ERR_ARG;
+  a.alpha = alpha; a.beta = beta; a.slope = act == ACT_LRELU_01 ? 0.1f : act == ACT_LRELU_001 ? 0.01f : 1.0f;
+  if ((size_t)(Cout) * (a.K + 8) * sizeof(bf16_t) > 160 * 1024) return ST5_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  static const bool first_form_only = getenv("ST5_NARROW_V1") && getenv("ST5_NARROW_V1")[0] == '1';   // (A/B switch)
+  const bool vec16 = (uintptr_t)y % 16 == 0 && y_ts % 8 == 0 && y_bs % 8 == 0 &&
+                     (!residual || ((uintptr_t)residual % 16 == 0 && r_ts % 8 == 0 && r_bs % 8 == 0));
+  if (Cout == 32 && !first_form_only && vec16 && x_ts == Cin && tap_stride % Cin == 0 && (Cin == 32 || Cin == 64)) {
+    bool fits = false;
+    const int rc = Cin == 32 ? launch_narrow32<2>(a, tap_stride / Cin, s, &fits) : launch_narrow32<4>(a, tap_stride / Cin, s, &fits);
+    if (rc != ST5_OK || fits) return rc;
+  }
+  if (Cout == 32) {
+    if (Cin == 32) return launch_narrow<1, 2>(a, s);
+    if (Cin == 64) return launch_narrow<1, 4>(a, s);
+    return launch_narrow<1, 8>(a, s);
+  }
+  if (Cin == 32) return launch_narrow<2, 2>(a, s);
+  if (Cin == 64) return launch_narrow<2, 4>(a, s);
+  return launch_narrow<2, 8>(a, s);
+}
+
+extern "C" int st5_conv1d_cout1(const void* x, int64_t x_bs, int32_t x_ts, const void* w, const float* bias, void* y, int32_t B, int32_t L,
+                                int32_t Cin, int32_t taps, int32_t tap_stride, float alpha, int32_t act, void* stream) {
+  if (!x || !w || !y || B <= 0 || L <= 0 || taps <= 0 || Cin <= 0 || Cin % 8) return ST5_ERR_ARG;
+  if (x_ts % 8 || x_bs % 8 || tap_stride % 8 || (uintptr_t)x % 16) return ST5_ERR_ALIGN;
+  const long long n = (long long)B * L;
+  const unsigned grid = (unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+  hipLaunchKernelGGL(conv1d_cout1_kernel, dim3(grid), dim3(256), (size_t)taps * Cin * sizeof(float), (hipStream_t)stream, (const bf16_t*)x,
+                     (long long)x_bs, x_ts, (const bf16_t*)w, bias, (bf16_t*)y, B, L, Cin, taps, tap_stride, alpha, act);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}

@@ -448,6 +448,47 @@ __global__ void pad_time_kernel(const T* __restrict__ src, T* __restrict__ dst, 
   for (int c = threadIdx.x & 63; c < C; c += 64) d[c] = in ? s[c] : zero;
 }
 
+// dst[b, t', :] = act(src[b, t' - pad_l, :]) inside, 0 in the halo (every activation used here maps 0 to 0, so this is the padded
+// copy of act(src)); one 16-byte vector per thread -- with narrow rows (HiFi-GAN's late stages: 32 channels = 64 bytes per row) a
+// wave-per-row copy moves 64 bytes per wave.  Requires C * sizeof(T) % 16 == 0.
+template <typename T>
+__global__ void pad_time_act_vec_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int Tn, int C, int pad_l, int pad_r,
+                                        int act) {
+  constexpr int V = Elem<T>::VEC;
+  const int cv = C / V, Tp = pad_l + Tn + pad_r;
+  const long long n = (long long)B * Tp * cv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / cv;
+    const int c = (int)(i - row * cv) * V;
+    const int b = (int)(row / Tp), t = (int)(row - (long long)b * Tp) - pad_l;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (t >= 0 && t < Tn) {
+      v = *reinterpret_cast<const uint4*>(src + ((long long)b * Tn + t) * C + c);
+      if (act != ACT_NONE) {
+        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) e[j] = Elem<T>::from_f(act_f(act, Elem<T>::to_f(e[j])));
+      }
+    }
+    *reinterpret_cast<uint4*>(dst + row * C + c) = v;
+  }
+}
+// zero rows [0, pad_l) and [pad_l + Tn, Tp) of every batch element of a [B, Tp, C] buffer (the halo of a convolution output
+// that its producer writes straight into the padded layout the next convolution reads)
+template <typename T>
+__global__ void zero_halo_kernel(T* __restrict__ dst, int B, int Tn, int C, int pad_l, int pad_r) {
+  const int P = pad_l + pad_r, Tp = P + Tn;
+  const long long n = (long long)B * P * C;
+  const T zero = Elem<T>::from_f(0.f);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    const int b = (int)(r / P), h = (int)(r % P);
+    const int t = h < pad_l ? h : Tn + h;
+    dst[((long long)b * Tp + t) * C + c] = zero;
+  }
+}
+
 template <typename T>
 __global__ void channel_affine_kernel(const T* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
                                       T* __restrict__ y, long long rows, int cols, int act) {
@@ -848,6 +889,32 @@ extern "C" int st5_pad_time(const void* src, void* dst, int32_t B, int32_t T, in
   dim3 grid((unsigned)((nrow + 3) / 4));
   DISPATCH(dtype, hipLaunchKernelGGL(pad_time_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, B, T, C, pad_l, pad_r),
            hipLaunchKernelGGL(pad_time_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, B, T, C, pad_l, pad_r));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_pad_time_act(const void* src, void* dst, int32_t B, int32_t T, int32_t C, int32_t pad_l, int32_t pad_r,
+                                int32_t act, int dtype, void* stream) {
+  if (!src || !dst || B <= 0 || T <= 0 || C <= 0 || pad_l < 0 || pad_r < 0) return ST5_ERR_ARG;
+  const int esz = dtype == ST5_BF16 ? 2 : 4;
+  if ((C * esz) % 16 != 0 || ((uintptr_t)src | (uintptr_t)dst) % 16 != 0) {   // odd rows: the row-per-wave copy, then the activation in place
+    const int rc = st5_pad_time(src, dst, B, T, C, pad_l, pad_r, dtype, stream);
+    if (rc != ST5_OK || act == ACT_NONE) return rc;
+    return st5_act_fwd(dst, dst, (int64_t)B * (pad_l + T + pad_r) * C, act, dtype, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)B * (pad_l + T + pad_r) * (C * esz / 16);
+  DISPATCH(dtype, hipLaunchKernelGGL(pad_time_act_vec_kernel<bf16_t>, grid_for(n), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, B, T, C, pad_l, pad_r, act),
+           hipLaunchKernelGGL(pad_time_act_vec_kernel<float>, grid_for(n), dim3(256), 0, s, (const float*)src, (float*)dst, B, T, C, pad_l, pad_r, act));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_zero_halo(void* dst, int32_t B, int32_t T, int32_t C, int32_t pad_l, int32_t pad_r, int dtype, void* stream) {
+  if (!dst || B <= 0 || T <= 0 || C <= 0 || pad_l < 0 || pad_r < 0) return ST5_ERR_ARG;
+  if (pad_l + pad_r == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)B * (pad_l + pad_r) * C;
+  DISPATCH(dtype, hipLaunchKernelGGL(zero_halo_kernel<bf16_t>, grid_for(n), dim3(256), 0, s, (bf16_t*)dst, B, T, C, pad_l, pad_r),
+           hipLaunchKernelGGL(zero_halo_kernel<float>, grid_for(n), dim3(256), 0, s, (float*)dst, B, T, C, pad_l, pad_r));
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

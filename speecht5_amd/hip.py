@@ -109,6 +109,12 @@ _SIGS = {
     "st5_embed_rows_bwd_det": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_int, c_void_p]),
     "st5_unfold_rows": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "st5_pad_time": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    "st5_pad_time_act": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    "st5_zero_halo": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    "st5_conv1d_narrow": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
+                                  c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32, c_void_p]),
+    "st5_conv1d_cout1": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                 c_float, c_int32, c_void_p]),
     "st5_stft_frames": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "st5_stft_magnitude": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "st5_log10_floor": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
