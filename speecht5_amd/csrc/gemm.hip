@@ -329,11 +329,30 @@ __device__ __forceinline__ void epilogue_rows(const EpiArgs& ea, const float* st
 // aligned, N % 8 == 0 so a lane's 8 columns are all valid or all out of range).  Both 32-row halves are staged through the
 // wave-private LDS slab; the per-lane constants (bias, column offsets) are loaded once, the uniform feature tests are
 // per 8-vector, and the four row passes of a half are unrolled so their LDS reads / global loads overlap.
-template <typename T, typename OUT>
+#ifdef ST5_EPI_SLIM   // (experiment: how much of the epilogue's cost is code size? GELU / ReLU only in the fast epilogue)
+#define EPI_ACT(act, x) ((act) == ACT_GELU ? gelu_fast<false>(x) : (act) == ACT_RELU ? fmaxf((x), 0.f) : (x))
+#define EPI_ACT_GRAD(act, x) ((act) == ACT_GELU ? gelu_fast<true>(x) : (act) == ACT_RELU ? ((x) > 0.f ? 1.f : 0.f) : 1.f)
+#else
+#define EPI_ACT(act, x) act_f<FASTACT>((act), (x))
+#define EPI_ACT_GRAD(act, x) act_grad_f<FASTACT>((act), (x))
+#endif
+// FEAT < 0: every epilogue feature is tested at run time (uniform branches; ALL of the code is in the kernel).  FEAT >= 0: a bit
+// mask of the features this instantiation has, everything else is compiled out.  Why: the run-time form of the 128^2 NT kernel is
+// 18.6 k instructions (~130 KB against a 64 KB instruction cache shared by two CUs); a tile's epilogue walks through all of it
+// while the other resident block is in its k-loop.  Measured: removing only the tanh / LeakyReLU cases from the activation switch
+// made the step's NT launches 4.5 % faster; the hot combinations of the training step therefore get kernels of their own
+// (nt_feat_of() picks, the run-time form stays the fallback).
+enum { F_GELU = 1, F_DACT = 2, F_DROP = 4, F_RES = 8, F_PRE = 16, F_BETA = 32 };
+template <typename T, typename OUT, int FEAT = -1>
 __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, const f32x16& acc00, const f32x16& acc01,
                                               const f32x16& acc10, const f32x16& acc11, const int mbase, const int nbase,
                                               const int lane) {
+  // no mul + add contraction ACROSS the feature steps below: in the run-time form they sit in different basic blocks and are never
+  // fused; a specialised instantiation has them in straight-line code -- with contraction it would round (x * keep + residual)
+  // once instead of twice and stop being bit-identical to the run-time form
+#pragma clang fp contract(off)
   constexpr bool FASTACT = sizeof(T) == 2;   // bf16 compute mode
+  constexpr bool RT = FEAT < 0;
   const int cc = (lane & 7) * 8, rsub = lane >> 3;
   const int gn = nbase + cc;
   const bool col_ok = gn < ea.N;
@@ -346,13 +365,18 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
   }
-  const bool drop = ea.dropout_p > 0.f;
+  const bool drop = RT ? ea.dropout_p > 0.f : (FEAT & F_DROP) != 0;
   const unsigned int thresh = drop ? dropout_thresh(ea.dropout_p) : 0u;
   const float inv_keep = drop ? 1.f / (1.f - ea.dropout_p) : 1.f;
   OUT* const Cb = reinterpret_cast<OUT*>(ea.C) + gn;
-  const OUT* const Rb = ea.R ? reinterpret_cast<const OUT*>(ea.R) + gn : nullptr;
-  const T* const Pb = ea.P ? reinterpret_cast<const T*>(ea.P) + gn : nullptr;
-  T* const Qb = ea.Cpre ? reinterpret_cast<T*>(ea.Cpre) + gn : nullptr;
+  const bool has_res = RT ? ea.R != nullptr : (FEAT & F_RES) != 0;
+  const bool has_pre = RT ? ea.Cpre != nullptr : (FEAT & F_PRE) != 0;
+  const bool dact = RT ? ea.dact != 0 : (FEAT & F_DACT) != 0;
+  const bool has_beta = RT ? ea.beta != 0.f : (FEAT & F_BETA) != 0;
+  const int act = RT ? ea.act : ((FEAT & (F_GELU | F_DACT)) ? ACT_GELU : ACT_NONE);
+  const OUT* const Rb = has_res ? reinterpret_cast<const OUT*>(ea.R) + gn : nullptr;
+  const T* const Pb = dact ? reinterpret_cast<const T*>(ea.P) + gn : nullptr;
+  T* const Qb = has_pre ? reinterpret_cast<T*>(ea.Cpre) + gn : nullptr;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h == 0) stage_write(stage, acc00, acc01, lane);
@@ -379,19 +403,19 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
           if (ea.rpb) { q = gm / ea.rpb; rm = gm - q * ea.rpb; }
           const long long c_off = q * ea.c_bs + rm * ea.c_ld;
           float rv[8], pv[8], ov[8];
-          if (Rb) load8f<OUT>(Rb + q * ea.r_bs + rm * ea.r_ld, rv);
-          if (ea.dact) load8f<T>(Pb + q * ea.p_bs + rm * ea.p_ld, pv);
-          if (ea.beta != 0.f) load8f<OUT>(Cb + c_off, ov);
+          if (has_res) load8f<OUT>(Rb + q * ea.r_bs + rm * ea.r_ld, rv);
+          if (dact) load8f<T>(Pb + q * ea.p_bs + rm * ea.p_ld, pv);
+          if (has_beta) load8f<OUT>(Cb + c_off, ov);
           float x[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = fmaf(v[k][e], ea.alpha, bias8[e]);
-          if (Qb) store8f<T>(Qb + q * ea.q_bs + rm * ea.q_ld, x);
-          if (ea.dact) {
+          if (has_pre) store8f<T>(Qb + q * ea.q_bs + rm * ea.q_ld, x);
+          if (dact) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] *= act_grad_f<FASTACT>(ea.act, pv[e]);
-          } else if (ea.act != ACT_NONE) {
+            for (int e = 0; e < 8; ++e) x[e] *= EPI_ACT_GRAD(act, pv[e]);
+          } else if (act != ACT_NONE) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = act_f<FASTACT>(ea.act, x[e]);
+            for (int e = 0; e < 8; ++e) x[e] = EPI_ACT(act, x[e]);
           }
           if (drop) {
             float dsc[8];
@@ -399,11 +423,11 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] *= dsc[e];
           }
-          if (Rb) {
+          if (has_res) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] += rv[e];
           }
-          if (ea.beta != 0.f) {
+          if (has_beta) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = fmaf(ea.beta, ov[e], x[e]);
           }
@@ -415,10 +439,14 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
   }
 }
 
-template <typename T>
+template <typename T, int FEAT = -1>
 __device__ __forceinline__ void run_epilogue(const EpiArgs& ea, float* stage, const f32x16& acc00, const f32x16& acc01,
                                              const f32x16& acc10, const f32x16& acc11, const int mbase, const int nbase,
                                              const int lane) {
+  if constexpr (FEAT >= 0) {     // (the launcher only picks a feature-specialised kernel for the fast layout with T outputs)
+    epilogue_fast<T, T, FEAT>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
+    return;
+  }
   if (ea.fast) {
     if (ea.out_f32) epilogue_fast<T, float>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
     else epilogue_fast<T, T>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
@@ -722,7 +750,7 @@ __device__ unsigned long long g_gemm_timing[8];
 #define GPROBE(i)
 #endif
 
-template <typename T, int NBUF>
+template <typename T, int NBUF, int FEAT = -1>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
   ST5_PAD_TO_256_VGPRS();
 #ifdef GEMM_TIMING
@@ -843,7 +871,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
   asm volatile("" :: "v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11));
   if (ea.alpha == 123.f)
 #endif
-  run_epilogue<T>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
+  run_epilogue<T, FEAT>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
 #ifdef GEMM_TIMING
   GPROBE(4);
   if (lane == 0) { for (int i = 0; i < 5; ++i) atomicAdd(&g_gemm_timing[i], (unsigned long long)tacc[i]); atomicAdd(&g_gemm_timing[7], 1ull); }
@@ -1082,29 +1110,71 @@ namespace {
 // the deep ring off (st5_gemm_set_deep_ring(0, 2)).
 int g_deep_blocks = 256, g_deep_nbuf = 4;
 
-template <typename T>
-int launch_glds(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  dim3 grid(tiles, 1, p.batch), block(NTHREADS);
-  static bool attr = false;
+// The feature mask of a launch when one of the specialised instantiations covers it exactly, else -1 (run-time form).
+// The hot combinations of the training step (transformer_layer.py / multihead_attention.py call sites through functional.py):
+//   0                plain / bias          (QKV and cross-attention projections, plain data gradients)
+//   F_GELU | F_PRE   fc1 forward           (bias, GELU, pre-activation kept for the backward)
+//   F_DROP | F_RES   fc2 / output projection forward (bias, dropout, residual)
+//   F_DACT           data gradient through the GELU (x act'(pre))
+//   F_BETA           accumulating data gradient (dX += ...)
+int nt_feat_of(const st5_gemm_params& p, int c_vec_ok) {
+  if (!c_vec_ok || p.N % 8 != 0 || (p.flags & ST5_GEMM_OUT_F32)) return -1;
+  const bool dact = (p.flags & ST5_GEMM_DACT) != 0;
+  if (p.act != ACT_NONE && p.act != ACT_GELU) return -1;
+  if (dact && p.act != ACT_GELU) return -1;
+  int f = 0;
+  if (dact) f |= F_DACT;
+  else if (p.act == ACT_GELU) f |= F_GELU;
+  if (p.dropout_p > 0.f) f |= F_DROP;
+  if (p.R.ptr) f |= F_RES;
+  if (p.Cpre.ptr) f |= F_PRE;
+  if (p.beta != 0.f) f |= F_BETA;
+  switch (f) {
+    case 0: case F_GELU | F_PRE: case F_DROP | F_RES: case F_DACT: case F_BETA: return f;
+    default: return -1;
+  }
+}
+
+template <typename T, int NBUF, int FEAT>
+int launch_glds_as(const st5_gemm_params& p, int c_vec_ok, dim3 grid, hipStream_t s) {
+  static bool attr = false;      // (one flag per instantiation)
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<T, NBUF, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return ST5_ERR_LAUNCH;
     attr = true;
   }
-  const int nk = p.K / (128 / (int)sizeof(T));
-  const bool deep = sizeof(T) == 2 && (long long)tiles * p.batch <= g_deep_blocks && nk >= 4 && g_deep_nbuf > 2;
-  if (deep && g_deep_nbuf == 4)
-    hipLaunchKernelGGL((gemm_nt_glds_kernel<T, 4>), grid, block, (size_t)4 * 2 * TILE_BYTES, s, p, c_vec_ok);
-  else if (deep)
-    hipLaunchKernelGGL((gemm_nt_glds_kernel<T, 3>), grid, block, (size_t)3 * 2 * TILE_BYTES, s, p, c_vec_ok);
-  else
-    hipLaunchKernelGGL((gemm_nt_glds_kernel<T, 2>), grid, block, (size_t)2 * 2 * TILE_BYTES, s, p, c_vec_ok);
+  hipLaunchKernelGGL((gemm_nt_glds_kernel<T, NBUF, FEAT>), grid, dim3(NTHREADS), (size_t)NBUF * 2 * TILE_BYTES, s, p, c_vec_ok);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
+}
+
+template <typename T, int NBUF>
+int launch_glds_feat(const st5_gemm_params& p, int c_vec_ok, dim3 grid, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {      // (bf16: the training step; the fp32 parity mode keeps the one run-time form)
+    static const bool rt_only = getenv("ST5_GEMM_RT_EPILOGUE") && getenv("ST5_GEMM_RT_EPILOGUE")[0] == '1';   // A/B switch
+    switch (rt_only ? -1 : nt_feat_of(p, c_vec_ok)) {
+      case 0: return launch_glds_as<T, NBUF, 0>(p, c_vec_ok, grid, s);
+      case F_GELU | F_PRE: return launch_glds_as<T, NBUF, F_GELU | F_PRE>(p, c_vec_ok, grid, s);
+      case F_DROP | F_RES: return launch_glds_as<T, NBUF, F_DROP | F_RES>(p, c_vec_ok, grid, s);
+      case F_DACT: return launch_glds_as<T, NBUF, F_DACT>(p, c_vec_ok, grid, s);
+      case F_BETA: return launch_glds_as<T, NBUF, F_BETA>(p, c_vec_ok, grid, s);
+      default: break;
+    }
+  }
+  return launch_glds_as<T, NBUF, -1>(p, c_vec_ok, grid, s);
+}
+
+template <typename T>
+int launch_glds(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  dim3 grid(tiles, 1, p.batch);
+  const int nk = p.K / (128 / (int)sizeof(T));
+  const bool deep = sizeof(T) == 2 && (long long)tiles * p.batch <= g_deep_blocks && nk >= 4 && g_deep_nbuf > 2;
+  if constexpr (sizeof(T) == 2) {
+    if (deep && g_deep_nbuf == 4) return launch_glds_feat<T, 4>(p, c_vec_ok, grid, s);
+    if (deep) return launch_glds_feat<T, 3>(p, c_vec_ok, grid, s);
+  }
+  return launch_glds_feat<T, 2>(p, c_vec_ok, grid, s);
 }
 
 bool g_use_glds = true;
