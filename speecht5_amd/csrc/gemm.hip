@@ -439,12 +439,12 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
   }
 }
 
-template <typename T, int FEAT = -1>
+template <typename T, int FEAT = -1, typename OUT = T>
 __device__ __forceinline__ void run_epilogue(const EpiArgs& ea, float* stage, const f32x16& acc00, const f32x16& acc01,
                                              const f32x16& acc10, const f32x16& acc11, const int mbase, const int nbase,
                                              const int lane) {
-  if constexpr (FEAT >= 0) {     // (the launcher only picks a feature-specialised kernel for the fast layout with T outputs)
-    epilogue_fast<T, T, FEAT>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
+  if constexpr (FEAT >= 0) {     // (the launcher only picks a feature-specialised kernel for the fast layout with OUT outputs)
+    epilogue_fast<T, OUT, FEAT>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
     return;
   }
   if (ea.fast) {
@@ -1204,6 +1204,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile_row, int off0, int of
   return u.v;
 }
 
+template <int FEAT>   // (epilogue features, see epilogue_fast; >= 0: fp32 output in the fast layout, compile-time feature set)
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
   ST5_PAD_TO_256_VGPRS();
   typedef bf16_t T;
@@ -1359,13 +1360,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
     if (ea.Cpre) ea.Cpre = reinterpret_cast<T*>(ea.Cpre) + z_off(p.Cpre.zs0, p.Cpre.zs1, z, p.zdiv);
   }
   float* stage = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
-  run_epilogue<T>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
+  run_epilogue<T, FEAT, float>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 int launch_tn_glds(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, nsplit, p.batch), block(NTHREADS);
-  hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, block, (size_t)4 * TILE_BYTES, s, p, c_vec_ok);
+  // weight gradients: fp32 output, plain store (split-K slabs / first contribution) or accumulate -- own instantiations
+  static const bool rt_only = getenv("ST5_GEMM_RT_EPILOGUE") && getenv("ST5_GEMM_RT_EPILOGUE")[0] == '1';   // A/B switch
+  const bool plain = !rt_only && c_vec_ok && p.N % 8 == 0 && (p.flags & ST5_GEMM_OUT_F32) && !(p.flags & ST5_GEMM_DACT) && p.act == ACT_NONE &&
+                     p.dropout_p == 0.f && !p.R.ptr && !p.Cpre.ptr;
+  if (plain && p.beta == 0.f) hipLaunchKernelGGL(gemm_tn_glds_kernel<0>, grid, block, (size_t)4 * TILE_BYTES, s, p, c_vec_ok);
+  else if (plain) hipLaunchKernelGGL(gemm_tn_glds_kernel<F_BETA>, grid, block, (size_t)4 * TILE_BYTES, s, p, c_vec_ok);
+  else hipLaunchKernelGGL(gemm_tn_glds_kernel<-1>, grid, block, (size_t)4 * TILE_BYTES, s, p, c_vec_ok);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
