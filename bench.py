@@ -281,10 +281,11 @@ def main():
         import hashlib
         cur = hashlib.sha1(open(os.path.join(here, "speecht5_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:12]
         if pm.get("gemm_hip_sha1") == cur and a.dtype == "bf16":
-            cand = [v for kname, v in pm["kernels"].items() if NT_KERNEL_NAME in kname]
+            # every bf16 instantiation of the kernel (one per epilogue feature set), weighted by launches; the fp32 one serves the
+            # NCE head only
+            cand = [v for kname, v in pm["kernels"].items() if NT_KERNEL_NAME in kname and "IfLi" not in kname and "<float" not in kname]
             if cand:
-                v = max(cand, key=lambda v: v["launches"])   # (the bf16 instantiation; the fp32 one serves the NCE head)
-                traffic = v["hbm_corrected_bytes_per_launch"]
+                traffic = int(sum(v["hbm_corrected_bytes_per_launch"] * v["launches"] for v in cand) / sum(v["launches"] for v in cand))
                 traffic_src = f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes/launch; gemm.hip {cur})"
     except Exception:
         traffic = None

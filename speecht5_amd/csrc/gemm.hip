@@ -329,13 +329,6 @@ __device__ __forceinline__ void epilogue_rows(const EpiArgs& ea, const float* st
 // aligned, N % 8 == 0 so a lane's 8 columns are all valid or all out of range).  Both 32-row halves are staged through the
 // wave-private LDS slab; the per-lane constants (bias, column offsets) are loaded once, the uniform feature tests are
 // per 8-vector, and the four row passes of a half are unrolled so their LDS reads / global loads overlap.
-#ifdef ST5_EPI_SLIM   // (experiment: how much of the epilogue's cost is code size? GELU / ReLU only in the fast epilogue)
-#define EPI_ACT(act, x) ((act) == ACT_GELU ? gelu_fast<false>(x) : (act) == ACT_RELU ? fmaxf((x), 0.f) : (x))
-#define EPI_ACT_GRAD(act, x) ((act) == ACT_GELU ? gelu_fast<true>(x) : (act) == ACT_RELU ? ((x) > 0.f ? 1.f : 0.f) : 1.f)
-#else
-#define EPI_ACT(act, x) act_f<FASTACT>((act), (x))
-#define EPI_ACT_GRAD(act, x) act_grad_f<FASTACT>((act), (x))
-#endif
 // FEAT < 0: every epilogue feature is tested at run time (uniform branches; ALL of the code is in the kernel).  FEAT >= 0: a bit
 // mask of the features this instantiation has, everything else is compiled out.  Why: the run-time form of the 128^2 NT kernel is
 // 18.6 k instructions (~130 KB against a 64 KB instruction cache shared by two CUs); a tile's epilogue walks through all of it
@@ -412,10 +405,10 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
           if (has_pre) store8f<T>(Qb + q * ea.q_bs + rm * ea.q_ld, x);
           if (dact) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] *= EPI_ACT_GRAD(act, pv[e]);
+            for (int e = 0; e < 8; ++e) x[e] *= act_grad_f<FASTACT>(act, pv[e]);
           } else if (act != ACT_NONE) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = EPI_ACT(act, x[e]);
+            for (int e = 0; e < 8; ++e) x[e] = act_f<FASTACT>(act, x[e]);
           }
           if (drop) {
             float dsc[8];

@@ -1,6 +1,6 @@
 # HBM traffic of the bench step per kernel: two SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; no trace domains beside
 # them) over `python bench.py --steps 3 --warmup 3 --no-cpu-baseline`, summarised into gpurun_out/pmc/$1_pmc_traffic.json
-# (copy it to profiles/: bench.py reads profiles/r2_pmc_traffic.json and only trusts it when its gemm.hip hash matches).
+# (copy it to profiles/: bench.py reads profiles/r3_pmc_traffic.json and only trusts it when its gemm.hip hash matches).
 TAG=${1:-r2}
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
@@ -22,7 +22,7 @@ for d, name in (("/tmp/pmc_f", "FETCH_SIZE"), ("/tmp/pmc_w", "WRITE_SIZE")):
         acc[k][name] += float(row["Counter_Value"])
 kern = {}
 for k, v in acc.items():
-    if not any(t in k for t in ("gemm", "fa2::", "conv0", "ln_", "adam")) or not v["launches"]:
+    if not any(t in k for t in ("gemm", "fa2::", "conv0", "ln_", "adam", "conv1d_narrow")) or not v["launches"]:
         continue
     n = v["launches"]
     f_kb, w_kb = v["FETCH_SIZE"] / n, v["WRITE_SIZE"] / n
