@@ -35,6 +35,7 @@ struct NarrowArgs {
 
 template <int CB, int NJ>     // CB: output-channel blocks of 32; NJ: Cin / 16
 __global__ __launch_bounds__(NTHR) void conv1d_narrow_kernel(const NarrowArgs a) {
+  constexpr int TBv = CB == 2 ? 2 : TB;                    // time blocks per wave (64 channels: 2, so that the NEXT tap's fragments fit)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* const wl = reinterpret_cast<bf16_t*>(smem);      // [CB * 32][Kp]
   const int Kp = a.K + 8;                                  // (+16 bytes per row: fragment reads of 32 rows spread over the banks)
@@ -54,43 +55,78 @@ __global__ __launch_bounds__(NTHR) void conv1d_narrow_kernel(const NarrowArgs a)
   const bf16_t* const xb = a.x + (long long)b * a.x_bs + 8 * h;
   const bf16_t* const wrow = wl + tl * Kp + 8 * h;
   for (int tile = tile0; tile < tile1; ++tile) {
-    const int t0 = tile * TILE_T + wave * (TB * 32);
+    const int t0 = tile * (NW * TBv * 32) + wave * (TBv * 32);
     if (t0 >= a.L) break;                                  // (wave-uniform; no barrier inside the loop)
-    f32x16 acc[CB][TB];
+    f32x16 acc[CB][TBv];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-      for (int tb = 0; tb < TB; ++tb)
+      for (int tb = 0; tb < TBv; ++tb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[cb][tb][e] = 0.f;
-    const bf16_t* xr[TB];
+    const bf16_t* xr[TBv];
 #pragma unroll
-    for (int tb = 0; tb < TB; ++tb) xr[tb] = xb + (long long)min(t0 + 32 * tb + tl, a.L - 1) * a.x_ts;   // (rows past L: clamped, never stored)
-#pragma unroll 1
-    for (int tau = 0; tau < a.taps; ++tau) {
-      const int xo = tau * a.tap_stride, wo = tau * a.Cin;
-      bf16x8 bf[NJ][TB];
+    for (int tb = 0; tb < TBv; ++tb) xr[tb] = xb + (long long)min(t0 + 32 * tb + tl, a.L - 1) * a.x_ts;   // (rows past L: clamped, never stored)
+    // the fragments of tap tau + 1 are requested before the MFMAs of tap tau: one memory latency per tile instead of one per tap
+    constexpr bool PF = NJ * TBv <= 8;                      // (16 fragments in flight twice over do not fit beside the accumulators)
+    bf16x8 cur[NJ][TBv], nxt[PF ? NJ : 1][PF ? TBv : 1];
+    if (PF) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int tb = 0; tb < TB; ++tb) bf[j][tb] = *reinterpret_cast<const bf16x8*>(xr[tb] + xo + 16 * j);
+        for (int tb = 0; tb < TBv; ++tb) cur[j][tb] = *reinterpret_cast<const bf16x8*>(xr[tb] + 16 * j);
+    }
+#pragma unroll 1
+    for (int tau = 0; tau < a.taps; ++tau) {
+      const int wo = tau * a.Cin;
+      const int xo = (PF ? min(tau + 1, a.taps - 1) : tau) * a.tap_stride;      // (PF, last tap: reloads itself, unused)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int tb = 0; tb < TBv; ++tb) {
+          if (PF) nxt[j][tb] = *reinterpret_cast<const bf16x8*>(xr[tb] + xo + 16 * j);
+          else cur[j][tb] = *reinterpret_cast<const bf16x8*>(xr[tb] + xo + 16 * j);
+        }
+      __builtin_amdgcn_sched_barrier(0);     // (left alone the scheduler sinks these loads to just before their first use: no distance)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
           const bf16x8 af = *reinterpret_cast<const bf16x8*>(wrow + cb * 32 * Kp + wo + 16 * j);
 #pragma unroll
-          for (int tb = 0; tb < TB; ++tb) acc[cb][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j][tb], acc[cb][tb], 0, 0, 0);
+          for (int tb = 0; tb < TBv; ++tb) acc[cb][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, cur[j][tb], acc[cb][tb], 0, 0, 0);
         }
       }
-    }
-    // epilogue: register r of a lane = output channel 8 (r >> 2) + 4 half + (r & 3) of time step t0 + 32 tb + (lane & 31)
+      __builtin_amdgcn_sched_barrier(0);
+      if (PF) {
 #pragma unroll
-    for (int tb = 0; tb < TB; ++tb) {
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int tb = 0; tb < TBv; ++tb) cur[j][tb] = nxt[j][tb];
+      }
+    }
+    // epilogue: register r of a lane = output channel 8 (r >> 2) + 4 half + (r & 3) of time step t0 + 32 tb + (lane & 31).
+    // Residual and old-output values of the WHOLE wave tile are requested first (one memory latency, not one per 8-byte piece).
+    const bool has_r = a.R != nullptr, has_o = a.beta != 0.f;
+    bf16x4 r4[TBv][CB][4], o4[TBv][CB][4];
+#pragma unroll
+    for (int tb = 0; tb < TBv; ++tb) {
+      const int t = min(t0 + 32 * tb + tl, a.L - 1);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = cb * 32 + 8 * g + 4 * h;
+          if (has_r) r4[tb][cb][g] = *reinterpret_cast<const bf16x4*>(a.R + (long long)b * a.r_bs + (long long)t * a.r_ts + c0);
+          if (has_o) o4[tb][cb][g] = *reinterpret_cast<const bf16x4*>(a.y + (long long)b * a.y_bs + (long long)t * a.y_ts + c0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tb = 0; tb < TBv; ++tb) {
       const int t = t0 + 32 * tb + tl;
       if (t >= a.L) continue;
       bf16_t* const yr = a.y + (long long)b * a.y_bs + (long long)t * a.y_ts;
-      const bf16_t* const rr = a.R ? a.R + (long long)b * a.r_bs + (long long)t * a.r_ts : nullptr;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
@@ -103,15 +139,13 @@ __global__ __launch_bounds__(NTHR) void conv1d_narrow_kernel(const NarrowArgs a)
             if (a.bias) x += a.bias[c0 + e];
             v[e] = x > 0.f ? x : x * a.slope;      // (the generic act_f() switch, inlined 64 times, made this kernel I-cache bound)
           }
-          if (rr) {
-            const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rr + c0);
+          if (has_r) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+            for (int e = 0; e < 4; ++e) v[e] += (float)r4[tb][cb][g][e];
           }
-          if (a.beta != 0.f) {
-            const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(yr + c0);
+          if (has_o) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += a.beta * (float)o4[e];
+            for (int e = 0; e < 4; ++e) v[e] += a.beta * (float)o4[tb][cb][g][e];
           }
           bf16x4 o;
 #pragma unroll
@@ -154,21 +188,41 @@ __global__ __launch_bounds__(NTHR) void conv1d_narrow32_kernel(const NarrowArgs 
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = a.bias ? a.bias[ec + e] : 0.f;
-  for (int it = 0; it < a.tiles_per_block; ++it) {         // (block-uniform trip count: barriers inside)
+  __syncthreads();                                         // weights visible; the ONLY block barrier: everything below is wave-private
+  // The staged input and the accumulator staging live in a region only this wave touches, and a wave's LDS operations complete
+  // in issue order: WAVE_LDS_FENCE (wait for this wave's outstanding LDS ops, compiler barrier) is all the ordering the
+  // write -> read hand-overs inside a wave need.  Without block barriers the waves of a block drift apart, so one wave's global
+  // loads overlap another's MFMAs and stores (with __syncthreads() the whole CU alternated between loading and computing).
+#define WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+  for (int it = 0; it < a.tiles_per_block; ++it) {
     const int t0 = (tile0 + it) * TILE_T + wave * (TB * 32);
-    __syncthreads();                                       // weights visible (first trip); previous trip's staging reads done
+    if (t0 >= a.L) break;                                  // (wave-uniform)
+    WAVE_LDS_FENCE();                                      // previous trip's staged reads done
     // ---- stage rows [t0, t0 + rows_w) of the padded input, clamped to the buffer ----
     {
       constexpr int CV = CIN / 8;                          // 16-byte chunks per row
-      const int nch = rows_w * CV;
-      for (int i = lane; i < nch; i += 64) {
-        const int r = i / CV, c = i - r * CV;
-        const int gr = min(t0 + r, rows_in - 1);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (long long)max(gr, 0) * CIN + c * 8);
-        *reinterpret_cast<u32x4*>(xs + r * ROWB + c * 16) = v;
+      constexpr int U = 6;                                 // loads in flight per lane: U loads issued, then U LDS writes (a load ->
+      const int nch = rows_w * CV;                         // write -> load chain paid one memory latency per 64 chunks: 11 per tile)
+      for (int base = lane; base < nch; base += 64 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = min(base + 64 * u, nch - 1);       // (clamped: a duplicate load, not written below)
+          const int r = i / CV, c = i - r * CV;
+          const int gr = min(t0 + r, rows_in - 1);
+          v[u] = *reinterpret_cast<const u32x4*>(xb + (long long)gr * CIN + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = base + 64 * u;
+          if (i < nch) {
+            const int r = i / CV, c = i - r * CV;
+            *reinterpret_cast<u32x4*>(xs + r * ROWB + c * 16) = v[u];
+          }
+        }
       }
     }
-    __syncthreads();
+    WAVE_LDS_FENCE();
     f32x16 acc[TB];
 #pragma unroll
     for (int tb = 0; tb < TB; ++tb)
@@ -191,9 +245,21 @@ __global__ __launch_bounds__(NTHR) void conv1d_narrow32_kernel(const NarrowArgs 
     }
     // ---- epilogue through the wave's LDS region (now free): [32 t][SLD] floats per time block ----
     float* const st = reinterpret_cast<float*>(xs);
+    // residual / old output of the whole wave tile requested up front: their latency hides behind the LDS round trips below
+    const bool has_r = a.R != nullptr, has_o = a.beta != 0.f;
+    u32x4 rraw[TB][2], oraw[TB][2];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = min(t0 + 32 * tb + (lane >> 2) + 16 * half, a.L - 1);
+        if (has_r) rraw[tb][half] = *reinterpret_cast<const u32x4*>(a.R + (long long)b * a.r_bs + (long long)t * a.r_ts + ec);
+        if (has_o) oraw[tb][half] = *reinterpret_cast<const u32x4*>(a.y + (long long)b * a.y_bs + (long long)t * a.y_ts + ec);
+      }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tb = 0; tb < TB; ++tb) {             // (fully unrolled: a dynamic index into acc[] would live in scratch)
-      __syncthreads();                                     // fragment reads (first trip) / previous block's staged reads done
+      WAVE_LDS_FENCE();                                    // fragment reads (first trip) / previous block's staged reads done
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 v;
@@ -201,12 +267,12 @@ __global__ __launch_bounds__(NTHR) void conv1d_narrow32_kernel(const NarrowArgs 
         for (int e = 0; e < 4; ++e) v[e] = acc[tb][4 * g + e];
         *reinterpret_cast<f32x4*>(st + tl * SLD + 8 * g + 4 * h) = v;
       }
-      __syncthreads();
+      WAVE_LDS_FENCE();
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int tt = (lane >> 2) + 16 * half;
         const int t = t0 + 32 * tb + tt;
-        if (t >= a.L || t0 >= a.L) continue;
+        if (t >= a.L) continue;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(st + tt * SLD + ec);
         const f32x4 s1 = *reinterpret_cast<const f32x4*>(st + tt * SLD + ec + 4);
         float v[8];
@@ -218,23 +284,27 @@ __global__ __launch_bounds__(NTHR) void conv1d_narrow32_kernel(const NarrowArgs 
           v[e] = x > 0.f ? x : x * a.slope;
         }
         bf16_t* const yp = a.y + (long long)b * a.y_bs + (long long)t * a.y_ts + ec;
-        if (a.R) {
-          float r8[8];
-          load8f<bf16_t>(a.R + (long long)b * a.r_bs + (long long)t * a.r_ts + ec, r8);
+        if (has_r) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += r8[e];
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] += __uint_as_float(rraw[tb][half][e] << 16);
+            v[2 * e + 1] += __uint_as_float(rraw[tb][half][e] & 0xffff0000u);
+          }
         }
-        if (a.beta != 0.f) {
-          float o8[8];
-          load8f<bf16_t>(yp, o8);
+        if (has_o) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += a.beta * o8[e];
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] += a.beta * __uint_as_float(oraw[tb][half][e] << 16);
+            v[2 * e + 1] += a.beta * __uint_as_float(oraw[tb][half][e] & 0xffff0000u);
+          }
         }
         store8f<bf16_t>(yp, v);
       }
     }
   }
 }
+
+#undef WAVE_LDS_FENCE
 
 // One output channel (the generator's conv_post: 32 -> 1, k = 7, tanh): a dot product of taps * Cin values per time step.
 __global__ __launch_bounds__(256) void conv1d_cout1_kernel(const bf16_t* __restrict__ x, long long x_bs, int x_ts, const bf16_t* __restrict__ w,
@@ -313,7 +383,10 @@ extern "C" int st5_conv1d_narrow(const void* x, int64_t x_bs, int32_t x_ts, cons
   a.x = (const bf16_t*)x; a.x_bs = x_bs; a.x_ts = x_ts; a.w = (const bf16_t*)w; a.bias = bias;
   a.y = (bf16_t*)y; a.y_bs = y_bs; a.y_ts = y_ts; a.R = (const bf16_t*)residual; a.r_bs = r_bs; a.r_ts = r_ts;
   a.B = B; a.L = L; a.Cin = Cin; a.taps = taps; a.tap_stride = tap_stride; a.K = taps * Cin;
-  a.tiles_per_batch = (L + TILE_T - 1) / TILE_T;
+  // (time steps per block tile: 8 waves x 128, or x 64 in the first form's 64-channel instantiations; a launch that falls back from
+  //  the staged 32-channel form recomputes nothing: both 32-channel forms use 1024)
+  const int tile_t = Cout == 64 ? NW * 2 * 32 : TILE_T;
+  a.tiles_per_batch = (L + tile_t - 1) / tile_t;
   // the weight image is loaded once per block: several tiles per block when there are enough tiles to keep > 4 blocks per CU
   a.tiles_per_block = 1;
   while (a.tiles_per_block < 8 && (long long)B * (a.tiles_per_batch / (a.tiles_per_block * 2)) >= 1024) a.tiles_per_block *= 2;
