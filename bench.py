@@ -86,7 +86,10 @@ def cpu_baseline(model, args, seconds=4.0, runs=5):
     t = ts[len(ts) // 2]
     return {"value": round(seconds / t, 4), "unit": "audio-sec/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 x {seconds:g} s clip, speech_pretrain fwd+bwd (fp32 CPU oracle): median of {runs} runs after 2 warm-ups, "
-                      f"{t:.2f} s per run (min {ts[0]:.2f}, max {ts[-1]:.2f})"}
+                      f"{t:.2f} s per run (min {ts[0]:.2f}, max {ts[-1]:.2f})",
+            # the reference itself cannot travel to this box; timed once beside the port where it exists (oracle/time_reference_cpu.py)
+            "reference_vs_port": "verbatim reference stack 1.90 s vs this port 3.61 s per run of the same clip on the same 8 cores "
+                                 "(profiles/r3_cpu_reference_vs_port.json): the reference's own CPU path is ~1.9x faster than `value`"}
 
 
 def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, graph=True, micro="in_turn", layerdrop=0.05,
