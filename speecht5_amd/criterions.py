@@ -196,12 +196,12 @@ class SpeechPretrainCriterion(nn.Module):
         with alignment_weights(model, getattr(self.speech_criterion, "use_guided_attn_loss", False)):
             net_output, net_output_dec = model(target_list=sample["target_list"], **sample["net_input"])
         loss, sample_size, log = 0.0, 0, {}
-        reduction = "sum" if reduce else "none"
+        _summed_only(reduce)
         logp_m_list = model.get_logits(net_output, True)
         targ_m_list = model.get_targets(None, net_output, True)
         loss_m_list = []
         for i, (lm, tm) in enumerate(zip(logp_m_list, targ_m_list)):
-            l = Fn.cross_entropy_sum(lm, tm)[0] if reduce else F.cross_entropy(lm, tm, reduction=reduction)
+            l = Fn.cross_entropy_sum(lm, tm)[0]
             loss_m_list.append(l)
             log[f"loss_m_{i}"] = _item(l, s)
         if self.pred_masked_weight > 0:
@@ -211,7 +211,7 @@ class SpeechPretrainCriterion(nn.Module):
         targ_u_list = model.get_targets(None, net_output, False)
         loss_u_list = []
         for i, (lu, tu) in enumerate(zip(logp_u_list, targ_u_list)):
-            l = Fn.cross_entropy_sum(lu, tu)[0] if reduce else F.cross_entropy(lu, tu, reduction=reduction)
+            l = Fn.cross_entropy_sum(lu, tu)[0]
             loss_u_list.append(l)
             log[f"loss_u_{i}"] = _item(l, s)
         if self.pred_nomask_weight > 0:
@@ -257,13 +257,10 @@ class TextPretrainCriterion(nn.Module):
         s = self.sync_logging
         with alignment_weights(model, False):
             net_output, codebook_out, encoder_output = model(**sample["net_input"])
-        if reduce:   # fused log-softmax + NLL + logit gradient on the decoder logits (one kernel)
-            logits = net_output[0]
-            bart_loss = Fn.cross_entropy_sum(logits.reshape(-1, logits.size(-1)), sample["target"].view(-1), 0.0, self.padding_idx)[0]
-        else:
-            lprobs = model.get_normalized_probs(net_output, log_probs=True)
-            bart_loss = F.nll_loss(lprobs.view(-1, lprobs.size(-1)), sample["target"].view(-1), ignore_index=self.padding_idx,
-                                   reduction="sum" if reduce else "none")
+        _summed_only(reduce)
+        # fused log-softmax + NLL + logit gradient on the decoder logits (one kernel)
+        logits = net_output[0]
+        bart_loss = Fn.cross_entropy_sum(logits.reshape(-1, logits.size(-1)), sample["target"].view(-1), 0.0, self.padding_idx)[0]
         sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
         loss = self.bart_weight * bart_loss
         log = {"loss": _item(loss, s), "ntokens": sample["ntokens"], "nsentences": sample["target"].size(0),
@@ -356,11 +353,20 @@ class SpeechtoTextLoss(nn.Module):
         targets_flat = sample["target"].masked_select(pad_mask)
         target_lengths = sample["target_lengths"] if "target_lengths" in sample else pad_mask.sum(-1)
         target_lengths = target_lengths - 1
-        if lprobs.is_cuda and lprobs.dtype == torch.float32:   # alpha / beta recursions as two kernels (csrc/ctc_loss.hip)
-            return Fn.ctc_loss_sum(lprobs, targets_flat, input_lengths, target_lengths, self.blank_idx, self.zero_infinity,
-                                   max_target_len=sample["target"].size(1))
-        return F.ctc_loss(lprobs, targets_flat, input_lengths, target_lengths, blank=self.blank_idx, reduction="sum",
-                          zero_infinity=self.zero_infinity)
+        # alpha / beta recursions as two kernels (csrc/ctc_loss.hip); no torch fallback: log-probabilities that are not fp32 on the
+        # GPU mean the model did not run on the HIP path, and that must not pass silently
+        if not (lprobs.is_cuda and lprobs.dtype == torch.float32):
+            raise RuntimeError(f"CTC loss: expected fp32 log-probabilities on the GPU (csrc/ctc_loss.hip), got {lprobs.dtype} on {lprobs.device}")
+        return Fn.ctc_loss_sum(lprobs, targets_flat, input_lengths, target_lengths, self.blank_idx, self.zero_infinity,
+                               max_target_len=sample["target"].size(1))
+
+
+def _summed_only(reduce):
+    """The criteria compute SUMMED losses on the HIP kernels (what fairseq's trainer asks for: `reduce=True` in every
+    `train_step` / `valid_step`, tasks/speecht5.py:519-579).  Per-element losses would have to come from torch ops -- a silent
+    fallback the product path does not have."""
+    if not reduce:
+        raise NotImplementedError("reduce=False (per-element losses) is not on the HIP path; the trainer never asks for it")
 
 
 @register_criterion("speecht5")
