@@ -1,7 +1,6 @@
 """One optimizer update of the pre-training recipe (`--update-freq 2`: a speech micro-batch and a text micro-batch, SURVEY.md
-3.1-3.2) the way bench.py times it: forward + backward of both micro-batches (side by side on two streams, two gradient
-buffers), the gradient exchange over the ranks, global-norm clip and the fused Adam step -- enqueued eagerly or replayed as a
-HIP graph.  bench.py and tests/test_bench_update_gpu.py build their step from THIS class, so the thing that is timed is the
+3.1-3.2) the way bench.py times it: forward + backward of both micro-batches (in turn on one stream by default), the gradient
+exchange over the ranks, global-norm clip and the fused Adam step -- enqueued eagerly or replayed as a HIP graph.  bench.py and tests/test_bench_update_gpu.py build their step from THIS class, so the thing that is timed is the
 thing whose results are checked.
 
 Modes (what the reference's trainer does in turn -- tasks/speecht5.py:519-556 called once per micro-batch by fairseq's
@@ -15,8 +14,9 @@ arithmetic):
                              reproducible on this hardware: kernels of the two streams that share a CU perturb each other
                               -- kept as a measurement mode
   graph      True: the update (one rank) or its local phase (several ranks) is captured once and replayed
-  several ranks, graph: the captured part is the LOCAL phase (zero_grad, both micro-batches, buffer sum); the gradient
-             all-reduce and the Adam step follow every replay eagerly (ddp.local_phase / all_reduce_gradients)
+  several ranks, graph: the captured part is the LOCAL phase (zero_grad, both micro-batches); exchange = "phased" (default) cuts
+             it into three graphs and all-reduces each completed bucket range under the next one, "one_message" keeps one
+             graph and one all-reduce of the whole buffer behind it; Adam follows eagerly
 """
 import os
 
@@ -36,7 +36,6 @@ class PretrainUpdate:
         self.use_graph = graph
         self.device = device if device is not None else next(model.parameters()).device
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        overlapped = micro != "in_turn"
         # every form of cross-stream kernel concurrency is OFF by default: the micro-batches in turn, no
         # weight-gradient stream, no attention helper stream -- one stream, results reproducible bit for bit, replay == eager
         if wgrad_stream is None:
