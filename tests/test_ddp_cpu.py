@@ -282,3 +282,34 @@ def test_tensor_shared_by_a_cut_stack_keeps_its_summation_order():
         assert ref["table"].abs().max() > 0
     finally:
         ddp.close()
+
+
+def test_shared_tensor_when_no_cut_materialises_or_the_cut_is_the_first_layer():
+    """Edge cases of the shared-tensor bookkeeping: (a) the requested cut sits where nothing requires a gradient yet (the stack's
+    input): no cut is made, one region, and the producer's backward still runs (once) inside the only phase; (b) a cut directly behind
+    the first layer: the producer's region holds a single consumer.  Both must give the uncut backward's bits."""
+    from speecht5_amd.ddp import BucketGroup, FlatGradDataParallel
+    torch.manual_seed(4)
+    model = _SharedKeyStack()
+    ddp = FlatGradDataParallel(model, bucket_groups=[BucketGroup([model.head], triggers=[(model, "out")])] +
+                               [BucketGroup([l]) for l in reversed(list(model.layers))])
+    try:
+        x = torch.randn(32, 16)
+        ddp.zero_grad()
+        model(x).backward()
+        ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+        mb = ddp.module_bucket
+        for cut_layers, n_real in (([0], 0), ([1], 1), ([1, 5], 2)):
+            ddp.zero_grad()
+            with ddp.local_phase():
+                with ddp.cut_points([mb[(id(model.layers[i]), None)] for i in cut_layers]) as cuts:
+                    loss = model(x)
+                assert sum(1 for c in cuts if c[0] != "shared") == n_real, (cut_layers, cuts)
+                phases = ddp.backward_phases(loss, cuts)
+                assert len(phases) == n_real + 1
+                for fn, _ in phases:
+                    fn()
+            for n, p in model.named_parameters():
+                assert torch.equal(p.grad, ref[n]), (cut_layers, n, float((p.grad - ref[n]).abs().max()))
+    finally:
+        ddp.close()
