@@ -597,6 +597,7 @@ class FusedAdam:
     def __init__(self, ddp: FlatGradDataParallel, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0):
         self.ddp = ddp
         self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip_norm
+        self.lr_step = None    # graph.StepGraph: this step's learning rate when self.lr already belongs to the next one
         total = ddp.flat.numel()
         dev = ddp.flat.device
         self.pflat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -630,13 +631,18 @@ class FusedAdam:
         self.hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self.hyper_host2 = None
 
-    def push_hyper(self, slot=0):
-        """Host -> device copy of (lr, next step count); call before the step that will read it.  `slot` picks one of two
-        pinned images (the copy is asynchronous: a caller that runs ahead of the GPU alternates them, graph.StepGraph)."""
-        if slot and self.hyper_host2 is None:
+    def ensure_second_hyper_image(self):
+        if self.hyper_host2 is None:
             self.hyper_host2 = torch.zeros(2, dtype=torch.float32).pin_memory()
+
+    def push_hyper(self, slot=0, lr=None):
+        """Host -> device copy of (lr, next step count); call before the step that will read it.  `slot` picks one of two
+        pinned images (the copy is asynchronous: a caller that runs ahead of the GPU alternates them, graph.StepGraph).  `lr`:
+        the value to push when it is not self.lr at this moment (a schedule advanced on another thread)."""
+        if slot:
+            self.ensure_second_hyper_image()
         h = self.hyper_host2 if slot else self.hyper_host
-        h[0] = float(self.lr)
+        h[0] = float(self.lr if lr is None else lr)
         h[1] = float(self.t + 1)
         self.hyper_dev.copy_(h, non_blocking=True)
 
@@ -651,6 +657,7 @@ class FusedAdam:
         from . import hip
         self.t += 1
         L = hip.lib()
+        lr = self.lr if self.lr_step is None else self.lr_step
         g = self.ddp.flat
         hyper = hip.ptr(self.hyper_dev) if (self.hyper_dev is not None and g.is_cuda and torch.cuda.is_current_stream_capturing()) else 0
         if self.ddp._pair_pending and self.ddp.world == 1:
@@ -660,7 +667,7 @@ class FusedAdam:
             if self.clip > 0:
                 hip.check(L.st5_sumsq_pair(g.data_ptr(), g2.data_ptr(), self.gnorm_sq.data_ptr(), g.numel(), 1.0, 0, hip.stream()), "st5_sumsq_pair")
             hip.check(L.st5_adam_step_pair(self.pflat.data_ptr(), g.data_ptr(), g2.data_ptr(), 1, self.m.data_ptr(), self.v.data_ptr(), g.numel(),
-                                           self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                           lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
                                            self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
                                            self.wflat.data_ptr() if self.mirror is not None else 0, hyper, hip.stream()),
                       "st5_adam_step_pair")
@@ -673,7 +680,7 @@ class FusedAdam:
             # (one buffer; the kernel leaves it zeroed in passing -- the second buffer, if there is one, is zero whenever no sum
             # is pending -- so the next zero_grad() has no fill to launch)
             hip.check(L.st5_adam_step_pair(self.pflat.data_ptr(), g.data_ptr(), 0, 1, self.m.data_ptr(), self.v.data_ptr(), g.numel(),
-                                           self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                           lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
                                            self.gnorm_sq.data_ptr() if self.clip > 0 else 0, self.clip, grad_scale,
                                            self.wflat.data_ptr() if self.mirror is not None else 0, hyper, hip.stream()),
                       "st5_adam_step_pair")

@@ -76,13 +76,22 @@ class SeedSlots:
         import numpy as np
         vals = ((np.uint64(_S.seed) << np.uint64(32)) | ((np.arange(1, n + 1, dtype=np.uint64) + np.uint64(base)) & np.uint64(0xFFFFFFFF)))
         if slot and self.host2 is None:
-            self.host2 = torch.empty_like(self.host).pin_memory()
+            self.ensure_second_image()
         (self.host2 if slot else self.host)[:n] = torch.from_numpy(vals.astype(np.int64))
         _S.counter += n
 
     def upload(self, slot):
         self.dev.copy_(self.host2 if slot else self.host, non_blocking=True)
         self.k = 0
+
+    def ensure_second_image(self):
+        if self.host2 is None:
+            self.host2 = torch.zeros(self.n, dtype=torch.int64).pin_memory()
+
+    def digest(self, slot):
+        import zlib
+        n = self.used if self.used else self.n
+        return zlib.crc32((self.host2 if slot else self.host)[:n].numpy().tobytes())
 
 
 # Host-produced step inputs (random span masks, time-mix indices, ...): in eager mode a plain host->device copy; while a
@@ -164,6 +173,16 @@ class HostStaging:
         for e in self.entries:
             if e[0] is not None:
                 e[0].copy_(e[3] if slot else e[1], non_blocking=True)
+
+    def ensure_second_images(self):
+        """Second pinned image of every staged input, allocated on the calling thread (graph.StepGraph.capture)."""
+        for e in self.entries:
+            if e[0] is not None and len(e) == 3:
+                e.append(torch.empty(e[1].shape, dtype=e[1].dtype).pin_memory())
+
+    def digests(self, slot):
+        import zlib
+        return [zlib.crc32((e[3] if slot else e[1]).numpy().tobytes()) for e in self.entries if e[0] is not None]
 
 
 staging = HostStaging()

@@ -53,6 +53,8 @@ class StepGraph:
         self.prefetch_host = prefetch_host
         self._ahead = None      # (thread, slot) preparing the next step
         self._slot = 0
+        self._lr = [None, None]  # the learning rate on_step() left behind, per pinned slot (read on the thread that ran on_step)
+        self.trace = None        # tests: a list -> one record per replay of what was uploaded (digests of the pinned images)
         self._uploaded = [None, None]   # event after the last upload from each pinned slot (the slot may be rewritten only after it)
         self.slots = Fn.SeedSlots(seed_slots, self.device)
         self.staging = Fn.HostStaging()   # per graph: two graphs (two tests, two shapes) never share a staging sequence
@@ -148,12 +150,21 @@ class StepGraph:
         if self.opt is not None and self.after_fn is None:
             self.opt.t = t0
         assert self.slots.k == self.slots.used, "the captured step used a different number of dropout seeds than the recorded one"
+        if self.prefetch_host:
+            # every pinned image the helper thread will write exists before it first runs: the helper never allocates pinned
+            # memory (hipHostMalloc from a second host thread beside a graph launch) and never touches the HIP runtime at all
+            self.slots.ensure_second_image()
+            self.staging.ensure_second_images()
+            if self.opt is not None:
+                self.opt.ensure_second_hyper_image()
         self._pending = True   # buffers are already staged for the first replay
 
     def _produce(self, slot):
         """Host half of the preparation of one step (no device work)."""
         if self.on_step is not None:
             self.on_step()
+        if self.opt is not None:
+            self._lr[slot] = float(self.opt.lr)   # (snapshot on the producing thread: the upload never reads a half-advanced schedule)
         self.slots.produce(slot)
         self.staging.produce(slot)
 
@@ -161,7 +172,10 @@ class StepGraph:
         self.slots.upload(slot)
         self.staging.upload(slot)
         if self.opt is not None:
-            self.opt.push_hyper(slot)
+            self.opt.push_hyper(slot, lr=self._lr[slot])
+        if self.trace is not None:
+            self.trace.append({"slot": slot, "seeds": self.slots.digest(slot), "staged": self.staging.digests(slot),
+                               "lr": self._lr[slot], "t": (self.opt.t + 1) if self.opt is not None else None})
         # the uploads are asynchronous reads of pinned host images: remember when this slot's have executed (a host that runs
         # ahead of the GPU -- small steps -- must not rewrite the images before that)
         ev = torch.cuda.Event()
@@ -175,17 +189,32 @@ class StepGraph:
         self._upload(0)
 
     def replay(self):
+        """One replayed update.  It is ALWAYS enqueued on this graph's own stream (uploads of the staged inputs, the graph
+        launch, the eager tail), whatever stream the caller is on -- in particular never on the legacy NULL stream, which this
+        runtime does not keep in issue order when more than one host thread is alive beside it; the
+        caller's stream is ordered before and behind the replay, so for the caller it behaves like work on its own stream."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur == self.stream:
+            return self._replay()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._replay()
+        cur.wait_stream(self.stream)
+
+    def _replay(self):
+        used = 0            # the pinned slot this step's inputs came from
         if self._pending:
             self._pending = False
         elif self._ahead is not None:
-            th, slot = self._ahead
+            th, used = self._ahead
             th.join()
             self._ahead = None
             if self._ahead_error is not None:
                 raise self._ahead_error
-            self._upload(slot)
+            self._upload(used)
         else:
             self._pre_replay()
+        step_lr = self._lr[used]
         if self.prefetch_host:
             import threading
             self._slot ^= 1
@@ -214,7 +243,15 @@ class StepGraph:
         else:
             self.graph.replay()
         if self.after_fn is not None:
-            self.after_fn()          # (its optimizer step advances opt.t itself)
+            # the eager tail's optimizer step passes lr BY VALUE; by now the helper thread may have advanced the schedule to the
+            # next step (on_step runs one step early there): the tail reads this step's snapshot
+            if self.opt is not None:
+                self.opt.lr_step = step_lr
+            try:
+                self.after_fn()          # (its optimizer step advances opt.t itself)
+            finally:
+                if self.opt is not None:
+                    self.opt.lr_step = None
         elif self.opt is not None:
             self.opt.t += 1
             if ddp is not None:

@@ -23,7 +23,7 @@ def _run(cuda, graph, micro, n_updates, layerdrop=0.05, batch=8, poison=False, e
     upd = None
     try:
         _, _, model, upd = bench.make_update(cuda, torch.bfloat16, "base", batch, 0, graph=graph, micro=micro, layerdrop=layerdrop,
-                                             prefetch_host=False, exchange=exchange)
+                                             exchange=exchange)   # prefetch_host: bench.make_update's default = what bench.py times
         with poisoned_allocations() if poison else contextlib.nullcontext():
             if graph:
                 upd.prepare_graph()                     # two recorded updates
