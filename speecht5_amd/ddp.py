@@ -50,6 +50,7 @@ class FlatGradDataParallel:
         # ST5_DDP_FORCE_COLLECTIVES=1 runs the bucketed async all-reduce path even in a 1-rank group (used to exercise the
         # RCCL stream / event plumbing on a single-GPU box; a 1-rank all-reduce leaves the data unchanged)
         self.collectives = self.world > 1 or (os.environ.get("ST5_DDP_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
+        self.overlap_exchange = None    # decided at the first bucket trigger (exchange_overlap_allowed: RCCL needs NCCL_ALGO=Ring)
         groups = [g if isinstance(g, BucketGroup) else BucketGroup(list(g)) for g in
                   (bucket_groups if bucket_groups is not None else default_buckets(model))]
         nb = len(groups)
@@ -203,7 +204,10 @@ class FlatGradDataParallel:
         if not self.collectives or self._accumulating:
             return
         self._ready[bi] = True
-        self._launch_in_order(False)
+        if self.overlap_exchange is None:
+            self.overlap_exchange = exchange_overlap_allowed(self.pg)
+        if self.overlap_exchange:           # else: finish() launches every bucket, in index order, behind the backward
+            self._launch_in_order(False)
 
     def _launch_in_order(self, everything):
         nb = len(self.buckets)
@@ -494,6 +498,27 @@ class FlatGradDataParallel:
             if self.world > 1:
                 self.flat.mul_(1.0 / self.world)
         self._reset_round()
+
+
+def exchange_overlap_allowed(pg=None, warn=True):
+    """May a collective run on the process group's stream UNDERNEATH this library's MFMA kernels?  On RCCL only with
+    NCCL_ALGO=Ring: the ring Sum<float> device functions of the librccl torch ships contain no packed-fp32 VALU ops, the tree /
+    PreMulSum ones do (profiles/r3_rccl_packed_fp32.txt), and packed-fp32 math beside another stream's MFMA waves returned stale
+    lanes on this hardware.  Anything else (gloo: host-side reduction) is safe.  When the answer is no
+    the callers serialise: the exchange goes out behind the backward (update.PretrainUpdate falls back to one message,
+    FlatGradDataParallel._bucket_ready leaves every bucket to finish())."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    if dist.get_backend(pg) != "nccl":
+        return True
+    ok = os.environ.get("NCCL_ALGO", "").strip().lower() == "ring"
+    if not ok and warn:
+        import warnings
+        warnings.warn("speecht5_amd: NCCL_ALGO is not 'Ring' -- the gradient exchange will NOT be overlapped with the backward "
+                      "(RCCL's tree / PreMulSum kernels contain packed-fp32 ops that are unsafe beside MFMA kernels on gfx950; "
+                      "export NCCL_ALGO=Ring before the process group is created to get the overlapped exchange)")
+    return ok
 
 
 def _fusion_ordered_parameters(module):

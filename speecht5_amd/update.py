@@ -53,6 +53,10 @@ class PretrainUpdate:
         # (ST5_EAGER_PHASED=1: the same three phases enqueued eagerly -- tools/diag_phased.py, the tests' reference point)
         self.phased = ((self.split or (self.ddp.collectives and os.environ.get("ST5_EAGER_PHASED") == "1"))
                        and micro == "in_turn" and exchange == "phased" and len(self.micro) >= 1)
+        if self.phased:
+            from .ddp import exchange_overlap_allowed
+            if not exchange_overlap_allowed(self.ddp.pg):
+                self.phased = False      # one message behind the local phase: no collective beside the backward's kernels
         self._ph = None
         self.n = 0            # update counter (fairseq's num_updates)
         self.sg = None
@@ -98,8 +102,23 @@ class PretrainUpdate:
         return sorted(set(cuts))
 
     def phase_fns(self):
+        """The local phase as len(cuts) + 1 callables and, behind each, the hand-over of a bucket range to the process group.
+        The bucket ranges are STATIC (cut_buckets() is a function of the model alone, the same list on every rank): message k
+        covers the buckets up to cuts[k], the last one the rest.  What this rank's forward materialised only decides how many of
+        its own backward phases run inside nominal phase k (a cut whose input needed no gradient on this rank does not
+        materialise: the phase in front of it then runs through, and the nominal phase behind it is empty) -- the number and the
+        extent of the collectives never depend on per-rank state."""
         ddp, cuts_b = self.ddp, self.cut_buckets()
         nph = len(cuts_b) + 1
+        nb = len(ddp.buckets)
+
+        def run_until(b):     # this rank's backward phases until bucket b (None: every bucket) is complete
+            while self._ph_done < len(self._ph) and (b is None or self._ph_complete < b):
+                fn, upto = self._ph[self._ph_done]
+                with ddp.local_phase():
+                    fn()
+                self._ph_complete = nb - 1 if upto is None else upto
+                self._ph_done += 1
 
         def first():
             ddp.zero_grad()
@@ -109,21 +128,24 @@ class PretrainUpdate:
                 with ddp.cut_points(cuts_b) as cuts:
                     loss = self._fwd(self.micro[-1])
                 self._ph = ddp.backward_phases(loss, cuts)
-                self._ph[0][0]()
+            self._ph_done, self._ph_complete = 0, -1
+            fn, upto = self._ph[0]           # (from the loss to the last materialised cut: always runs here)
+            with ddp.local_phase():
+                fn()
+            self._ph_complete = nb - 1 if upto is None else upto
+            self._ph_done = 1
+            run_until(cuts_b[0] if cuts_b else None)
             ddp.flush_deferred()
 
         def later(k):
             def fn():
-                if k < len(self._ph):
-                    with ddp.local_phase():
-                        self._ph[k][0]()
+                run_until(cuts_b[k] if k < len(cuts_b) else None)
                 ddp.flush_deferred()
             return fn
 
         def reduce_after(k):
             def fn():
-                last = k == nph - 1 or k >= len(self._ph) - 1
-                ddp.reduce_bucket_range(None if last else self._ph[k][1])
+                ddp.reduce_bucket_range(cuts_b[k] if k < len(cuts_b) else None)
             return fn
         return [first] + [later(k) for k in range(1, nph)], [reduce_after(k) for k in range(nph)]
 

@@ -1,0 +1,44 @@
+"""Several RANKS on real hardware: two processes sharing the one MI355X of the test box, gradient exchange
+over gloo -- the `shared` branch of bench.py -- running the replayed several-rank update of speecht5_amd/update.py in both
+exchange forms (phased: three graphs with the bucket ranges all-reduced between them; one_message: one graph + one all-reduce).
+Both ranks hold rank 0's data and seeds, so the exchanged sum is exactly 2 x one rank's gradient and, with
+grad_scale = 1 / (2 micro-batches x 2 ranks), every rank's parameters and Adam moments after 4 updates must equal the ONE-rank
+replayed update's bit for bit (tests/two_rank_worker.py).  What it proves: the phased capture, the asynchronous hand-over of
+bucket ranges between graph launches, wait + eager Adam tail work with a REAL second process on the same GPU; what it cannot
+prove on one GPU: RCCL over xGMI (the driver's 8-GPU run)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(nproc, exchange, out, port):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "8"
+    worker = os.path.join(ROOT, "tests", "two_rank_worker.py")
+    if nproc == 1:
+        cmd = [sys.executable, worker, "--exchange", exchange, "--out", out]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), worker, "--exchange", exchange, "--out", out]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"{' '.join(cmd)}\n{r.stdout[-3000:]}\n{r.stderr[-6000:]}"
+    return [json.load(open(f"{out}.rank{k}.json")) for k in range(nproc)]
+
+
+def test_two_ranks_sharing_the_gpu_equal_the_one_rank_update(cuda, tmp_path):
+    one = _launch(1, "phased", str(tmp_path / "one"), 0)[0]
+    assert one["finite"] and one["t"] == 4 and not one["split"]
+    for i, exchange in enumerate(("phased", "one_message")):
+        ranks = _launch(2, exchange, str(tmp_path / exchange), 29611 + i)
+        assert all(r["split"] for r in ranks)
+        assert all(r["phased"] == (exchange == "phased") for r in ranks)
+        assert ranks[0]["t"] == ranks[1]["t"] == 4
+        assert ranks[0]["digest"] == ranks[1]["digest"], f"{exchange}: the two ranks disagree ({ranks[0]['pnorm']} vs {ranks[1]['pnorm']})"
+        assert ranks[0]["digest"] == one["digest"], f"{exchange}: two ranks != one rank ({ranks[0]['pnorm']} vs {one['pnorm']})"
