@@ -219,13 +219,6 @@ int64_t st5_colsum_ws_bytes(int64_t rows, int32_t cols);
 int st5_sumsq(const void* x, float* out, int64_t n, float scale, int32_t accumulate, int dtype, void* stream);
 /* y = a*x + b*y */
 int st5_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, void* stream);
-/* Debug: `blocks` workgroups keep a pattern in `bytes` of LDS and count words that change under them (errors_dev[0] +=): detects
- * another workgroup on the same CU writing outside its own LDS allocation (tools/diag_lds.py, tests/test_lds_gpu.py). */
-int st5_debug_lds_canary(int32_t* errors_dev, int32_t blocks, int32_t bytes, int32_t spins, void* stream);
-/* Debug: re-read a constant pattern buffer (buf[i] == i * 2654435761) `passes` times and count wrong words (errors_dev[0] +=). */
-int st5_debug_load_check(const uint32_t* buf, int64_t n, int32_t* errors_dev, int32_t blocks, int32_t passes, void* stream);
-/* Debug: every lane holds 48 register values through `spins` sleep rounds; hist64_dev[lane] += mismatching values at the end. */
-int st5_debug_vgpr_canary(int32_t* hist64_dev, int32_t blocks, int32_t spins, void* stream);
 /* LayerDrop inside a replayed (HIP-graph) step, where the host's per-layer draw cannot steer control flow
  * (modules/encoder.py:251-257 `if not self.training or (dropout_probability > self.encoder_layerdrop)`, modules/decoder.py:64-67
  * LayerDropModuleList): every layer runs and  y = keep ? b (layer output) : a (layer input),  keep = one float in device memory

@@ -238,7 +238,7 @@ __device__ __forceinline__ long long drop_row_stride(int row_len) { return ((lon
 
 // Kernels that are built for exactly two waves per SIMD (the 128x128 GEMM family: ~180 VGPRs) declare the WHOLE half of the
 // register file (256 VGPRs), so that no third wave -- of this or of ANY OTHER kernel on another stream -- is placed on a SIMD
-// that already holds two of them.  Measured on MI355X / ROCm 7.2 (tools/diag_order2.py): a wave of an unrelated kernel
+// that already holds two of them.  Measured on MI355X / ROCm 7.2 (tools/diag/diag_order2.py): a wave of an unrelated kernel
 // (conv layer 0's backward: 88 VGPRs, 250 us per block) that shared a SIMD with two ~184-VGPR GEMM waves (general, LDS-DMA
 // NT or TN form alike; never with one such wave, never with a copy kernel) had lanes 48..63 of its registers corrupted in
 // 10-16 of 16 runs -- the source of the run-to-run differences of the side-by-side micro-batches at full size.  With the

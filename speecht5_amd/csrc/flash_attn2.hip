@@ -16,6 +16,11 @@
 #include "common.h"
 #include "../../include/speecht5_hip.h"
 
+// FA2_ABL (timing experiments only, results wrong by construction; tools/r4/fa_abl.sh): 1 = no bias-window DMA, 2 = also no LDS
+// reads of the window, 3 = dkv writes no dQP, 4 = every bias tile treated as fully clipped (uniform bias)
+#ifndef FA2_ABL
+#define FA2_ABL 0
+#endif
 namespace fa2 {
 
 constexpr int HD = 64;
@@ -79,6 +84,9 @@ struct WinStager {
     }
   }
   __device__ __forceinline__ void issue(const bf16_t* qpb, int wbc, int nchunks_data, char* scratch) const {
+#if FA2_ABL == 1 || FA2_ABL == 2
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       int c = wbc + (int)(pk[i] & 15u) + 1;             // +1: data chunk c sits at row chunk c+1 (chunk 0 = low end replica)
@@ -123,6 +131,10 @@ __device__ __forceinline__ unsigned int kpm_raw(const uint8_t* mrow, int key, in
 // rd = scratch byte address of window position (q_l + 63 - 4hi + mis) - 59 ... see caller; value index decreases with c.
 __device__ __forceinline__ void read_bias(unsigned int (&braw)[32], const char* rd) {
   const unsigned short* p = reinterpret_cast<const unsigned short*>(rd);
+#if FA2_ABL == 2
+  for (int i = 0; i < 32; ++i) { braw[i] = 0x3c00u + i; asm volatile("" : "+v"(braw[i])); }
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
     const int c = (i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2);
@@ -244,13 +256,19 @@ __device__ __forceinline__ WinGeom win_geom(int qw0, int j0, int maxrel, int nb)
   WinGeom g;
   const int bmin = qw0 - (j0 + 63) + maxrel, bmax = qw0 + 31 - j0 + maxrel;   // unclamped bucket range of the rectangle
   g.mode = bmax <= 0 ? 1 : (bmin >= nb - 1 ? 2 : 0);
+#if FA2_ABL == 4
+  g.mode = g.mode == 0 ? 1 : g.mode;
+#endif
   const int wb8 = bmin & ~7;            // floor to a multiple of 8 (two's complement: also for negatives)
   g.wbc = wb8 >> 3;
   g.mis = bmin - wb8;
   return g;
 }
 
-template <bool BIAS>
+// DROP is a launch-time constant (dropout_p > 0), so it is a template parameter: the element-wise blocks exist once per kernel
+// instead of twice behind a uniform branch (round 3's GEMM lesson -- code size against a 64 KB instruction cache shared by two
+// CUs; bwd_dq_kernel<true> was 7.9 k instructions with its 16-way run-time dispatch).
+template <bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void fwd_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kbuf = smem;                 // 2 x 8 KB
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void fwd_kernel(const Args a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
-  const bool drop = a.dropout_p > 0.f;
+  constexpr bool drop = DROP;
   const unsigned int thresh = drop ? dropout_thresh(a.dropout_p) : 0u;
   const float inv_keep = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
   const float sc2 = a.scale * LOG2E;
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void fwd_kernel(const Args a) {
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = m_run == -INFINITY ? 0.f : fast_exp2(m_run - m_use);
     float psum;
-    if (drop) psum = tile_probs<true>(s0, s1, m_use, drop_block_key(a.seed, ctr_blk + (unsigned long long)jt), hoff, thresh);
+    if constexpr (DROP) psum = tile_probs<true>(s0, s1, m_use, drop_block_key(a.seed, ctr_blk + (unsigned long long)jt), hoff, thresh);
     else psum = tile_probs<false>(s0, s1, m_use, 0u, hoff, thresh);
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -491,11 +509,15 @@ __device__ __forceinline__ void dq_half(const int t, f32x16& s, const f32x16& dp
 // bias values of one 32-key half tile: element r is key offset c = 32t + (r&3) + 8(r>>2) (+ 4 hi)
 __device__ __forceinline__ void read_bias_half(const int t, unsigned int (&braw)[16], const char* rd) {
   const unsigned short* p = reinterpret_cast<const unsigned short*>(rd);
+#if FA2_ABL == 2
+  for (int r = 0; r < 16; ++r) { braw[r] = 0x3c00u + r; asm volatile("" : "+v"(braw[r])); }
+  return;
+#endif
 #pragma unroll
   for (int r = 0; r < 16; ++r) braw[r] = p[59 - (32 * t + (r & 3) + 8 * (r >> 2))];
 }
 
-template <bool BIAS>
+template <bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kbuf = smem;                 // 2 x 8 KB
@@ -559,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
   float acc_lo = 0.f, acc_hi = 0.f;
-  const bool drop = a.dropout_p > 0.f;
+  constexpr bool drop = DROP;
   const unsigned int thresh = drop ? dropout_thresh(a.dropout_p) : 0u;
   const float inv_keep = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
   const float sc2 = a.scale * LOG2E;
@@ -628,8 +650,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
     else if (bmode == 0) { if (clip) DQ_HALF(1, true, MASK_, DROP_); else DQ_HALF(1, false, MASK_, DROP_); } \
     else DQ_HALF(2, false, MASK_, DROP_);                                                    \
   } while (0)
-      if (drop) { if (need_mask) DQ_DISPATCH(true, true); else DQ_DISPATCH(false, true); }
-      else { if (need_mask) DQ_DISPATCH(true, false); else DQ_DISPATCH(false, false); }
+      if (need_mask) DQ_DISPATCH(true, DROP); else DQ_DISPATCH(false, DROP);
 #undef DQ_DISPATCH
 #undef DQ_HALF
       // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]   (K^T fragments by transpose reads of the [key][d] tile)
@@ -694,6 +715,9 @@ struct KWinStager {
   }
   // q0: first query of the sub-tile
   __device__ __forceinline__ void issue(const bf16_t* qpb, int q0, int T, int nbp, int wbc, int nchunks_data, char* scratch) const {
+#if FA2_ABL == 1 || FA2_ABL == 2
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       int q = q0 + qrow[i];
@@ -735,12 +759,16 @@ __device__ __forceinline__ void dkv_sub(f32x16& s, const f32x16& dp, f32x16& pd,
     if (BMODE == 1) {
       bool st_ok = kvalid && bk > 0 && bk < a.nb - 1;
       if (SLOW) st_ok = st_ok && qq < a.T;
+#if FA2_ABL != 3
       if (st_ok) dqpb[(unsigned int)(qq * a.nb + bk)] = (bf16_t)ds;
+#else
+      asm volatile("" :: "v"(st_ok));
+#endif
     }
   }
 }
 
-template <bool BIAS>
+template <bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -769,7 +797,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
   f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
-  const bool drop = a.dropout_p > 0.f;
+  constexpr bool drop = DROP;
   const unsigned int thresh = drop ? dropout_thresh(a.dropout_p) : 0u;
   const float inv_keep = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
   const float sc2 = a.scale * LOG2E;
@@ -798,6 +826,9 @@ __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
   auto sub_geom = [&](int n, int& mode, int& wbc, int& mis) {
     const int bmin = 32 * n - (kw0 + 31) + a.maxrel, bmax = 32 * n + 31 - kw0 + a.maxrel;
     mode = bmax <= 0 ? 1 : (bmin >= a.nb - 1 ? 2 : 0);
+#if FA2_ABL == 4
+    mode = mode == 0 ? 1 : mode;
+#endif
     const int wb8 = bmin & ~7;
     wbc = wb8 >> 3;
     mis = bmin - wb8;
@@ -867,8 +898,13 @@ __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
       if (BIAS && bmode == 0) {
         if (sub == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window issued during sub 0 (own DMA, own reads)
         const unsigned short* pw = reinterpret_cast<const unsigned short*>(scratch + rd_lane + mis * 2);
+#if FA2_ABL == 2
+        for (int r = 0; r < 16; ++r) { braw[r] = 0x3c000000u + (r << 16); asm volatile("" : "+v"(braw[r])); }
+        (void)pw;
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) braw[r] = (unsigned int)pw[((r & 3) + 8 * (r >> 2)) * (KWIN + 1)] << 16;
+#endif
       } else if (BIAS && bmode != 3) {   // fully clipped sub-tile: the queries' end values from the side array
         const unsigned int* pe_ = reinterpret_cast<const unsigned int*>(stv) + (bmode == 1 ? 256 : 320) + sub * 32 + 4 * hi;
 #pragma unroll
@@ -905,8 +941,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
     else if (bmode == 0) DKV_SUB(1, SLOW_, DROP_);            \
     else DKV_SUB(2, SLOW_, DROP_);                            \
   } while (0)
-      if (drop) { if (slow) DKV_DISPATCH(true, true); else DKV_DISPATCH(false, true); }
-      else { if (slow) DKV_DISPATCH(true, false); else DKV_DISPATCH(false, false); }
+      if (slow) DKV_DISPATCH(true, DROP); else DKV_DISPATCH(false, DROP);
 #undef DKV_DISPATCH
 #undef DKV_SUB
       // dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]
@@ -967,8 +1002,10 @@ int g_impl = 2;
 bool g_attr = false;
 int set_attrs() {
   if (g_attr) return ST5_OK;
-  const void* fns[] = {(const void*)fa2::fwd_kernel<true>, (const void*)fa2::fwd_kernel<false>, (const void*)fa2::bwd_dq_kernel<true>,
-                       (const void*)fa2::bwd_dq_kernel<false>, (const void*)fa2::bwd_dkv_kernel<true>, (const void*)fa2::bwd_dkv_kernel<false>};
+  const void* fns[] = {(const void*)fa2::fwd_kernel<true, true>, (const void*)fa2::fwd_kernel<false, true>, (const void*)fa2::fwd_kernel<true, false>,
+                       (const void*)fa2::fwd_kernel<false, false>, (const void*)fa2::bwd_dq_kernel<true, true>, (const void*)fa2::bwd_dq_kernel<false, true>,
+                       (const void*)fa2::bwd_dq_kernel<true, false>, (const void*)fa2::bwd_dq_kernel<false, false>, (const void*)fa2::bwd_dkv_kernel<true, true>,
+                       (const void*)fa2::bwd_dkv_kernel<false, true>, (const void*)fa2::bwd_dkv_kernel<true, false>, (const void*)fa2::bwd_dkv_kernel<false, false>};
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
   g_attr = true;
@@ -1017,8 +1054,12 @@ extern "C" int st5_flash_attn_fwd_qp(const void* q, int64_t q_ld, const void* k,
   a.B = B; a.H = H; a.T = T; a.S = S; a.nb = pe ? nb : 0; a.maxrel = maxrel; a.causal = causal; a.lds = lds;
   a.scale = scale; a.dropout_p = dropout_p; a.seed = seed;
   dim3 grid((T + 127) / 128, B * H), block(256);
-  if (pe) hipLaunchKernelGGL(fa2::fwd_kernel<true>, grid, block, (size_t)4 * fa2::TILE_B + 4 * fa2::SCR_B, s, a);
-  else hipLaunchKernelGGL(fa2::fwd_kernel<false>, grid, block, (size_t)4 * fa2::TILE_B, s, a);
+  const bool dr = dropout_p > 0.f;
+  const size_t shm = (size_t)4 * fa2::TILE_B + (pe ? 4 * fa2::SCR_B : 0);
+  if (pe && dr) hipLaunchKernelGGL((fa2::fwd_kernel<true, true>), grid, block, shm, s, a);
+  else if (pe) hipLaunchKernelGGL((fa2::fwd_kernel<true, false>), grid, block, shm, s, a);
+  else if (dr) hipLaunchKernelGGL((fa2::fwd_kernel<false, true>), grid, block, shm, s, a);
+  else hipLaunchKernelGGL((fa2::fwd_kernel<false, false>), grid, block, shm, s, a);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -1060,13 +1101,18 @@ extern "C" int st5_flash_attn_bwd_2s(const void* q, int64_t q_ld, const void* k,
   if (s2) { if (st5_stream_fork(s, s2) != ST5_OK) return ST5_ERR_LAUNCH; } else s2 = s;
   const size_t shm_dq = (size_t)4 * fa2::TILE_B + (pe ? 4 * fa2::SCR_B : 0);
   const size_t shm_dkv = (size_t)2 * fa2::QBUF_B + (pe ? 4 * fa2::KSCR_B : 0);
-  if (pe) {
-    hipLaunchKernelGGL(fa2::bwd_dq_kernel<true>, dim3((T + 127) / 128, B * H), dim3(256), shm_dq, s, a);
-    hipLaunchKernelGGL(fa2::bwd_dkv_kernel<true>, dim3((S + 127) / 128, B * H), dim3(256), shm_dkv, s2, a);
-  } else {
-    hipLaunchKernelGGL(fa2::bwd_dq_kernel<false>, dim3((T + 127) / 128, B * H), dim3(256), shm_dq, s, a);
-    hipLaunchKernelGGL(fa2::bwd_dkv_kernel<false>, dim3((S + 127) / 128, B * H), dim3(256), shm_dkv, s2, a);
-  }
+  const dim3 gq((T + 127) / 128, B * H), gk((S + 127) / 128, B * H), blk(256);
+  const bool dr = dropout_p > 0.f;
+#define FA2_BWD(BIAS_, DROP_)                                                                        \
+  do {                                                                                               \
+    hipLaunchKernelGGL((fa2::bwd_dq_kernel<BIAS_, DROP_>), gq, blk, shm_dq, s, a);    \
+    hipLaunchKernelGGL((fa2::bwd_dkv_kernel<BIAS_, DROP_>), gk, blk, shm_dkv, s2, a); \
+  } while (0)
+  if (pe && dr) FA2_BWD(true, true);
+  else if (pe) FA2_BWD(true, false);
+  else if (dr) FA2_BWD(false, true);
+  else FA2_BWD(false, false);
+#undef FA2_BWD
   HIP_CHECK_LAUNCH();
   if (s2 != s && st5_stream_fork(s2, s) != ST5_OK) return ST5_ERR_LAUNCH;
   return ST5_OK;

@@ -89,9 +89,6 @@ _SIGS = {
     "st5_colsum_ws_bytes": (c_int64, [c_int64, c_int32]),
     "st5_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int32, c_int, c_void_p]),
     "st5_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
-    "st5_debug_lds_canary": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
-    "st5_debug_load_check": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p]),
-    "st5_debug_vgpr_canary": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "st5_select": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "st5_select_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "st5_act_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),

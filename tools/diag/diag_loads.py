@@ -1,9 +1,11 @@
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from speecht5_amd import hip
 dev = torch.device("cuda:0")
 L = hip.lib()
+import ctypes
+D = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libst5_diag.so'))   # tools/diag/build.sh
 err = torch.zeros(1, dtype=torch.int32, device=dev)
 main, noise = torch.cuda.Stream(), torch.cuda.Stream()
 bf = torch.bfloat16
@@ -32,7 +34,7 @@ for kind in ("none", "blas", "nt256", "nt128"):
             with torch.cuda.stream(noise):
                 for _ in range(60): noise_fn(kind)
             with torch.cuda.stream(main):
-                hip.check(L.st5_debug_load_check(buf.data_ptr(), buf.numel(), err.data_ptr(), blocks, passes, hip.stream()), "check")
+                hip.check(D.st5_debug_load_check(buf.data_ptr(), buf.numel(), err.data_ptr(), blocks, passes, hip.stream()), "check")
             torch.cuda.synchronize()
             tot += int(err.item())
         print(f"noise={kind:6s} {name:14s}: wrong words over 5 runs = {tot}", flush=True)

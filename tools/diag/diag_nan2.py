@@ -1,6 +1,6 @@
 import sys, os
 os.environ["ST5_POISON"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from speecht5_amd import functional as Fn, hip

@@ -1,6 +1,6 @@
 import os, sys
 os.environ.setdefault("ST5_POISON", "0")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from speecht5_amd import hip
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 import os, sys, collections
 os.environ["ST5_DDP_FORCE_COLLECTIVES"] = "1"
 os.environ["ST5_EAGER_PHASED"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.distributed as dist
 import bench
 from speecht5_amd import functional as Fn

@@ -2,7 +2,7 @@
 torch.empty / hipMalloc'ed buffer poisoned (0xFF bytes = NaN) vs the same update unpoisoned."""
 import os, sys
 os.environ["ST5_POISON"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from speecht5_amd import functional as Fn

@@ -1,6 +1,6 @@
 """Diagnostic (GPU): run-to-run determinism of the replayed full-size update under different amounts of concurrency."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from speecht5_amd import functional as Fn

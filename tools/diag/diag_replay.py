@@ -1,7 +1,7 @@
 """Diagnostic (GPU): where do replayed / side-by-side updates stop being bit-identical to the eager in-turn form?
 Tiny model (tests/test_graph_gpu._run) over mode x LayerDrop, then the full-size update of bench.py."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests.test_graph_gpu import _run
 

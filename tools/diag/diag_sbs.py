@@ -2,7 +2,7 @@
 switches that remove one source of concurrency at a time; reports which parameters differ (clipping off: a differing gradient
 only moves its own parameter)."""
 import sys, os, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from speecht5_amd import functional as Fn
