@@ -473,10 +473,17 @@ __global__ __launch_bounds__(256) void dvec_kernel(const bf16_t* __restrict__ o,
 // dS of one 32-key half tile (t) for the dq kernel.  In: s = raw q.k, dp = dO.V^T; out: s = dS = P * (dP_drop - D).
 // CLIP: the rectangle touches a clipped end bucket (unclamped bucket <= 0 or >= nb-1): those elements' dS are summed into
 // acc_lo / acc_hi.  b0 = unclamped bucket of key offset 0 of the 64-key tile for this lane (decreases with the key offset).
+// The three running sums come back BY VALUE (DqSums): as reference parameters -- threaded through sixteen differently instantiated
+// inlined call sites behind uniform branches -- hipcc kept acc_lo / acc_hi / csum in SCRATCH memory (private_segment_fixed_size 12,
+// 68 scratch_store + 68 scratch_load per tile): every `acc_lo += ds` was a round trip through memory.  That, not the window DMA or the
+// LDS reads, was the 2.2x of bwd_dq_kernel<true> over its no-bias form (round-4 ablations: no DMA -5 us, no LDS reads -3 us, all tiles
+// uniform -52 us of 105.6 us; profiles/r4_attention.md).
+struct DqSums { float lo, hi, c; };
 template <int BMODE /*0 none, 1 per element, 2 uniform*/, bool CLIP, bool MASK, bool DROP>
-__device__ __forceinline__ void dq_half(const int t, f32x16& s, const f32x16& dpv, float sc2, const unsigned int (&braw)[16], float buni,
-                                        int b0, int nbm1, unsigned long long km, int jrel, float lse2, float dsum, unsigned int key32,
-                                        unsigned int hoff, unsigned int thresh, float inv_keep, float& acc_lo, float& acc_hi, float& csum) {
+__device__ __forceinline__ DqSums dq_half(const int t, f32x16& s, const f32x16& dpv, float sc2, const unsigned int (&braw)[16], float buni,
+                                          int b0, int nbm1, unsigned long long km, int jrel, float lse2, float dsum, unsigned int key32,
+                                          unsigned int hoff, unsigned int thresh, float inv_keep, const DqSums in) {
+  float acc_lo = in.lo, acc_hi = in.hi, csum = in.c;     // (continued, not restarted: the summation order of the first generation)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     unsigned int bits0 = 0u, bits1 = 0u;
@@ -504,6 +511,7 @@ __device__ __forceinline__ void dq_half(const int t, f32x16& s, const f32x16& dp
       }
     }
   }
+  return DqSums{acc_lo, acc_hi, csum};
 }
 
 // bias values of one 32-key half tile: element r is key offset c = 32t + (r&3) + 8(r>>2) (+ 4 hi)
@@ -643,16 +651,18 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
         }
       }
 #define DQ_HALF(BM_, CL_, MASK_, DROP_) \
-  dq_half<BM_, CL_, MASK_, DROP_>(t, sv, pv, sc2, t == 0 ? braw0 : braw1, buni, b0, a.nb - 1, km, jrel, lse2, dsum, key32, hoff, thresh, inv_keep, acc_lo, acc_hi, csum)
+  hs = dq_half<BM_, CL_, MASK_, DROP_>(t, sv, pv, sc2, t == 0 ? braw0 : braw1, buni, b0, a.nb - 1, km, jrel, lse2, dsum, key32, hoff, thresh, inv_keep, hs)
 #define DQ_DISPATCH(MASK_, DROP_)                                                            \
   do {                                                                                       \
     if (bmode == 3) DQ_HALF(0, false, MASK_, DROP_);                                         \
     else if (bmode == 0) { if (clip) DQ_HALF(1, true, MASK_, DROP_); else DQ_HALF(1, false, MASK_, DROP_); } \
     else DQ_HALF(2, false, MASK_, DROP_);                                                    \
   } while (0)
+      DqSums hs{acc_lo, acc_hi, csum};
       if (need_mask) DQ_DISPATCH(true, DROP); else DQ_DISPATCH(false, DROP);
 #undef DQ_DISPATCH
 #undef DQ_HALF
+      acc_lo = hs.lo; acc_hi = hs.hi; csum = hs.c;
       // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]   (K^T fragments by transpose reads of the [key][d] tile)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
