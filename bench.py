@@ -80,16 +80,37 @@ def cpu_baseline(model, args, seconds=4.0, runs=5):
         (loss / ss).backward()
         return time.perf_counter() - t0
 
-    run(1.0)
+    # thread sweep (on a 128-thread host all-threads is SLOWER than 8 for this one-clip workload -- the oracle's
+    # GEMMs are small): one warm-up + one timed run per setting on a 2 s clip, then the median of `runs` at the best setting
+    avail = torch.get_num_threads()
+    cand = sorted({n for n in (8, 16, 32, 64, avail) if 1 <= n <= avail})
+    sweep = {}
+    for n in cand:
+        torch.set_num_threads(n)
+        run(1.0)
+        sweep[n] = round(run(2.0), 3)
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     run(1.0)
     ts = sorted(run(seconds) for _ in range(runs))
+    torch.set_num_threads(avail)
     t = ts[len(ts) // 2]
-    return {"value": round(seconds / t, 4), "unit": "audio-sec/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 x {seconds:g} s clip, speech_pretrain fwd+bwd (fp32 CPU oracle): median of {runs} runs after 2 warm-ups, "
-                      f"{t:.2f} s per run (min {ts[0]:.2f}, max {ts[-1]:.2f})",
-            # the reference itself cannot travel to this box; timed once beside the port where it exists (oracle/time_reference_cpu.py)
-            "reference_vs_port": "verbatim reference stack 1.90 s vs this port 3.61 s per run of the same clip on the same 8 cores "
-                                 "(profiles/r3_cpu_reference_vs_port.json): the reference's own CPU path is ~1.9x faster than `value`"}
+    ref = None
+    try:   # the verbatim reference stack timed beside this port on the build container's cores (oracle/time_reference_cpu.py)
+        ref = json.load(open(os.path.join(ROOT, "profiles", "r3_cpu_reference_vs_port.json")))
+    except Exception:
+        pass
+    out = {"value": round(seconds / t, 4), "unit": "audio-sec/s", "cores": best, "kind": "port",
+           "sample": f"1 x {seconds:g} s clip, speech_pretrain fwd+bwd (fp32 CPU oracle): median of {runs} runs after warm-up at the best "
+                     f"thread count of a sweep, {t:.2f} s per run (min {ts[0]:.2f}, max {ts[-1]:.2f})",
+           "thread_sweep_s_per_2s_clip": {str(k): v for k, v in sweep.items()}, "host_threads": avail}
+    if ref is not None:
+        # the reference itself cannot travel to this box: its ratio to the port, measured where both exist, is read from the committed file
+        rs, ps = ref.get("reference", {}).get("median_s"), ref.get("port", {}).get("median_s")
+        out["reference_vs_port"] = {"source": "profiles/r3_cpu_reference_vs_port.json", "reference_s_per_run": rs, "port_s_per_run": ps,
+                                    "cores": ref.get("cores"), "port_over_reference": round(ps / rs, 3) if rs and ps else None,
+                                    "reference_estimate_audio_sec_per_s": round(seconds / t * ps / rs, 4) if rs and ps else None}
+    return out
 
 
 def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, graph=True, micro="in_turn", layerdrop=0.05,

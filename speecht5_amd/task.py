@@ -32,15 +32,32 @@ def post_process(sentence, symbol):
 
 
 class _Dictionary(list):
-    """Symbol table with fairseq's special-symbol layout (<s>=0, <pad>=1, </s>=2, <unk>=3)."""
+    """Symbol table with fairseq's special-symbol layout (<s>=0, <pad>=1, </s>=2, <unk>=3) and the part of
+    fairseq.data.Dictionary's interface the plug-in and the reference's data plane use: index / add_symbol (with fairseq's
+    `overwrite` row semantics) / encode_line (what the reference's LabelEncoder calls, tasks/speecht5.py:24-36) / string /
+    pad / eos / bos / unk / count / indices / nspecial.  When fairseq is importable setup_task() builds real
+    fairseq.data.Dictionary objects instead (the data plane's mmap readers want those)."""
+    nspecial = 4
 
     def __init__(self, symbols=(), extra=()):
-        super().__init__(["<s>", "<pad>", "</s>", "<unk>"] + list(symbols) + list(extra))
+        super().__init__()
+        self.count = []
+        self.indices = {}
+        for s in ["<s>", "<pad>", "</s>", "<unk>"] + list(symbols) + list(extra):
+            self.add_symbol(s)
+
+    @property
+    def symbols(self):
+        return self
+
+    def __contains__(self, sym):
+        return sym in self.indices
 
     @classmethod
     def load(cls, path):
         """fairseq dictionary file (fairseq/data/dictionary.py add_from_file): one `<symbol> <count>` per line, in index order
-        after the four specials; a duplicate symbol is an error unless its line ends with the `#fairseq:overwrite` flag."""
+        after the four specials; a duplicate symbol is an error unless its line ends with the `#fairseq:overwrite` flag -- then
+        fairseq APPENDS a new row and re-points the symbol to it, so every later symbol keeps fairseq's index."""
         d = cls()
         with open(path, encoding="utf-8") as f:
             for line in f:
@@ -57,15 +74,19 @@ class _Dictionary(list):
                 if sym in d and not overwrite:
                     raise RuntimeError(f"Duplicate word found when loading Dictionary: '{sym}'. Duplicate words can overwrite earlier "
                                        "ones by adding the #fairseq:overwrite flag at the end of the corresponding row in the dictionary file.")
-                if sym in d:
-                    continue   # (overwrite: fairseq re-points the symbol's index to the new, last row; a list-backed table keeps the first)
-                d.append(sym)
+                d.add_symbol(sym, n=int(count), overwrite=overwrite)
         return d
 
-    def add_symbol(self, sym):
-        if sym in self:
-            return list.index(self, sym)
+    def add_symbol(self, sym, n=1, overwrite=False):
+        """fairseq Dictionary.add_symbol: an existing symbol only gains count -- unless overwrite, which appends a new row and
+        makes it the symbol's index (the old row stays, unreachable by name)."""
+        if sym in self.indices and not overwrite:
+            idx = self.indices[sym]
+            self.count[idx] += n
+            return idx
         self.append(sym)
+        self.count.append(n)
+        self.indices[sym] = len(self) - 1
         return len(self) - 1
 
     def unk_string(self, escape=False):
@@ -90,6 +111,22 @@ class _Dictionary(list):
         sent = separator.join(sym(int(t)) for t in tokens if int(t) not in skip)
         return post_process(sent, bpe_symbol)
 
+    def encode_line(self, line, line_tokenizer=None, add_if_not_exist=True, consumer=None, append_eos=True, reverse_order=False):
+        """fairseq Dictionary.encode_line: whitespace tokens -> IntTensor of ids (+ </s>); unknown words are added or map to <unk>."""
+        import re
+        words = (line_tokenizer(line) if line_tokenizer is not None else re.sub(r"\s+", " ", line).strip().split())
+        if reverse_order:
+            words = list(reversed(words))
+        ids = torch.IntTensor(len(words) + (1 if append_eos else 0))
+        for i, w in enumerate(words):
+            idx = self.add_symbol(w) if add_if_not_exist else self.index(w)
+            if consumer is not None:
+                consumer(w, idx)
+            ids[i] = idx
+        if append_eos:
+            ids[len(words)] = self.eos()
+        return ids
+
     def pad(self):
         return 1
 
@@ -103,11 +140,21 @@ class _Dictionary(list):
         return 3
 
     def index(self, sym):
-        """fairseq Dictionary.index: the symbol's id, <unk> for a symbol the table does not hold."""
+        """fairseq Dictionary.index: the symbol's id (its LAST row when rows were overwritten), <unk> for an unknown symbol."""
+        return self.indices.get(sym, self.unk())
+
+
+def _load_dictionary(path):
+    """A real fairseq.data.Dictionary when fairseq imports (the reference's data plane -- LabelEncoder, mmap text readers,
+    MultitaskDataset -- runs on these objects, tasks/speecht5.py:298-318), else the in-tree table with the same interface."""
+    from .fairseq_compat import HAVE_FAIRSEQ
+    if HAVE_FAIRSEQ:
         try:
-            return list.index(self, sym)
-        except ValueError:
-            return self.unk()
+            from fairseq.data import Dictionary
+            return Dictionary.load(path)
+        except ImportError:
+            pass
+    return _Dictionary.load(path)
 
 
 def _reference_task_class():
@@ -149,6 +196,11 @@ class SpeechT5Task(LegacyFairseqTask):
             self.mask_idx = text.add_symbol("<mask>")
             self.blank_symbol_idx = text.add_symbol("<ctc_blank>")
         self.blank_symbol = "<ctc_blank>"
+        # --iid-noise-target: 600 sentinel tokens <mask0> .. <mask599> (tasks/speecht5.py:289-294), read by the reference's
+        # TextPretrainDataset through load_dataset (uni_mask_idxs)
+        self.uni_mask_idxs = None
+        if getattr(args, "iid_noise_target", False) and text is not None and hasattr(text, "add_symbol"):
+            self.uni_mask_idxs = torch.tensor([text.add_symbol("<mask>" + str(i)) for i in range(600)])
         self.seed = getattr(args, "seed", 1)
 
     @staticmethod
@@ -166,8 +218,8 @@ class SpeechT5Task(LegacyFairseqTask):
         if args.t5_task == "pretrain":
             if not hasattr(args, "shuffle_instance"):
                 args.shuffle_instance = False
-            dicts["hubert"] = [_Dictionary.load(f"{args.hubert_label_dir}/dict.{label}.txt") for label in args.hubert_labels]
-        dicts["text"] = _Dictionary.load(op.join(args.data, "dict.txt"))
+            dicts["hubert"] = [_load_dictionary(f"{args.hubert_label_dir}/dict.{label}.txt") for label in args.hubert_labels]
+        dicts["text"] = _load_dictionary(op.join(args.data, "dict.txt"))
         return cls(args, dicts, None)
 
     def load_dataset(self, split, epoch=1, combine=False, **kwargs):
