@@ -109,6 +109,17 @@ int st5_gemm_set_deep_ring(int max_blocks, int nbuf);
  * st5_gemm_flush_splitk launches ONE kernel that folds every queued reduction into its output (the outputs are complete
  * only after the flush; same stream as the GEMMs).  Used by the data-parallel wrapper, which flushes before it reduces a
  * gradient bucket across ranks and at the end of backward.  Disabling flushes. */
+/* MX-fp8 NT GEMM for the d = 1024 / FFN 4096 Linears of t5_transformer_large (models/speecht5.py:1402-1425; BASELINE.json
+ * configs[4]): C = epilogue(A . B^T) with the epilogue features of st5_gemm, A [M x K] and B [N x K] as OCP fp8 e4m3 bytes
+ * (p->A / p->B: ld in bytes, K-major, no row split / segments / batch, K % 128 == 0) and one e8m0 scale byte per 32 consecutive
+ * k-elements of a row (a_scale [M x K/32], b_scale [N x K/32], row pitches % 4 == 0): element = fp8 * 2^(scale - 127), the OCP
+ * microscaling (MX) format consumed directly by v_mfma_scale_f32_32x32x64_f8f6f4.  C-class operands (C, R, P, Cpre) are bf16.
+ * Replaces the same F.linear call sites as st5_gemm when the fp8 compute mode is on (speecht5_amd.functional.set_fp8). */
+int st5_gemm_mxfp8(const st5_gemm_params* p, const uint8_t* a_scale, int64_t a_scale_ld, const uint8_t* b_scale, int64_t b_scale_ld,
+                   void* stream);
+/* MX quantisation along rows of a bf16 matrix x [rows x cols] (ld elements, cols % 32 == 0): q = e4m3(x * 2^(127 - s)) bytes
+ * (pitch q_ld), s[r][c / 32] = floor(log2(max|block|)) - 8 + 127 as e8m0 (pitch s_ld); round to nearest even, saturating. */
+int st5_quant_mxfp8(const void* x, int64_t ld, void* q, int64_t q_ld, uint8_t* s, int64_t s_ld, int64_t rows, int32_t cols, void* stream);
 int st5_gemm_defer_splitk(int enabled, void* stream);
 int st5_gemm_flush_splitk(void* stream);
 

@@ -1391,6 +1391,195 @@ bool nt256_pays(int M, int N, int nk, int batch) {
   return t256 >= 448;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// MX-fp8 NT path (BASELINE.json configs[4]: SpeechT5-Large with fp8 MFMA GEMMs; arch models/speecht5.py:1402-1425).
+// C = epilogue(A . B^T) with A [M x K], B [N x K] stored as OCP fp8 e4m3 bytes plus one e8m0 scale byte per 32 consecutive
+// k-elements of a row (the OCP microscaling format: value = fp8 * 2^(scale - 127)), C-class operands bf16.  The block-scaled
+// v_mfma_scale_f32_32x32x64_f8f6f4 is the only fp8 MFMA on gfx950 that runs at twice the bf16 rate (the unscaled fp8 forms
+// run AT the bf16 rate): 64 k-elements = two MX blocks per instruction; a lane (row = lane & 31, h = lane >> 5) supplies 16 bytes of each
+// block (k = 16h .. 16h+15) and the scale byte of block h -- the hardware's scale block IS the 32-element MX block.
+// Same skeleton as gemm_nt_glds_kernel: 128 x 128 tile, 4 waves x 64 x 64, tile rows of 128 BYTES (= 128 k-elements, twice the
+// reduction depth per LDS-DMA byte of the bf16 kernel: the per-CU operand fill rate that caps the 128^2 bf16 kernel at
+// ~1 PFLOP/s caps this one at ~2), 16-byte XOR swizzle on the source side, two-stage ring, the shared fused epilogues.
+// Scale bytes: the 4 blocks of a row's k-tile are one aligned dword; it is loaded one k-step ahead straight into registers
+// (issued BEFORE that step's LDS-DMA loads, so the in-order vmcnt wait at the top of the next step covers it and no wait of
+// its own drains the DMA queue); op_sel is ignored by the hardware (byte 0 is always taken), so the two 64-deep k-groups of the
+// tile get pre-shifted copies of the dword.
+// ------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+__device__ __forceinline__ i32x8 mx_frag2(const char* tile, int row, int c0, int c1) {
+  const u32x4 lo = *reinterpret_cast<const u32x4*>(tile + lds_off(row, c0));
+  const u32x4 hi = *reinterpret_cast<const u32x4*>(tile + lds_off(row, c1));
+  i32x8 r;
+  r[0] = (int)lo[0]; r[1] = (int)lo[1]; r[2] = (int)lo[2]; r[3] = (int)lo[3];
+  r[4] = (int)hi[0]; r[5] = (int)hi[1]; r[6] = (int)hi[2]; r[7] = (int)hi[3];
+  return r;
+}
+template <int FEAT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_mx8_kernel(const st5_gemm_params p, const int c_vec_ok,
+                                                                  const unsigned char* __restrict__ sa, const long long sa_ld,
+                                                                  const unsigned char* __restrict__ sb, const long long sb_ld) {
+  ST5_PAD_TO_256_VGPRS();
+  typedef bf16_t T;                 // type of the C-class operands
+  constexpr int BK = 128;           // k-elements (= bytes) per tile row
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
+    bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const unsigned char* Ap = reinterpret_cast<const unsigned char*>(p.A.ptr);
+  const unsigned char* Bp = reinterpret_cast<const unsigned char*>(p.B.ptr);
+
+  const unsigned char* asrc[4];
+  const unsigned char* bsrc[4];
+  const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wave) * 8 + rsub;
+    const int c = pc ^ ((row >> 1) & 7);
+    int gr = m0 + row; gr = gr < p.M ? gr : p.M - 1;
+    asrc[i] = Ap + (long long)gr * p.A.ld + c * 16;
+    int gc = n0 + row; gc = gc < p.N ? gc : p.N - 1;
+    bsrc[i] = Bp + (long long)gc * p.B.ld + c * 16;
+  }
+  const int dst0 = wave * 1024;
+  auto issue = [&](int kt, int buf) {
+    char* base = dsm + buf * 2 * TILE_BYTES + dst0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[i] + (long long)kt * BK), (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, 0);
+    }
+  };
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int arow0 = wr * 64 + frow, brow0 = wc * 64 + frow;
+  // scale rows of this lane's four fragment rows (dword kt of a row = the 4 block scales of k-tile kt)
+  const unsigned int* srow[4];
+  {
+    int r0 = m0 + arow0, r1 = r0 + 32, c0 = n0 + brow0, c1 = c0 + 32;
+    r0 = r0 < p.M ? r0 : p.M - 1; r1 = r1 < p.M ? r1 : p.M - 1;
+    c0 = c0 < p.N ? c0 : p.N - 1; c1 = c1 < p.N ? c1 : p.N - 1;
+    srow[0] = reinterpret_cast<const unsigned int*>(sa + (long long)r0 * sa_ld);
+    srow[1] = reinterpret_cast<const unsigned int*>(sa + (long long)r1 * sa_ld);
+    srow[2] = reinterpret_cast<const unsigned int*>(sb + (long long)c0 * sb_ld);
+    srow[3] = reinterpret_cast<const unsigned int*>(sb + (long long)c1 * sb_ld);
+  }
+  const int sh = 8 * fhalf;
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+  const int nk = p.K / BK;
+  unsigned int scn[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) scn[j] = srow[j][0];
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt and its scales (both issued one step ago)
+    __builtin_amdgcn_s_barrier();
+    // the scale operand is ALWAYS read from byte 0 of its register on this part (op_sel is ignored -- also composable_kernel's
+    // finding, ck/utility/amd_xdlops.hpp), so each k-group gets its own pre-shifted copy: block 2g + (lane >> 5) of the row's dword
+    int sc0[4], sc1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc0[j] = (int)(scn[j] >> sh); sc1[j] = (int)(scn[j] >> (16 + sh)); }
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) scn[j] = srow[j][kt + 1];
+      issue(kt + 1, (kt + 1) & 1);
+    }
+    const char* cur = dsm + (kt & 1) * 2 * TILE_BYTES;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {   // k-group g: bytes 64g .. 64g+63 of the tile rows = MX blocks 2g, 2g+1
+      const int* sc = g == 0 ? sc0 : sc1;
+      // operand layout measured on the part (tools/probe/mx_layout_probe.hip, tests/test_fp8_gpu.py): lane (row, h = lane >> 5)
+      // supplies bytes k = 16h .. 16h+15 of the instruction's FIRST 32-block in registers 0-3 and k = 16h .. 16h+15 of its SECOND
+      // block in registers 4-7; the scale of block b comes from the lanes with h == b (byte 0 of their scale register)
+      const int ca = 4 * g + fhalf, cb = 4 * g + 2 + fhalf;
+      const i32x8 a0 = mx_frag2(cur, arow0, ca, cb), a1 = mx_frag2(cur, arow0 + 32, ca, cb);
+      const i32x8 b0 = mx_frag2(cur + TILE_BYTES, brow0, ca, cb), b1 = mx_frag2(cur + TILE_BYTES, brow0 + 32, ca, cb);
+      acc00 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b0, acc00, 0, 0, 0, sc[0], 0, sc[2]);
+      acc01 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b1, acc01, 0, 0, 0, sc[0], 0, sc[3]);
+      acc10 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b0, acc10, 0, 0, 0, sc[1], 0, sc[2]);
+      acc11 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b1, acc11, 0, 0, 0, sc[1], 0, sc[3]);
+    }
+  }
+  __syncthreads();
+
+  EpiArgs ea;
+  ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
+  ea.bias = p.bias;
+  ea.c_ld = p.C.ld; ea.c_bs = p.C.bstride; ea.r_ld = p.R.ld; ea.r_bs = p.R.bstride;
+  ea.p_ld = p.P.ld; ea.p_bs = p.P.bstride; ea.q_ld = p.Cpre.ld; ea.q_bs = p.Cpre.bstride;
+  ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
+  ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
+  ea.atomic = 0;
+  ea.fast = c_vec_ok && (p.N % 8 == 0);
+  ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
+  ea.ctr_base = 0ull;
+  float* stage = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
+  run_epilogue<T, FEAT>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
+}
+
+template <int FEAT>
+int launch_mx8_as(const st5_gemm_params& p, int c_vec_ok, const unsigned char* sa, long long sa_ld, const unsigned char* sb, long long sb_ld,
+                  dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_nt_mx8_kernel<FEAT>), grid, dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, p, c_vec_ok, sa, sa_ld, sb, sb_ld);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+// MX quantisation of a row-major bf16 matrix along its rows: per 32 consecutive elements one e8m0 scale byte
+// E = floor(log2(amax)) - 8 + 127 (the OCP MX rule for e4m3, whose largest binade is 2^8) and 32 e4m3 bytes of x * 2^(127 - E),
+// round-to-nearest-even, saturating at +-448.  One lane per block: 64 bytes in, 32 + 1 bytes out.
+__global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict__ x, long long ld, unsigned char* __restrict__ q, long long q_ld,
+                                                        unsigned char* __restrict__ s, long long s_ld, long long rows, int cols) {
+  const int nb = cols >> 5;
+  const long long total = rows * nb;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long row = i / nb;
+    const int b = (int)(i - row * nb);
+    const bf16_t* src = x + row * ld + b * 32;
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t8[8];
+      load8f<bf16_t>(src + 8 * j, t8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[8 * j + e] = t8[e];
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;      // biased exponent of amax, minus emax(e4m3)
+    E = E < 0 ? 0 : (E > 254 ? 254 : E);
+    const float inv = __uint_as_float((unsigned int)(254 - E) << 23);    // 2^(127 - E)
+    u32x4 o0, o1;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      float f[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float t = v[4 * w + e] * inv; f[e] = fminf(fmaxf(t, -448.f), 448.f); }
+      int pk = 0;
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+      if (w < 4) o0[w] = (unsigned int)pk; else o1[w - 4] = (unsigned int)pk;
+    }
+    unsigned char* dst = q + row * q_ld + b * 32;
+    *reinterpret_cast<u32x4*>(dst) = o0;
+    *reinterpret_cast<u32x4*>(dst + 16) = o1;
+    s[row * s_ld + b] = (unsigned char)E;
+  }
+}
+
 }  // namespace
 
 extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
@@ -1504,6 +1693,61 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   if (g_use_glds && tn_glds_ok(p, dtype)) return launch_tn_glds(p, c_vec_ok, nsplit, s);
   if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, nsplit, s);
   return launch<float>(p, c_vec_ok, nsplit, s);
+}
+
+/* MX-fp8 GEMM (see gemm_nt_mx8_kernel): p describes fp8 operands A [M x K], B [N x K] (ld in BYTES = elements, K-major, no row
+ * split / segments / batch) and bf16 C-class operands; a_scale / b_scale hold one e8m0 byte per 32 k-elements of a row. */
+extern "C" int st5_gemm_mxfp8(const st5_gemm_params* pp, const uint8_t* a_scale, int64_t a_scale_ld, const uint8_t* b_scale,
+                              int64_t b_scale_ld, void* stream) {
+  if (!pp || !a_scale || !b_scale) return ST5_ERR_ARG;
+  st5_gemm_params p = *pp;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A.ptr || !p.B.ptr || !p.C.ptr) return ST5_ERR_ARG;
+  if (p.K % 128 || (p.batch > 1) || p.asum || (p.flags & (ST5_GEMM_A_KSTRIDED | ST5_GEMM_B_KSTRIDED | ST5_GEMM_OUT_F32))) return ST5_ERR_ARG;
+  if (p.A.rpb || p.B.rpb || p.A.seg || p.B.seg) return ST5_ERR_ARG;
+  if ((p.flags & ST5_GEMM_DACT) && !p.P.ptr) return ST5_ERR_ARG;
+  if (!aligned(p.A.ptr, 16) || !aligned(p.B.ptr, 16) || p.A.ld % 16 || p.B.ld % 16) return ST5_ERR_ALIGN;
+  if (!aligned(a_scale, 4) || !aligned(b_scale, 4) || a_scale_ld % 4 || b_scale_ld % 4) return ST5_ERR_ALIGN;
+  p.batch = 1; p.zdiv = 1;
+  auto c_ok = [&](const st5_operand& o) {
+    if (!o.ptr) return true;
+    return aligned(o.ptr, 16) && o.ld % 8 == 0 && o.bstride % 8 == 0;
+  };
+  const int c_vec_ok = c_ok(p.C) && c_ok(p.R) && c_ok(p.P) && c_ok(p.Cpre);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static bool attr = false;
+  if (!attr) {
+    const void* fns[] = {(const void*)gemm_nt_mx8_kernel<0>, (const void*)gemm_nt_mx8_kernel<F_GELU | F_PRE>, (const void*)gemm_nt_mx8_kernel<F_DROP | F_RES>,
+                         (const void*)gemm_nt_mx8_kernel<F_DACT>, (const void*)gemm_nt_mx8_kernel<F_BETA>, (const void*)gemm_nt_mx8_kernel<-1>};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
+    attr = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  dim3 grid(tiles, 1, 1);
+  const long long al = a_scale_ld, bl = b_scale_ld;
+  switch (nt_feat_of(p, c_vec_ok)) {
+    case 0: return launch_mx8_as<0>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
+    case F_GELU | F_PRE: return launch_mx8_as<F_GELU | F_PRE>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
+    case F_DROP | F_RES: return launch_mx8_as<F_DROP | F_RES>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
+    case F_DACT: return launch_mx8_as<F_DACT>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
+    case F_BETA: return launch_mx8_as<F_BETA>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
+    default: return launch_mx8_as<-1>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
+  }
+}
+
+/* q[r, c] (e4m3 bytes) and s[r, c / 32] (e8m0 bytes) of the bf16 matrix x [rows x cols] (cols % 32 == 0), MX blocks along a row. */
+extern "C" int st5_quant_mxfp8(const void* x, int64_t ld, void* q, int64_t q_ld, uint8_t* s, int64_t s_ld, int64_t rows, int32_t cols,
+                               void* stream) {
+  if (!x || !q || !s || rows < 0 || cols <= 0 || cols % 32) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  if (!aligned(x, 16) || !aligned(q, 16) || ld % 8 || q_ld % 16) return ST5_ERR_ALIGN;
+  const long long total = (long long)rows * (cols / 32);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(quant_mx8_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16_t*)x, (long long)ld,
+                     (unsigned char*)q, (long long)q_ld, (unsigned char*)s, (long long)s_ld, (long long)rows, (int)cols);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
 }
 
 #undef g_pending

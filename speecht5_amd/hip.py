@@ -74,6 +74,8 @@ _SIGS = {
                                    c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, c_float, c_float, c_uint64, c_int, c_void_p]),
     "st5_flash_attn_set_impl": (c_int, [c_int]),
+    "st5_gemm_mxfp8": (c_int, [POINTER(GemmParams), c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "st5_quant_mxfp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     "st5_flash_attn_qp_row": (c_int32, [c_int32]),
     "st5_flash_attn_qp_table": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_int, c_void_p]),
     "st5_conv0_gn_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
@@ -332,6 +334,40 @@ def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_
         profiler.records.append((variant, 2.0 * M * N * K * batch, e0, e1, (M, N, K, batch)))
         return
     check(lib().st5_gemm(byref(p), dtype, stream() if on is None else on.cuda_stream), "st5_gemm")
+
+
+def quant_mxfp8(x2):
+    """MX-fp8 image of a contiguous bf16 matrix [rows, cols] (cols % 32 == 0): (q uint8 [rows, cols], s uint8 [rows, cols/32])."""
+    rows, cols = x2.shape
+    assert x2.dtype == torch.bfloat16 and x2.stride(1) == 1 and cols % 32 == 0
+    q = torch.empty(rows, cols, dtype=torch.uint8, device=x2.device)
+    sc = torch.empty(rows, cols // 32, dtype=torch.uint8, device=x2.device)
+    check(lib().st5_quant_mxfp8(x2.data_ptr(), x2.stride(0), q.data_ptr(), cols, sc.data_ptr(), cols // 32, rows, cols, stream()), "st5_quant_mxfp8")
+    return q, sc
+
+
+def gemm_mxfp8(Aq, As, Bq, Bs, C, M, N, K, *, R=None, P=None, Cpre=None, bias=None, act=ACT_NONE, flags=0, alpha=1.0, beta=0.0,
+               dropout_p=0.0, seed=0):
+    """C (bf16 operand) = epilogue(Aq . Bq^T) on the block-scaled fp8 MFMA; Aq / Bq uint8 [rows, K] with scales As / Bs [rows, K/32]."""
+    p = GemmParams()
+    p.A, p.B, p.C = operand(Aq, Aq.stride(0)), operand(Bq, Bq.stride(0)), C
+    p.R = R if R is not None else _NULL_OP
+    p.P = P if P is not None else _NULL_OP
+    p.Cpre = Cpre if Cpre is not None else _NULL_OP
+    p.bias = ptr(bias)
+    p.bias_zs = 0
+    p.M, p.N, p.K, p.batch, p.zdiv = M, N, K, 1, 1
+    p.act, p.flags = act, flags
+    p.alpha, p.beta, p.dropout_p, p.seed = alpha, beta, dropout_p, seed
+    p.asum = 0
+    if profiler.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().st5_gemm_mxfp8(byref(p), As.data_ptr(), As.stride(0), Bs.data_ptr(), Bs.stride(0), stream()), "st5_gemm_mxfp8")
+        e1.record()
+        profiler.records.append(("fp8_NT", 2.0 * M * N * K, e0, e1, (M, N, K, 1)))
+        return
+    check(lib().st5_gemm_mxfp8(byref(p), As.data_ptr(), As.stride(0), Bs.data_ptr(), Bs.stride(0), stream()), "st5_gemm_mxfp8")
 
 
 # ---------------------------------------------------------------------------------------------
