@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+FP8_DENSE_PEAK_TFLOPS = 5000.0   # MI355X_MICROARCH.md: ~5 PFLOP/s dense fp8 (MX-scaled K = 64 / 128 forms)
 
 
 def build(device, compute_dtype, arch="base", layerdrop=0.05):
@@ -175,7 +176,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8: bf16 compute mode with the forward / data-gradient GEMMs of the large Linears on the block-scaled (MX) fp8 "
+                         "MFMA kernel, weight gradients bf16 (BASELINE.json configs[4]: --arch large --dtype fp8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=8, help="speech clips (10 s) per GPU per step")
     ap.add_argument("--arch", default="base", choices=["base", "large"],
@@ -222,7 +225,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from speecht5_amd import hip
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = torch.float32 if a.dtype == "f32" else torch.bfloat16
+    if a.dtype == "fp8":
+        from speecht5_amd import functional as _Fn
+        _Fn.set_fp8(True)
     # The update is captured into a HIP graph after the warm-up steps and REPLAYED in the timed region (fresh dropout
     # seeds / span masks / LayerDrop flags / lr per replay: speecht5_amd/graph.py).  ST5_GRAPH=0 or --no-graph: eager enqueue
     # (with the bucketed all-reduces overlapped with the backward when there are several ranks).
@@ -291,9 +297,9 @@ def main():
             print(f"#  {k[0]:8s} M={k[1]:7d} N={k[2]:6d} K={k[3]:7d} b={k[4]:4d}  x{n_:3d}  {t_ * 1e3:7.3f} ms  {t_ / n_ * 1e6:7.1f} us/launch  {f_ / t_ / 1e12:6.1f} TFLOP/s", file=sys.stderr)
     audio_seconds = a.batch * 10.0 * world * a.steps
     prof = hip.profiler.summary()
-    key = "bf16_NT" if a.dtype == "bf16" else "f32_NT"
+    key = {"bf16": "bf16_NT", "f32": "f32_NT", "fp8": "fp8_NT"}[a.dtype]
     n, flops, secs = prof.get(key, (0, 0.0, 0.0))
-    peak = BF16_DENSE_PEAK_TFLOPS if a.dtype == "bf16" else 157.3
+    peak = {"bf16": BF16_DENSE_PEAK_TFLOPS, "f32": 157.3, "fp8": FP8_DENSE_PEAK_TFLOPS}[a.dtype]
     # measured HBM bytes per launch of the same kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
     # (tools/pmc_traffic.sh), summary committed under profiles/ (the counters cannot be read from inside the process)
     traffic, traffic_src = None, None

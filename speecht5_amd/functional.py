@@ -435,6 +435,48 @@ def fused_weight_t(weights, dtype):
     return weight_cache.get(("wt", dtype) + tuple(id(w) for w in weights), weights, build)
 
 
+# -------------------------------------------------------------------------------------------------
+# MX-fp8 compute mode for the large Linears (BASELINE.json configs[4]: SpeechT5-Large, arch models/speecht5.py:1402-1425):
+# forward and data-gradient GEMMs of LinearFunction / FFNFunction run on st5_gemm_mxfp8 (block-scaled fp8 MFMA, twice the
+# bf16 rate), weight gradients stay bf16 (dW = dY^T X on the TN kernel, fp32 accumulation into the flat gradient buffer).
+# Activations / gradients are quantised per call (st5_quant_mxfp8: 32-element blocks along the reduction index), weights once
+# per optimizer step (cached with the other compute-dtype copies, dropped by weight_cache.clear()).
+# -------------------------------------------------------------------------------------------------
+_FP8 = SimpleNamespace(enabled=False, min_rows=512, min_n=512, launches=0)
+
+
+def set_fp8(enabled):
+    """MX-fp8 forward / data-gradient GEMMs for eligible Linears (bf16 compute mode only)."""
+    _FP8.enabled = bool(enabled)
+
+
+def fp8_enabled():
+    return _FP8.enabled
+
+
+def _fp8_ok(M, N, K, dtype):
+    """K = the reduction length: MX blocks of 32 along it, 128-byte k-tiles."""
+    return _FP8.enabled and dtype == torch.bfloat16 and K % 128 == 0 and N % 8 == 0 and M >= _FP8.min_rows and N >= _FP8.min_n
+
+
+def _quant_cached(kind, weights, mat):
+    """(q, scales) of a cached compute-dtype weight matrix, themselves cached until the parameters change."""
+    return weight_cache.get((kind,) + tuple(id(w) for w in weights), weights, lambda: hip.quant_mxfp8(mat))
+
+
+def _nt_gemm(a2, weights, transposed, C, M, N, K, dtype, **epi):
+    """C = epilogue(a2 . W^T) with W = stacked weights [N, K] (transposed: W = stack^T, the data-gradient form) -- on the MX-fp8
+    kernel when the mode is on and the shapes allow, else st5_gemm in the compute dtype."""
+    W = fused_weight_t(weights, dtype) if transposed else fused_weight(weights, dtype)
+    if _fp8_ok(M, N, K, dtype) and W.is_contiguous() and a2.is_contiguous():
+        Wq, Ws = _quant_cached("qt" if transposed else "q", weights, W)
+        aq, as_ = hip.quant_mxfp8(a2)
+        hip.gemm_mxfp8(aq, as_, Wq, Ws, C, M, N, K, **epi)
+        _FP8.launches += 1
+        return
+    hip.gemm(hip.operand(a2, a2.stride(0)), hip.operand(W, W.shape[1]), C, M, N, K, _dt(dtype), **epi)
+
+
 def fused_bias(biases):
     if all(b is None for b in biases):
         return None
@@ -715,7 +757,7 @@ class LinearFunction(torch.autograd.Function):
             res2 = _rows(residual)
             assert res2.shape == (M, N) and ldn == N
         if M > 0:
-            hip.gemm(hip.operand(x2, K), hip.operand(Wc, Wc.shape[1]), hip.operand(y, ldn), M, N, K, _dt(dtype),
+            _nt_gemm(x2, weights, False, hip.operand(y, ldn), M, N, K, dtype,
                      R=hip.operand(res2, ldn) if res2 is not None else None,
                      Cpre=hip.operand(pre, ldn) if pre is not None else None,
                      bias=bc, act=act, dropout_p=dropout_p, seed=seed)
@@ -755,8 +797,7 @@ class LinearFunction(torch.autograd.Function):
             dx = torch.empty(M, K, dtype=dtype, device=x2.device)
             if N % 8 == 0:
                 # dX = G . W as an NT GEMM against the cached transposed weights W^T [K, N]
-                Wt = fused_weight_t(weights, dtype)
-                hip.gemm(hip.operand(g, ldn), hip.operand(Wt, N), hip.operand(dx, K), M, K, N, _dt(dtype),
+                _nt_gemm(g, weights, True, hip.operand(dx, K), M, K, N, dtype,
                          R=hip.operand(extra, K) if extra is not None else None)
                 extra = None
             else:  # odd widths (vocabulary): B operand k-strided, W is [N, K], reduction over N
@@ -851,9 +892,9 @@ class FFNFunction(torch.autograd.Function):
         # epilogue of the dX GEMM instead of by a separate autograd accumulation kernel.
         res_is_x = isinstance(residual, str)
         res2 = x2 if res_is_x else (_rows(residual) if residual is not None else None)
-        hip.gemm(hip.operand(x2, d), hip.operand(W1, d), hip.operand(h, Fd), M, Fd, d, _dt(dtype), Cpre=hip.operand(hpre, Fd),
+        _nt_gemm(x2, [w1], False, hip.operand(h, Fd), M, Fd, d, dtype, Cpre=hip.operand(hpre, Fd),
                  bias=b1.detach(), act=act, dropout_p=p_act, seed=s1)
-        hip.gemm(hip.operand(h, Fd), hip.operand(W2, Fd), hip.operand(y, w2.shape[0]), M, w2.shape[0], Fd, _dt(dtype),
+        _nt_gemm(h, [w2], False, hip.operand(y, w2.shape[0]), M, w2.shape[0], Fd, dtype,
                  R=hip.operand(res2, w2.shape[0]) if res2 is not None else None, bias=b2.detach(), dropout_p=p_out, seed=s2)
         if p_out > 0:
             _tag_dropout_output(y, p_out, s2, M, w2.shape[0])
@@ -875,14 +916,12 @@ class FFNFunction(torch.autograd.Function):
             g = _dropped_grad(g, p_out, s2)
         # dHpre = (G . W2) * act'(Hpre) [* activation-dropout mask]   (fused epilogue)
         dh = torch.empty(M, Fd, dtype=dtype, device=x2.device)
-        W2t = fused_weight_t([w2], dtype)  # [Fd, dout]
-        hip.gemm(hip.operand(g, dout), hip.operand(W2t, dout), hip.operand(dh, Fd), M, Fd, dout, _dt(dtype),
+        _nt_gemm(g, [w2], True, hip.operand(dh, Fd), M, Fd, dout, dtype,     # (B operand: W2^T [Fd, dout])
                  P=hip.operand(hpre, Fd), act=act, flags=hip.DACT, dropout_p=p_act, seed=s1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, d, dtype=dtype, device=x2.device)
-            W1t = fused_weight_t([w1], dtype)  # [d, Fd]
-            hip.gemm(hip.operand(dh, Fd), hip.operand(W1t, Fd), hip.operand(dx, d), M, d, Fd, _dt(dtype),
+            _nt_gemm(dh, [w1], True, hip.operand(dx, d), M, d, Fd, dtype,     # (B operand: W1^T [d, Fd])
                      R=hip.operand(g_in, d) if res_is_x else None)
             dx = dx.view(xshape)
         # weight gradients last: both data-gradient GEMMs of the block are enqueued before the side stream forks
