@@ -447,6 +447,7 @@ struct BwdArgs {
   int B, H, T, S, nb, maxrel, causal, lds;
   float scale, dropout_p;
   unsigned long long seed;
+  int dvec_in_dq;   // 1: the dq kernel computes D = dO . O itself and writes dvec for the dkv kernel that follows it on the same stream
 };
 
 __global__ __launch_bounds__(256) void dvec_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ dvec,
@@ -548,7 +549,23 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
     dof[ks] = *reinterpret_cast<const bf16x8*>(a.dout + ((long long)b * a.T + qc) * a.do_ld + h * HD + ks * 16 + hi * 8);
   }
   const float lse2 = a.lse[(long long)bh * a.T + qc] * LOG2E;   // +inf for fully masked rows -> P = 0
-  const float dsum = a.dvec[(long long)bh * a.T + qc];
+  float dsum;
+  if (a.dvec_in_dq) {
+    // D[q] = dO[q] . O[q] here instead of in dvec_kernel (48 launches of ~6 us per update): the lane's 32 of the 64 head dims in
+    // the SAME order as dvec_kernel's thread (row, hi) -- ks-major, then element -- and the two halves added once, so the value is
+    // bit-identical; written out for the dkv kernel, which runs behind this one on the same stream
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.o + ((long long)b * a.T + qc) * a.o_ld + h * HD + ks * 16 + hi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf((float)dof[ks][e], (float)of[e], part);
+    }
+    dsum = part + __shfl_xor(part, 32, 64);
+    if (qvalid && hi == 0) a.dvec[(long long)bh * a.T + qi] = dsum;
+  } else {
+    dsum = a.dvec[(long long)bh * a.T + qc];
+  }
 
   int nkeys = a.S;
   if (a.causal) {
@@ -1107,7 +1124,11 @@ extern "C" int st5_flash_attn_bwd_2s(const void* q, int64_t q_ld, const void* k,
   hipStream_t s = (hipStream_t)stream, s2 = (hipStream_t)stream2;
   if (pe && hipMemsetAsync(dqp, 0, (size_t)B * H * T * nb * 2, s) != hipSuccess) return ST5_ERR_LAUNCH;
   const long long rows = (long long)B * H * T;
-  hipLaunchKernelGGL(fa2::dvec_kernel, dim3((unsigned)((rows * 2 + 255) / 256)), dim3(256), 0, s, a.o, a.dout, dvec, a.o_ld, a.do_ld, H, T, rows);
+  // one stream (the default): D = dO . O is computed by the dq kernel, which writes dvec for the dkv kernel behind it; with the
+  // helper stream (dq and dkv side by side) both need it up front
+  a.dvec_in_dq = (s2 == nullptr || s2 == s) ? 1 : 0;
+  if (!a.dvec_in_dq)
+    hipLaunchKernelGGL(fa2::dvec_kernel, dim3((unsigned)((rows * 2 + 255) / 256)), dim3(256), 0, s, a.o, a.dout, dvec, a.o_ld, a.do_ld, H, T, rows);
   if (s2) { if (st5_stream_fork(s, s2) != ST5_OK) return ST5_ERR_LAUNCH; } else s2 = s;
   const size_t shm_dq = (size_t)4 * fa2::TILE_B + (pe ? 4 * fa2::SCR_B : 0);
   const size_t shm_dkv = (size_t)2 * fa2::QBUF_B + (pe ? 4 * fa2::KSCR_B : 0);
