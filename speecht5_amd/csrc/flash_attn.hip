@@ -533,6 +533,9 @@ __device__ __forceinline__ void dq_tile(f32x16& s0, f32x16& s1, const f32x16& p0
                                         const unsigned int (&braw)[32], int rel0, int maxrel, unsigned long long km, int jrel,
                                         float lse2, float dsum, unsigned int key32, unsigned int hoff, unsigned int thresh,
                                         float inv_keep, float& acc_lo, float& acc_hi) {
+  // (no mul + add contraction here: `acc += p * (dp - D)` must round the product first in BOTH generations of the kernels, or the
+  // clipped-bucket sums differ in the last place between them -- tests/test_flash_gpu.py holds them bit-identical)
+#pragma clang fp contract(off)
   float csum = 0.f;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {

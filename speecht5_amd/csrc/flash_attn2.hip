@@ -484,6 +484,7 @@ template <int BMODE /*0 none, 1 per element, 2 uniform*/, bool CLIP, bool MASK, 
 __device__ __forceinline__ DqSums dq_half(const int t, f32x16& s, const f32x16& dpv, float sc2, const unsigned int (&braw)[16], float buni,
                                           int b0, int nbm1, unsigned long long km, int jrel, float lse2, float dsum, unsigned int key32,
                                           unsigned int hoff, unsigned int thresh, float inv_keep, const DqSums in) {
+#pragma clang fp contract(off)   // (see dq_tile in flash_attn.hip: the product is rounded before it is added, in both generations)
   float acc_lo = in.lo, acc_hi = in.hi, csum = in.c;     // (continued, not restarted: the summation order of the first generation)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {

@@ -21,7 +21,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 REL_TOL, COS_TOL = 1e-3, 0.99999
-BF16_COS, BF16_REL, BF16_POST_COS = 0.999, 5e-2, 0.98   # (measured at this shape: post-net >= 0.9934, everything else >= 0.99948)
+from tests.util import BF16_POST_COS   # (one bar for the mel post-net's bf16 gradients; measured here: 0.9934)
+BF16_COS, BF16_REL = 0.999, 5e-2      # (measured at this shape: everything outside the post-net >= 0.99948)
 BF16_LOOSE = {"quantizer.vars", "speech_decoder_postnet.feat_out.weight", "speech_decoder_postnet.feat_out.bias"}
 
 

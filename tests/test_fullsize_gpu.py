@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 REL_TOL, COS_TOL = 1e-3, 0.99999   # measured on MI355X: relative Frobenius error < 5e-6, cosine 1.0 for all ten tensors
-BF16_POST_COS = 0.98   # (one bar everywhere, VERDICT r3: the cfg-2-shape test measures 0.9934 inside the mel post-net)
+from tests.util import BF16_POST_COS   # (one bar for the mel post-net's bf16 gradients: tests/util.py)
 BF16_LOOSE = {"quantizer.vars", "speech_decoder_postnet.feat_out.weight", "speech_decoder_postnet.feat_out.bias"}
 BF16_COS, BF16_REL = 0.999, 5e-2   # bf16 compute mode vs the fp32 oracle, EVERY parameter
 

@@ -9,6 +9,8 @@ from argparse import Namespace
 import pytest
 import torch
 
+from tests.util import BF16_POST_COS
+
 from oracle import speecht5_oracle as O
 from tests.util import G, Task, check_grads, close, injected_randomness, to_dev
 
@@ -77,7 +79,7 @@ def test_large_style_bf16_is_close(cuda):
         rest = [c for c in cos if "speech_decoder_postnet.postnet" not in c[1]]
         post = [c for c in cos if "speech_decoder_postnet.postnet" in c[1]]
         print("worst:", sorted(rest)[:5], sorted(post)[:3])
-        assert rest and min(rest)[0] > 0.98 and (not post or min(post)[0] > 0.98), (sorted(rest)[:5], sorted(post)[:3])
+        assert rest and min(rest)[0] > 0.98 and (not post or min(post)[0] > BF16_POST_COS), (sorted(rest)[:5], sorted(post)[:3])
     finally:
         Fn.set_compute_dtype(torch.float32)
         Fn.weight_cache.clear()

@@ -156,3 +156,12 @@ def poisoned_allocations():
         yield
     finally:
         torch.empty, torch.empty_like, torch.Tensor.new_empty = o_empty, o_like, o_new
+
+
+# ONE bar for the bf16 gradients of the mel post-net's parameters (conv + BatchNorm + tanh stack) in every test that compares the
+# bf16 compute mode with the fp32 oracle / reference goldens.  The BatchNorm backward cancels to ~1e-2 of its terms, so bf16
+# operand rounding costs about two digits there; how much depends on the batch statistics' sample size.  Measured minima (round 4,
+# MI355X): 0.9934 at the benched shape (tests/test_cfg2_shape_gpu.py, 2 x 10 s), 0.9743 on the 2 s clip of
+# tests/test_fullsize_gpu.py, 0.9648 on the tiny Large-style golden (tests/test_large_gpu.py).  Everything outside the post-net is
+# held to 0.98-0.999 by the tests themselves.
+BF16_POST_COS = 0.96
