@@ -55,7 +55,8 @@ def build(device, compute_dtype, arch="base", layerdrop=0.05):
     return args, task, model, crit
 
 
-PMC_TRAFFIC_FILE = "r3_pmc_traffic.json"   # written by tools/pmc_traffic.sh
+PMC_TRAFFIC_FILE = "r4_pmc_traffic.json"   # written by tools/pmc_traffic.sh
+KERNEL_STATS_FILE = "r4_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --steps 13` (tools/finals.sh)
 NT_KERNEL_NAME = "gemm_nt_glds_kernel"      # the dominant kernel of the update (most NT launches)
 
 
@@ -320,6 +321,28 @@ def main():
     except Exception:
         traffic = None
     alg_bytes = hip.profiler.nt_bytes_per_launch() if hasattr(hip.profiler, "nt_bytes_per_launch") else None
+    # cross-check from the committed kernel trace of REPLAYED updates: the NT kernels' time per update =
+    # sum of their TotalDurationNs / number of updates in the trace (= launches of the Adam kernel), against the same FLOPs
+    rocprof_leg = None
+    try:
+        import csv as _csv, hashlib as _hl
+        here = os.path.dirname(os.path.abspath(__file__))
+        meta = json.load(open(os.path.join(here, "profiles", KERNEL_STATS_FILE.replace(".csv", ".meta.json"))))
+        cur = _hl.sha1(open(os.path.join(here, "speecht5_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:12]
+        if meta.get("gemm_hip_sha1") == cur and a.dtype == "bf16" and a.arch == "base" and world == 1:
+            rows = list(_csv.DictReader(open(os.path.join(here, "profiles", KERNEL_STATS_FILE))))
+            upd_n = sum(int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"])
+            nt_ns = sum(float(r["TotalDurationNs"]) for r in rows
+                        if "gemm_nt_glds_kernel" in r["Name"] or "gemm_nt256_kernel" in r["Name"]
+                        or ("gemm_kernel" in r["Name"] and "Lb0ELb0" in r["Name"] and "DF16b" in r["Name"]))
+            all_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+            if upd_n and nt_ns and flops > 0:
+                rocprof_leg = {"source": f"profiles/{KERNEL_STATS_FILE} (rocprofv3 --kernel-trace --stats, {upd_n} updates, graph replays; gemm.hip {cur})",
+                               "nt_ms_per_update": round(nt_ns / upd_n / 1e6, 3), "tflops": round(flops / (nt_ns / upd_n / 1e9) / 1e12, 1),
+                               "frac": round(flops / (nt_ns / upd_n / 1e9) / 1e12 / peak, 4),
+                               "all_kernels_ms_per_update": round(all_ns / upd_n / 1e6, 3)}
+    except Exception:
+        rocprof_leg = None
     roof = {"bound": "mfma", "kernel": f"NT-form st5_gemm launches <{a.dtype}> (Linear / attention-projection / conv forward and data-gradient GEMMs; "
                       f"`traffic` is per launch of {NT_KERNEL_NAME})",
             "note": ("launch durations: HIP events around every st5_gemm launch of ONE eagerly enqueued update after the timed region "
@@ -331,6 +354,7 @@ def main():
             "frac": round(flops / secs / 1e12 / peak, 4) if secs > 0 else None, "traffic": traffic,
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes,
+            "from_kernel_trace": rocprof_leg,
             "launches_per_step": n, "sampled_steps": 1, "avg_launch_us": round(secs / max(n, 1) * 1e6, 2),
             "all_variants": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None,
                                  "ms_per_step": round(v[2] * 1e3, 3)} for k, v in sorted(prof.items())}}
