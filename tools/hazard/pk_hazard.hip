@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void aggressor(float* __restrict__ sink, in
   if (s == 12345.678f) sink[blockIdx.x * 256 + tid] = s;   // keeps the accumulators live
 }
 
-struct Result { long launches = 0, wrong = 0; long quarter[4] = {0, 0, 0, 0}; std::vector<std::string> first; };
+struct Result { long launches = 0, wrong = 0; long quarter[4] = {0, 0, 0, 0}; std::vector<std::string> first; double victim_ms = 0; };
 
 template <bool PACKED, int AGG /*0 none, 1 plain, 2 padded*/>
 Result run(int rounds, int vblocks, int viters, int ablocks, int aiters) {
@@ -112,11 +112,16 @@ Result run(int rounds, int vblocks, int viters, int ablocks, int aiters) {
         else hipLaunchKernelGGL(aggressor<true>, dim3(ablocks), dim3(256), 0, sb, sink, aiters);
       }
     }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, sa));
     hipLaunchKernelGGL(victim<PACKED>, dim3(vblocks), dim3(64), 0, sa, out, viters);
+    CK(hipEventRecord(e1, sa));
     CK(hipGetLastError());
     CK(hipMemcpyAsync(host.data(), out, n * sizeof(float), hipMemcpyDeviceToHost, sa));
     CK(hipStreamSynchronize(sa));
     CK(hipStreamSynchronize(sb));
+    { float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1)); res.victim_ms += ms; CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1)); }
     ++res.launches;
     for (int b = 0; b < vblocks; ++b)
       for (int lane = 0; lane < 64; ++lane) {
@@ -142,8 +147,9 @@ Result run(int rounds, int vblocks, int viters, int ablocks, int aiters) {
 }
 
 void emit(const char* name, const Result& r, bool last) {
-  printf("\"%s\": {\"victim_launches\": %ld, \"wrong_lanes\": %ld, \"by_quarter_of_wave\": [%ld, %ld, %ld, %ld], \"first\": [", name, r.launches, r.wrong,
-         r.quarter[0], r.quarter[1], r.quarter[2], r.quarter[3]);
+  // victim_ms_mean: the victim grid's duration (HIP events on its stream) -- longer beside the aggressor = they really share the CUs
+  printf("\"%s\": {\"victim_launches\": %ld, \"victim_ms_mean\": %.3f, \"wrong_lanes\": %ld, \"by_quarter_of_wave\": [%ld, %ld, %ld, %ld], \"first\": [", name, r.launches,
+         r.launches ? r.victim_ms / r.launches : 0.0, r.wrong, r.quarter[0], r.quarter[1], r.quarter[2], r.quarter[3]);
   for (size_t i = 0; i < r.first.size(); ++i) printf("%s\"%s\"", i ? ", " : "", r.first[i].c_str());
   printf("]}%s", last ? "" : ", ");
 }
