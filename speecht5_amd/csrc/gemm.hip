@@ -1065,6 +1065,205 @@ __global__ __launch_bounds__(NT2) void gemm_nt256_kernel(const st5_gemm_params p
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// NT fast path, 256 x 256 block tile, PHASED schedule (round 4; cdna_hip_programming.md section 5 "The 256^2 8-phase template",
+// rebuilt on this file's 32x32x16 fragments, swizzle and epilogues).  512 threads = 8 waves as 2 (m) x 4 (n), wave tile 128 x 64,
+// k-tile 64 (128-byte rows).  LDS: two buffers x four HALF-tiles (A rows 0-127, A rows 128-255, B rows 0-127, B rows 128-255:
+// 128 rows x 128 B = 16 KB each, the 128^2 kernel's operand image) = 128 KB, one block per CU.
+// A k-tile is FOUR phases, each = {fragment reads + ONE half-tile of LDS-DMA staging} | barrier | 8 MFMAs (one 64 x 32 quadrant
+// of the wave tile over the whole k-tile) | barrier:
+//   phase 1: reads B cols 0-31 (4) then ALL A fragments (16); stages B0(t+1);      MFMA acc[0..1][0]
+//   phase 2:                                                   stages B1(t+1);      MFMA acc[2..3][0]
+//   phase 3: reads B cols 32-63 (4);                           stages A0(t+2);      MFMA acc[2..3][1]
+//   phase 4:                                                   stages A1(t+2); vmcnt(4);  MFMA acc[0..1][1]
+// A slots are last read in phase 1 and restaged from phase 3 (two phases later), B slots last read in phase 3 and restaged from the
+// next tile's phase 1; the ONE counted wait per k-tile (phase 4) leaves the two youngest half-tiles in flight and retires tile t+1
+// completely, one barrier before its first read; every half-tile has >= 3 phases (~1000 cycles) to land.  Two waves share a SIMD
+// (w and w + 4 = the two m-halves): with STAGGER the second half runs one barrier behind, so one wave of every SIMD is in its MFMA
+// section while the other issues reads / DMA, and s_setprio(1) around the MFMA sections has something to arbitrate.
+// ------------------------------------------------------------------------------------------------------
+template <int FEAT, bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_nt8p_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  typedef bf16_t T;
+  constexpr int BK = 64;
+  constexpr int HALF = TILE_BYTES;              // 16 KB: 128 rows x 128 B
+  constexpr int BUF = 4 * HALF;                 // A0 A1 B0 B1
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int z = blockIdx.z;
+  const int tiles_n = (p.N + 255) / 256;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
+    bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
+  const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
+  const OpAddr aa = make_addr(p.A.ld, p.A.bstride, 0, p.A.rpb, 0);
+  const OpAddr ab = make_addr(p.B.ld, p.B.bstride, 0, p.B.rpb, 0);
+
+  // LDS-DMA sources: half-tile h (0: A rows 0-127, 1: A rows 128-255, 2: B rows 0-127, 3: B rows 128-255), instruction i of this
+  // wave covers the half-tile's rows (i * 8 + wave) * 8 .. +7 (lane -> row + (lane >> 3), physical chunk lane & 7)
+  const T* src[4][2];
+  {
+    const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (i * 8 + wave) * 8 + rsub;
+      const int c = pc ^ ((row >> 1) & 7);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int gr = m0 + h * 128 + row; gr = gr < p.M ? gr : p.M - 1;
+        src[h][i] = Ap + aa.outer(gr) + c * 8;
+        int gc = n0 + h * 128 + row; gc = gc < p.N ? gc : p.N - 1;
+        src[2 + h][i] = Bp + ab.outer(gc) + c * 8;
+      }
+    }
+  }
+  auto stage = [&](const int h, const int kt) {        // half-tile h of k-tile kt -> buffer kt & 1
+    char* base = dsm + (kt & 1) * BUF + h * HALF + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[h][i] + (long long)kt * BK), (lds_ptr_t)(base + i * 8192), 16, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  // fragment byte offsets inside a half-tile: row = 32 * blk + frow (the swizzle term only sees frow), one per k16 group
+  int foff[4];
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) foff[kg] = lds_off(frow, 2 * kg + fhalf);
+  const int a_half = wr * HALF;                                    // this wave's A half-tile
+  const int b_base = (2 + (wc >> 1)) * HALF + (wc & 1) * 64 * 128; // its 64 B rows inside its B half-tile
+
+  // prologue: all of k-tile 0, the A halves of k-tile 1
+  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  if (nk > 1) { stage(0, 1); stage(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  bf16x8 af[4][4], bfr[4];
+  for (int t = 0; t < nk; ++t) {
+    const char* cur = dsm + (t & 1) * BUF;
+    // ---- phase 1 ----
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) bfr[kg] = *reinterpret_cast<const bf16x8*>(cur + b_base + foff[kg]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) af[i][kg] = *reinterpret_cast<const bf16x8*>(cur + a_half + i * 4096 + foff[kg]);
+    if (t + 1 < nk) stage(2, t + 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) { mma<T>(af[0][kg], bfr[kg], acc[0][0]); mma<T>(af[1][kg], bfr[kg], acc[1][0]); }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2 ----
+    if (t + 1 < nk) stage(3, t + 1);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) { mma<T>(af[2][kg], bfr[kg], acc[2][0]); mma<T>(af[3][kg], bfr[kg], acc[3][0]); }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3 ----
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) bfr[kg] = *reinterpret_cast<const bf16x8*>(cur + b_base + 4096 + foff[kg]);
+    if (t + 2 < nk) stage(0, t + 2);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) { mma<T>(af[2][kg], bfr[kg], acc[2][1]); mma<T>(af[3][kg], bfr[kg], acc[3][1]); }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4 ----
+    if (t + 2 < nk) { stage(1, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) { mma<T>(af[0][kg], bfr[kg], acc[0][1]); mma<T>(af[1][kg], bfr[kg], acc[1][1]); }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();     // (every wave executes the same number of barriers)
+  __syncthreads();
+
+  EpiArgs ea;
+  ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
+  ea.bias = p.bias ? p.bias + (long long)z * p.bias_zs : nullptr;
+  ea.c_ld = p.C.ld; ea.c_bs = p.C.bstride; ea.r_ld = p.R.ld; ea.r_bs = p.R.bstride;
+  ea.p_ld = p.P.ld; ea.p_bs = p.P.bstride; ea.q_ld = p.Cpre.ld; ea.q_bs = p.Cpre.bstride;
+  ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
+  ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
+  ea.atomic = 0;
+  ea.fast = c_vec_ok && (p.N % 8 == 0);
+  ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
+  ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
+  {
+    const long long zc = z_off(p.C.zs0, p.C.zs1, z, p.zdiv);
+    if (ea.out_f32) ea.C = reinterpret_cast<float*>(ea.C) + zc; else ea.C = reinterpret_cast<T*>(ea.C) + zc;
+    if (ea.R) {
+      const long long zr = z_off(p.R.zs0, p.R.zs1, z, p.zdiv);
+      if (ea.out_f32) ea.R = reinterpret_cast<const float*>(ea.R) + zr; else ea.R = reinterpret_cast<const T*>(ea.R) + zr;
+    }
+    if (ea.P) ea.P = reinterpret_cast<const T*>(ea.P) + z_off(p.P.zs0, p.P.zs1, z, p.zdiv);
+    if (ea.Cpre) ea.Cpre = reinterpret_cast<T*>(ea.Cpre) + z_off(p.Cpre.zs0, p.Cpre.zs1, z, p.zdiv);
+  }
+  float* stg = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
+  run_epilogue<T, FEAT>(ea, stg, acc[0][0], acc[0][1], acc[1][0], acc[1][1], m0 + wr * 128, n0 + wc * 64, lane);
+  run_epilogue<T, FEAT>(ea, stg, acc[2][0], acc[2][1], acc[3][0], acc[3][1], m0 + wr * 128 + 64, n0 + wc * 64, lane);
+}
+
+int g_p8_stagger = 1;     // st5_gemm_set_nt_tile(3 / 4): phased 256^2 kernel with / without the half-phase stagger of the two m-halves
+template <int FEAT>
+int launch_nt8p_as(const st5_gemm_params& p, int c_vec_ok, dim3 grid, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_nt8p_kernel<FEAT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_nt8p_kernel<FEAT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return ST5_ERR_LAUNCH;
+    attr = true;
+  }
+  if (g_p8_stagger) hipLaunchKernelGGL((gemm_nt8p_kernel<FEAT, true>), grid, dim3(512), (size_t)8 * TILE_BYTES, s, p, c_vec_ok);
+  else hipLaunchKernelGGL((gemm_nt8p_kernel<FEAT, false>), grid, dim3(512), (size_t)8 * TILE_BYTES, s, p, c_vec_ok);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+int nt_feat_of(const st5_gemm_params& p, int c_vec_ok);
+int launch_nt8p(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  dim3 grid(tiles, 1, p.batch);
+  switch (nt_feat_of(p, c_vec_ok)) {
+    case 0: return launch_nt8p_as<0>(p, c_vec_ok, grid, s);
+    case F_GELU | F_PRE: return launch_nt8p_as<F_GELU | F_PRE>(p, c_vec_ok, grid, s);
+    case F_DROP | F_RES: return launch_nt8p_as<F_DROP | F_RES>(p, c_vec_ok, grid, s);
+    case F_DACT: return launch_nt8p_as<F_DACT>(p, c_vec_ok, grid, s);
+    case F_BETA: return launch_nt8p_as<F_BETA>(p, c_vec_ok, grid, s);
+    default: return launch_nt8p_as<-1>(p, c_vec_ok, grid, s);
+  }
+}
+
 template <typename T>
 int launch_nt256(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
   const int tiles = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
@@ -1684,6 +1883,10 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   const int bk = 128 / es;
   if (g_use_glds && !p.asum && !(p.flags & (ST5_GEMM_A_KSTRIDED | ST5_GEMM_B_KSTRIDED)) && p.K % bk == 0 && p.K >= 2 * bk && !p.A.seg && !p.B.seg)
   {
+    if ((g_nt_tile == 3 || g_nt_tile == 4) && dtype == ST5_BF16 && p.K % 64 == 0) {
+      g_p8_stagger = g_nt_tile == 3;
+      return launch_nt8p(p, c_vec_ok, s);
+    }
     bool big = false;
     if (g_nt_tile == 2) big = true;
     else if (g_nt_tile == 0) big = nt256_pays(p.M, p.N, p.K / bk, p.batch);
@@ -1778,4 +1981,4 @@ extern "C" int st5_gemm_set_deep_ring(int max_blocks, int nbuf) {
   if (max_blocks < 0 || nbuf < 2 || nbuf > 4) return ST5_ERR_ARG;
   g_deep_blocks = max_blocks; g_deep_nbuf = nbuf; return ST5_OK;
 }
-extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 2) return ST5_ERR_ARG; g_nt_tile = mode; return ST5_OK; }
+extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 4) return ST5_ERR_ARG; g_nt_tile = mode; return ST5_OK; }

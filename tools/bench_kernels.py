@@ -58,7 +58,7 @@ if __name__ == "__main__":
             bias = torch.randn(N, device=dev); R = torch.randn(M, N, device=dev).to(dtype)
             outs = []
             line = f"M={M:6d} N={N:5d} K={K:5d}"
-            for mode in ((2,) if os.environ.get("NT256_ONLY") else (1, 2, 0)):
+            for mode in ((2,) if os.environ.get("NT256_ONLY") else tuple(int(m) for m in os.environ.get("NT_MODES", "1,2,0").split(","))):
                 L.st5_gemm_set_nt_tile(mode)
                 C = torch.zeros(M, N, device=dev, dtype=dtype)
                 if len(sys.argv) > 2 and sys.argv[2] == "plain":

@@ -7,6 +7,8 @@ dev = torch.device("cuda:0")
 M, N, K = (int(x) for x in os.environ.get("SHAPE", "8192,3072,768").split(","))
 form = os.environ.get("FORM", "NT")
 dt = torch.bfloat16
+if os.environ.get("ST5_NT_TILE"):
+    hip.lib().st5_gemm_set_nt_tile(int(os.environ["ST5_NT_TILE"]))
 if form == "NT":
     A = torch.randn(M, K, device=dev).to(dt); B = torch.randn(N, K, device=dev).to(dt); C = torch.empty(M, N, device=dev, dtype=dt)
     f = lambda: hip.gemm(hip.operand(A, K), hip.operand(B, K), hip.operand(C, N), M, N, K, hip.BF16)
