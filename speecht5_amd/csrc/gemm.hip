@@ -1580,16 +1580,18 @@ bool tn_glds_ok(const st5_gemm_params& p, int dtype) {
   return aligned(p.A.ptr, 16) && aligned(p.B.ptr, 16);
 }
 
-// Block-tile choice for the NT path (tools/bench_kernels.py nt256, MI355X): the 256^2 kernel keeps one block per CU and its
-// epilogue (128 KB of stores per block, ~10 us, nothing co-resident to overlap with) is exposed, so it only pays when
-// there are several rounds of full-chip work to amortise that over: the conv feature-extractor GEMMs (M = 64k..128k:
-// 0.79 vs 0.62-0.66 PFLOP/s) and large square problems.  The transformer shapes (<= 400 tiles) stay on 128^2.
-bool nt256_pays(int M, int N, int nk, int batch) {
-  (void)nk;
+// Block-tile choice for the NT path (tools/bench_kernels.py nt256 with NT_MODES=1,3; tools/gemm_cases.py with ST5_NT_TILE=3; MI355X,
+// round 4).  The phased 256^2 kernel keeps one block per CU, so its prologue and its epilogue (128 KB of stores per block) are
+// exposed (~6.5 us per tile against 1.8 us per 64-deep k-step): it pays when there are several rounds of full-chip work to amortise
+// that over -- the conv feature-extractor GEMMs (M = 32k..128k: 0.92-1.0 PFLOP/s against 0.70-0.80 on 128^2 tiles), large square
+// problems (8192^3: 1.20 against 0.89) -- or when ONE round of 256^2 tiles nearly fills the chip with a short reduction (3992 x 3072 x
+// 768: 192 tiles, 27.8 against 30.6 us).  Everything else of the transformer (96-384 tiles in 1.1-2 rounds, or long K on few tiles)
+// stays on 128^2, two blocks per CU.
+bool nt256_pays(int M, int N, int nk64, int batch) {
   const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
-  return t256 >= 448;
+  if (t256 >= 448) return true;
+  return t256 >= 176 && t256 <= 256 && nk64 <= 16;
 }
-
 
 // ------------------------------------------------------------------------------------------------------
 // MX-fp8 NT path (BASELINE.json configs[4]: SpeechT5-Large with fp8 MFMA GEMMs; arch models/speecht5.py:1402-1425).
@@ -1887,10 +1889,12 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
       g_p8_stagger = g_nt_tile == 3;
       return launch_nt8p(p, c_vec_ok, s);
     }
-    bool big = false;
-    if (g_nt_tile == 2) big = true;
-    else if (g_nt_tile == 0) big = nt256_pays(p.M, p.N, p.K / bk, p.batch);
-    if (big) return dtype == ST5_BF16 ? launch_nt256<bf16_t>(p, c_vec_ok, s) : launch_nt256<float>(p, c_vec_ok, s);
+    if (g_nt_tile == 2) return dtype == ST5_BF16 ? launch_nt256<bf16_t>(p, c_vec_ok, s) : launch_nt256<float>(p, c_vec_ok, s);
+    if (g_nt_tile == 0 && nt256_pays(p.M, p.N, p.K / 64, p.batch)) {
+      // bf16: the phased kernel (round 4); fp32 parity mode: the first 256^2 kernel (4-stage ring)
+      if (dtype == ST5_BF16 && p.K % 64 == 0) { g_p8_stagger = 1; return launch_nt8p(p, c_vec_ok, s); }
+      if (dtype != ST5_BF16) return launch_nt256<float>(p, c_vec_ok, s);
+    }
     return dtype == ST5_BF16 ? launch_glds<bf16_t>(p, c_vec_ok, s) : launch_glds<float>(p, c_vec_ok, s);
   }
   if (g_use_glds && tn_glds_ok(p, dtype)) return launch_tn_glds(p, c_vec_ok, nsplit, s);
