@@ -99,10 +99,14 @@ int st5_gemm(const st5_gemm_params* p, int dtype, void* stream);
  * optimizer / gradient all-reduce needs them) on a second stream beside the data-gradient chain. */
 int st5_stream_fork(void* from_stream, void* to_stream);
 int st5_gemm_set_glds(int enabled);
-/* NT block tile: 0 = chosen per problem (default), 1 = 128x128 always, 2 = 256x256 always (A/B measurements only). */
+/* NT block tile: 0 = chosen per problem (default), 1 = 128x128 always, 2 = first 256x256 kernel always, 3 / 4 = phased 256x256 kernel always
+ * with / without the half-phase stagger (A/B measurements only). */
 int st5_gemm_set_nt_tile(int mode);
 /* Block count the split-K choice of the fp32-output (weight-gradient) GEMMs aims for; default 384 (1.5 per CU). */
 int st5_gemm_set_splitk_target(int blocks);
+/* Weight-gradient (TN form, no row split / segments) GEMMs: 0 (default) = always the 128x128 LDS-DMA kernel; 1 = phased 256x256 kernel with
+ * its own split-K count (M, N multiples of 256, K >= 512), 2 = the same without the half-phase stagger (A/B measurements only). */
+int st5_gemm_set_tn_phased(int mode);
 /* 128x128 NT kernel: grids of at most max_blocks blocks (one per CU) use an nbuf-stage operand ring (2 = never; default 256, 4). */
 int st5_gemm_set_deep_ring(int max_blocks, int nbuf);
 /* Batch the slab reductions of split-K GEMMs (weight gradients): while enabled, a split-K st5_gemm only queues its reduction;

@@ -743,6 +743,14 @@ __device__ unsigned long long g_gemm_timing[8];
 #define GPROBE(i)
 #endif
 
+template <typename F, int OFF>
+__device__ __forceinline__ F lds_read128_asm(const unsigned lds_addr) {
+  static_assert(sizeof(F) == 16, "128-bit fragment");
+  F v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+  return v;
+}
+
 template <typename T, int NBUF, int FEAT = -1>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
   ST5_PAD_TO_256_VGPRS();
@@ -804,6 +812,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
     if (t < nk) issue(t, t);
   const int frow = lane & 31, fhalf = lane >> 5;
   const int arow0 = wr * 64 + frow, brow0 = wc * 64 + frow;
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)dsm;
+  const unsigned a_addr0 = lds_off(arow0, fhalf), b_addr0 = lds_off(brow0, fhalf);
   GPROBE(0);
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed when at most the 8 loads of tile kt+1 are still outstanding
@@ -820,19 +830,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
 #if GEMM_ABL != 2
     if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
 #endif
-    const char* cur = dsm + (kt % NBUF) * 2 * TILE_BYTES;
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      const frag_t a0 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0, kg * 2 + fhalf));
-      const frag_t a1 = *reinterpret_cast<const frag_t*>(cur + lds_off(arow0 + 32, kg * 2 + fhalf));
-      const frag_t b0 = *reinterpret_cast<const frag_t*>(cur + TILE_BYTES + lds_off(brow0, kg * 2 + fhalf));
-      const frag_t b1 = *reinterpret_cast<const frag_t*>(cur + TILE_BYTES + lds_off(brow0 + 32, kg * 2 + fhalf));
+    // Fragments double-buffered in registers: the four reads of k-group kg + 1 are issued before the MFMAs of group kg, and each group
+    // waits only for its own reads (LDS returns in order: lgkmcnt(4) = "all but the four newest").  Written as inline asm because hipcc
+    // keeps the source order "read, wait for everything, multiply" per group otherwise (and, given both sets, still waits with
+    // lgkmcnt(0)) -- one exposed LDS round trip per k-group instead of one per k-tile.  addr(kg) = addr(0) ^ (kg << 5): the swizzle
+    // XORs the chunk index, the k-group is bits 1-2 of it.
+    const unsigned cb = lds_base + (kt % NBUF) * 2 * TILE_BYTES;
+    const unsigned pa = cb + a_addr0, pb = cb + b_addr0;
+    frag_t fa0[2], fa1[2], fb0[2], fb1[2];
+#define NT_READ(S, KG)                                                                                      \
+  fa0[S] = lds_read128_asm<frag_t, 0>(pa ^ ((KG) << 5)); fb0[S] = lds_read128_asm<frag_t, TILE_BYTES>(pb ^ ((KG) << 5));          \
+  fa1[S] = lds_read128_asm<frag_t, 4096>(pa ^ ((KG) << 5)); fb1[S] = lds_read128_asm<frag_t, TILE_BYTES + 4096>(pb ^ ((KG) << 5));
+#define NT_WAIT(S, CNT)                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa0[S]), "+v"(fa1[S]), "+v"(fb0[S]), "+v"(fb1[S]) :: "memory");
 #if GEMM_ABL == 3
-      asm volatile("" :: "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+#define NT_MMA(S) asm volatile("" :: "v"(fa0[S]), "v"(fa1[S]), "v"(fb0[S]), "v"(fb1[S]));
 #else
-      mma<T>(a0, b0, acc00); mma<T>(a0, b1, acc01); mma<T>(a1, b0, acc10); mma<T>(a1, b1, acc11);
+#define NT_MMA(S)                                                                                           \
+  mma<T>(fa0[S], fb0[S], acc00); mma<T>(fa0[S], fb1[S], acc01); mma<T>(fa1[S], fb0[S], acc10); mma<T>(fa1[S], fb1[S], acc11);
 #endif
-    }
+    NT_READ(0, 0)
+    NT_READ(1, 1)
+    NT_WAIT(0, 4)
+    NT_MMA(0) __builtin_amdgcn_sched_barrier(0);
+    NT_READ(0, 2)
+    NT_WAIT(1, 4)
+    NT_MMA(1) __builtin_amdgcn_sched_barrier(0);
+    NT_READ(1, 3)
+    NT_WAIT(0, 4)
+    NT_MMA(0) __builtin_amdgcn_sched_barrier(0);
+    NT_WAIT(1, 0)
+    NT_MMA(1) __builtin_amdgcn_sched_barrier(0);
+#undef NT_READ
+#undef NT_WAIT
+#undef NT_MMA
     GPROBE(2);
   }
   __syncthreads();
@@ -1396,6 +1427,21 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile_row, int off0, int of
   return u.v;
 }
 
+// Transpose-read fragment as inline asm.  The builtin form makes hipcc treat the read as a possible alias of the in-flight LDS-DMA
+// writes and put s_waitcnt vmcnt(0) in front of it -- in the 128^2 kernel that serialised a k-tile's fragment reads and MFMAs behind the NEXT
+// tile's DMA (no overlap inside a block), in the phased kernel it drained the DMA queue twice per k-tile (4.5 us per k-tile against
+// 1.8 us for the NT kernel's plain ds_read_b128).  The asm read is invisible to that analysis; the kernels'
+// own vmcnt + barrier order the DMA against it, and their lgkmcnt waits (tied to the fragment registers) sit in front of the MFMAs.
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_frag_asm(const unsigned lds_addr) {
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(lds_addr), "n"(OFF) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(lds_addr), "n"(OFF + 1024) : "memory");
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
 template <int FEAT>   // (epilogue features, see epilogue_fast; >= 0: fp32 output in the fast layout, compile-time feature set)
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
   ST5_PAD_TO_256_VGPRS();
@@ -1509,23 +1555,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   f32x16 sum0, sum1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { sum0[r] = 0.f; sum1[r] = 0.f; }
+  // k-loop: the next tile's DMA is in flight while this tile is read and multiplied; fragments are double-buffered in registers (the reads
+  // of k16-group kg + 1 are issued before the MFMAs of group kg, lgkmcnt(8) = "all but the 8 newest reads have landed").
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)dsm;
+  bf16x8 fa0[2], fa1[2], fb0[2], fb1[2];
+#define TN_READ(S, KG)                                                                                      \
+  fa0[S] = tr_frag_asm<(KG) * 4096>(pa0); fb0[S] = tr_frag_asm<TILE_BYTES + (KG) * 4096>(pb0);             \
+  fa1[S] = tr_frag_asm<(KG) * 4096>(pa1); fb1[S] = tr_frag_asm<TILE_BYTES + (KG) * 4096>(pb1);
+#define TN_WAIT(S, CNT)                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa0[S]), "+v"(fa1[S]), "+v"(fb0[S]), "+v"(fb1[S]) :: "memory");
+#define TN_MMA(S)                                                                                           \
+  mma<T>(fa0[S], fb0[S], acc00); mma<T>(fa0[S], fb1[S], acc01); mma<T>(fa1[S], fb0[S], acc10); mma<T>(fa1[S], fb1[S], acc11); \
+  if (do_asum) { mma<T>(fa0[S], ones_frag<T>(), sum0); mma<T>(fa1[S], ones_frag<T>(), sum1); }
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + 1 < nk) issue(kt0 + kt + 1, (kt + 1) & 1);
-    const char* cur = dsm + (kt & 1) * 2 * TILE_BYTES;
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      const char* ta = cur + kg * 16 * 256;
-      const char* tb = ta + TILE_BYTES;
-      const bf16x8 a0 = tr_frag(ta, oa0, oa0 + 4 * 256);
-      const bf16x8 a1 = tr_frag(ta, oa1, oa1 + 4 * 256);
-      const bf16x8 b0 = tr_frag(tb, ob0, ob0 + 4 * 256);
-      const bf16x8 b1 = tr_frag(tb, ob1, ob1 + 4 * 256);
-      mma<T>(a0, b0, acc00); mma<T>(a0, b1, acc01); mma<T>(a1, b0, acc10); mma<T>(a1, b1, acc11);
-      if (do_asum) { mma<T>(a0, ones_frag<T>(), sum0); mma<T>(a1, ones_frag<T>(), sum1); }
-    }
+    const unsigned cur = lds_base + (kt & 1) * 2 * TILE_BYTES;
+    const unsigned pa0 = cur + oa0, pa1 = cur + oa1, pb0 = cur + ob0, pb1 = cur + ob1;
+    TN_READ(0, 0)
+    TN_READ(1, 1)
+    TN_WAIT(0, 8)
+    TN_MMA(0) __builtin_amdgcn_sched_barrier(0);
+    TN_READ(0, 2)
+    TN_WAIT(1, 8)
+    TN_MMA(1) __builtin_amdgcn_sched_barrier(0);
+    TN_READ(1, 3)
+    TN_WAIT(0, 8)
+    TN_MMA(0) __builtin_amdgcn_sched_barrier(0);
+    TN_WAIT(1, 0)
+    TN_MMA(1) __builtin_amdgcn_sched_barrier(0);
   }
+#undef TN_READ
+#undef TN_WAIT
+#undef TN_MMA
   __syncthreads();
   if (do_asum) { bool acc_; float* dst_ = asum_target(p, acc_); flush_asum(dst_, acc_, sum0, sum1, m0 + wr * 64, p.M, lane); }
 
@@ -1553,6 +1616,245 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   }
   float* stage = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
   run_epilogue<T, FEAT, float>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// TN fast path, 256 x 256 block tile, PHASED schedule (round 4): the weight-gradient form C[M, N] = A^T B (A = dY [K, M], B = X [K, N],
+// both k-strided, fp32 output) on the schedule of gemm_nt8p_kernel -- four phases per 64-deep k-tile, one half-tile of LDS-DMA staging per
+// phase, one counted vmcnt per k-tile, the two m-halves half a phase apart -- with the operand images and transpose-read fragments of
+// gemm_tn_glds_kernel: a half-tile is [64 k][128 m] (16 KB, 16-byte chunks XOR 4 * (k & 3)), fragments by ds_read_b64_tr_b16.
+// Weight gradients are long reductions (K = tokens: 2.5k-8k) over few output tiles (9-36 of 256 x 256): split-K over blockIdx.y brings
+// the grid to about one block per CU, every split stores its fp32 slab (the batched slab reduction of st5_gemm sums them).
+// The bias gradient dY^T . 1 (p.asum) is summed on the VALU from the A fragments the waves of the first tile column hold anyway
+// (four floats per lane; the 128^2 kernel spends an extra MFMA column on it), in a fixed order: deterministic, no atomics.
+// Not here: row-split / segmented operands (conv weight gradients) -- those stay on gemm_tn_glds_kernel.
+// ------------------------------------------------------------------------------------------------------
+template <int FEAT, bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_tn8p_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  typedef bf16_t T;
+  constexpr int BK = 64;
+  constexpr int HALF = TILE_BYTES;
+  constexpr int BUF = 4 * HALF;
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (p.N + 255) / 256;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
+    bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const T* Ap = reinterpret_cast<const T*>(p.A.ptr);
+  const T* Bp = reinterpret_cast<const T*>(p.B.ptr);
+
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int per = (nk_all + gridDim.y - 1) / gridDim.y;
+  const int kt0 = blockIdx.y * per;
+  int nk = nk_all - kt0; nk = nk < per ? nk : per; nk = nk > 0 ? nk : 0;
+
+  // LDS-DMA sources.  Instruction i of this wave covers half-tile rows (k) (i * 8 + wave) * 4 .. +3: lane l -> row + (l >> 4), physical
+  // chunk l & 15, logical chunk (l & 15) ^ 4 * (l >> 4).  M and N are multiples of 256 here (tn8p_ok), so every column chunk is inside
+  // the matrix and all lanes advance by the same (scalar) stride; only rows past K (the problem's last k-tile) read the zero page.
+  // (Per-lane strides and column predicates cost the two registers that made hipcc spill inside the k-loop -- and a spill reload is an
+  // ordinary VMEM load whose vmcnt(0) drains the LDS-DMA queue every k-tile: 5.6 us per k-tile instead of 1.8.)
+  const int lrow = lane >> 4;
+  const int lchunk = (lane & 15) ^ (4 * lrow);
+  const T* const zero = reinterpret_cast<const T*>(g_zero_page) + (lane & 15) * 8;
+  const long long astep = (long long)BK * p.A.ld, bstep = (long long)BK * p.B.ld;
+  const T* src[4][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long k = (long long)kt0 * BK + (i * 8 + wave) * 4 + lrow;
+      src[h][i] = Ap + k * p.A.ld + (m0 + h * 128 + lchunk * 8);
+      src[2 + h][i] = Bp + k * p.B.ld + (n0 + h * 128 + lchunk * 8);
+    }
+  auto stage = [&](const int h, const int kt) {        // half-tile h of this block's k-tile kt (absolute tile kt0 + kt) -> buffer kt & 1
+    char* base = dsm + (kt & 1) * BUF + h * HALF + wave * 1024;
+    if ((long long)(kt0 + kt + 1) * BK <= p.K) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src[h][i], (lds_ptr_t)(base + i * 8192), 16, 0, 0);
+        src[h][i] += h < 2 ? astep : bstep;
+      }
+    } else {   // the problem's last, partial k-tile: rows past K come from the zero page
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const long long k = (long long)(kt0 + kt) * BK + (i * 8 + wave) * 4 + lrow;
+        const T* sp = k < p.K ? src[h][i] : zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)sp, (lds_ptr_t)(base + i * 8192), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transpose-read addressing (gemm_tn_glds_kernel): group g = m sub-block of 16, hh = k half, jj = k row inside a 4-row group, q
+  const int g = (lane >> 4) & 1, hh = lane >> 5, jj = (lane & 15) >> 2, q = lane & 3;
+  auto frag_off = [&](int mbase) {
+    const int m = mbase + 16 * g + 4 * q;
+    const int pos = (m >> 3) ^ (4 * jj);
+    return (8 * hh + jj) * 256 + pos * 16 + ((m >> 2) & 1) * 8;
+  };
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = wr * HALF + frag_off(32 * i);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) boff[j] = (2 + (wc >> 1)) * HALF + frag_off((wc & 1) * 64 + 32 * j);
+
+  const bool do_asum = p.asum != nullptr && tn == 0 && wc == 0;
+  float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+    if (nk > 1) { stage(0, 1); stage(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  bf16x8 af[4][4], bfr[4];
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)dsm;
+  for (int t = 0; t < nk; ++t) {
+    const unsigned cur = lds_base + (t & 1) * BUF;
+    // ---- phase 1: B cols 0-31, all A; stage B0(t+1) ----
+    bfr[0] = tr_frag_asm<0>(cur + boff[0]); bfr[1] = tr_frag_asm<4096>(cur + boff[0]);
+    bfr[2] = tr_frag_asm<8192>(cur + boff[0]); bfr[3] = tr_frag_asm<12288>(cur + boff[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = tr_frag_asm<0>(cur + aoff[i]); af[i][1] = tr_frag_asm<4096>(cur + aoff[i]);
+      af[i][2] = tr_frag_asm<8192>(cur + aoff[i]); af[i][3] = tr_frag_asm<12288>(cur + aoff[i]);
+    }
+    if (t + 1 < nk) stage(2, t + 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) { mma<T>(af[0][kg], bfr[kg], acc[0][0]); mma<T>(af[1][kg], bfr[kg], acc[1][0]); }
+    __builtin_amdgcn_s_setprio(0);
+    if (do_asum) {   // bias gradient: row sums of A^T from the fragments in registers (lane: row 32 i + (lane & 31), 8 k of every 16)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rsum[i] += (float)af[i][kg][e];
+    }
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: stage B1(t+1) ----
+    if (t + 1 < nk) stage(3, t + 1);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) { mma<T>(af[2][kg], bfr[kg], acc[2][0]); mma<T>(af[3][kg], bfr[kg], acc[3][0]); }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: B cols 32-63; stage A0(t+2) ----
+    bfr[0] = tr_frag_asm<0>(cur + boff[1]); bfr[1] = tr_frag_asm<4096>(cur + boff[1]);
+    bfr[2] = tr_frag_asm<8192>(cur + boff[1]); bfr[3] = tr_frag_asm<12288>(cur + boff[1]);
+    if (t + 2 < nk) stage(0, t + 2);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) { mma<T>(af[2][kg], bfr[kg], acc[2][1]); mma<T>(af[3][kg], bfr[kg], acc[3][1]); }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4: stage A1(t+2); the one counted wait of the k-tile ----
+    if (t + 2 < nk) { stage(1, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) { mma<T>(af[0][kg], bfr[kg], acc[0][1]); mma<T>(af[1][kg], bfr[kg], acc[1][1]); }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+  __syncthreads();
+
+  if (do_asum) {
+    bool accumulate; float* dst = asum_target(p, accumulate);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = rsum[i] + __shfl_xor(rsum[i], 32, 64);
+      const int row = m0 + wr * 128 + 32 * i + (lane & 31);
+      if (hh == 0 && row < p.M) dst[row] = accumulate ? dst[row] + v : v;
+    }
+  }
+
+  EpiArgs ea;
+  ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
+  ea.bias = p.bias;
+  ea.c_ld = p.C.ld; ea.c_bs = p.C.bstride; ea.r_ld = p.R.ld; ea.r_bs = p.R.bstride;
+  ea.p_ld = p.P.ld; ea.p_bs = p.P.bstride; ea.q_ld = p.Cpre.ld; ea.q_bs = p.Cpre.bstride;
+  ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
+  ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
+  ea.atomic = 0;
+  ea.fast = c_vec_ok && (p.N % 8 == 0);
+  if (gridDim.y > 1) ea.C = reinterpret_cast<float*>(ea.C) + (long long)blockIdx.y * p.M * p.N;
+  ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
+  ea.ctr_base = 0ull;
+  float* stg = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
+  run_epilogue<T, FEAT, float>(ea, stg, acc[0][0], acc[0][1], acc[1][0], acc[1][1], m0 + wr * 128, n0 + wc * 64, lane);
+  run_epilogue<T, FEAT, float>(ea, stg, acc[2][0], acc[2][1], acc[3][0], acc[3][1], m0 + wr * 128 + 64, n0 + wc * 64, lane);
+}
+
+int g_tn8p = 0;   // st5_gemm_set_tn_phased: 0 (default) = always the 128^2 kernel; 1 / 2 = eligible weight-gradient GEMMs on the phased 256^2 kernel (staggered / not).
+                  // Measured (profiles/r4_gemm_tn_phased.txt): the phased kernel wins only on very long reductions over few tiles (512 x 1536 x 128k:
+                  // 335 vs 343 us); on the transformer weight gradients its 256^2 tiles need 2x the split-K slabs and lose 20-35 %.
+bool tn8p_ok(const st5_gemm_params& p, int c_vec_ok) {
+  if (!g_tn8p || p.batch != 1 || p.A.rpb || p.B.rpb || p.A.seg || p.B.seg) return false;
+  if (!c_vec_ok || p.N % 8 || !(p.flags & ST5_GEMM_OUT_F32) || (p.flags & ST5_GEMM_DACT) || p.act != ACT_NONE || p.dropout_p != 0.f ||
+      p.R.ptr || p.Cpre.ptr || p.bias)
+    return false;
+  return p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 512;
+}
+// split count of the phased kernel: about one block per CU, at least four k-tiles per split
+int tn8p_splits(const st5_gemm_params& p) {
+  const long long tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const int nk = (p.K + 63) / 64;
+  long long want = (256 + tiles - 1) / tiles;
+  long long maxs = nk / 4;
+  int ns = (int)(want < maxs ? want : maxs);
+  if (ns < 1) ns = 1;
+  const int per = (nk + ns - 1) / ns;
+  return (nk + per - 1) / per;
+}
+int launch_tn8p(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    const void* fns[] = {(const void*)gemm_tn8p_kernel<0, true>, (const void*)gemm_tn8p_kernel<F_BETA, true>,
+                         (const void*)gemm_tn8p_kernel<0, false>, (const void*)gemm_tn8p_kernel<F_BETA, false>};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
+    attr = true;
+  }
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  dim3 grid(tiles, nsplit, 1), block(512);
+  const size_t shm = (size_t)8 * TILE_BYTES;
+  if (p.beta == 0.f) {
+    if (g_tn8p == 2) hipLaunchKernelGGL((gemm_tn8p_kernel<0, false>), grid, block, shm, s, p, c_vec_ok);
+    else hipLaunchKernelGGL((gemm_tn8p_kernel<0, true>), grid, block, shm, s, p, c_vec_ok);
+  } else {
+    if (g_tn8p == 2) hipLaunchKernelGGL((gemm_tn8p_kernel<F_BETA, false>), grid, block, shm, s, p, c_vec_ok);
+    else hipLaunchKernelGGL((gemm_tn8p_kernel<F_BETA, true>), grid, block, shm, s, p, c_vec_ok);
+  }
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
 }
 
 int launch_tn_glds(const st5_gemm_params& p, int c_vec_ok, int nsplit, hipStream_t s) {
@@ -1829,6 +2131,9 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
       nsplit = (nk + per - 1) / per;
     }
   }
+  // weight gradients without row split / segments: the phased 256^2 kernel with its own split count (about one block per CU)
+  const bool use8p = dtype == ST5_BF16 && g_use_glds && tn_glds_ok(p, dtype) && tn8p_ok(p, c_vec_ok) && p.C.ld % 4 == 0;
+  if (use8p) nsplit = tn8p_splits(p);
   if (nsplit > 1 && g_defer && (p.flags & ST5_GEMM_DEFERRABLE) && !p.C.rpb && p.C.ld % 4 == 0) {
     const size_t need = ((size_t)nsplit * p.M * p.N + (p.asum ? (size_t)nsplit * p.M : 0)) * sizeof(float);
     // the same output twice in one batch (tied weights) would race inside the batched reduction: fold what is pending first
@@ -1853,7 +2158,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
     }
     st5_gemm_params q = p;
     q.C.ptr = slabs; q.C.ld = p.N; q.C.rpb = 0; q.C.bstride = 0; q.C.zs0 = q.C.zs1 = 0; q.beta = 0.f;
-    const int rc = (g_use_glds && tn_glds_ok(q, dtype)) ? launch_tn_glds(q, 1, nsplit, s)
+    const int rc = use8p ? launch_tn8p(q, 1, nsplit, s) : (g_use_glds && tn_glds_ok(q, dtype)) ? launch_tn_glds(q, 1, nsplit, s)
                    : dtype == ST5_BF16 ? launch<bf16_t>(q, 1, nsplit, s) : launch<float>(q, 1, nsplit, s);
     if (rc) return rc;
     MrDesc& d = g_pending.d[g_pending.n++];
@@ -1869,7 +2174,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
     if (!slabs) return ST5_ERR_LAUNCH;
     st5_gemm_params q = p;
     q.C.ptr = slabs; q.C.ld = p.N; q.C.rpb = 0; q.C.bstride = 0; q.C.zs0 = q.C.zs1 = 0; q.beta = 0.f;
-    const int rc = (g_use_glds && tn_glds_ok(q, dtype)) ? launch_tn_glds(q, 1, nsplit, s)
+    const int rc = use8p ? launch_tn8p(q, 1, nsplit, s) : (g_use_glds && tn_glds_ok(q, dtype)) ? launch_tn_glds(q, 1, nsplit, s)
                    : dtype == ST5_BF16 ? launch<bf16_t>(q, 1, nsplit, s) : launch<float>(q, 1, nsplit, s);
     if (rc) return rc;
     long long blocks = ((long long)p.M * p.N / 4 + 255) / 256;
@@ -1897,6 +2202,7 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
     }
     return dtype == ST5_BF16 ? launch_glds<bf16_t>(p, c_vec_ok, s) : launch_glds<float>(p, c_vec_ok, s);
   }
+  if (use8p) return launch_tn8p(p, c_vec_ok, nsplit, s);
   if (g_use_glds && tn_glds_ok(p, dtype)) return launch_tn_glds(p, c_vec_ok, nsplit, s);
   if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, nsplit, s);
   return launch<float>(p, c_vec_ok, nsplit, s);
@@ -1985,4 +2291,7 @@ extern "C" int st5_gemm_set_deep_ring(int max_blocks, int nbuf) {
   if (max_blocks < 0 || nbuf < 2 || nbuf > 4) return ST5_ERR_ARG;
   g_deep_blocks = max_blocks; g_deep_nbuf = nbuf; return ST5_OK;
 }
+/* Weight-gradient (TN) GEMMs without row split / segments: 1 (default) = phased 256^2 kernel, 2 = the same without the stagger of the
+ * two m-halves, 0 = always the 128^2 LDS-DMA kernel (A/B measurements). */
+extern "C" int st5_gemm_set_tn_phased(int mode) { if (mode < 0 || mode > 2) return ST5_ERR_ARG; g_tn8p = mode; return ST5_OK; }
 extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 4) return ST5_ERR_ARG; g_nt_tile = mode; return ST5_OK; }

@@ -74,6 +74,7 @@ _SIGS = {
                                    c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, c_float, c_float, c_uint64, c_int, c_void_p]),
     "st5_flash_attn_set_impl": (c_int, [c_int]),
+    "st5_gemm_set_tn_phased": (c_int, [c_int]),
     "st5_gemm_mxfp8": (c_int, [POINTER(GemmParams), c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "st5_quant_mxfp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     "st5_flash_attn_qp_row": (c_int32, [c_int32]),

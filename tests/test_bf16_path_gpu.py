@@ -156,6 +156,55 @@ def test_tn_glds_model_shapes_with_bias_column(cuda):
         assert (db - 2.0 - rb).abs().max().item() <= 2e-2 * max(rb.abs().max().item(), math.sqrt(K))
 
 
+@pytest.mark.parametrize("mode", [3, 4])
+@pytest.mark.parametrize("kind", EPI)
+def test_nt_phased_256_tile_forced(cuda, mode, kind):
+    """gemm_nt8p_kernel (phased 256^2 schedule; 3 = staggered wave halves, 4 = not) through st5_gemm_set_nt_tile: M / N tails, k-tile
+    counts 1, 2 (prologue-only paths) and 12, every epilogue; bit-equal to the 128^2 kernel (same MFMA chain per output element)."""
+    L = hip.lib()
+    for (M, N, K) in [(520, 776, 768), (264, 256, 64), (256, 520, 128)]:
+        hip.check(L.st5_gemm_set_nt_tile(mode), "set_nt_tile")
+        try:
+            C, ref, extra = _run_nt(cuda, torch.bfloat16, M, N, K, kind, seed=3)
+        finally:
+            hip.check(L.st5_gemm_set_nt_tile(0), "set_nt_tile")
+        _close(C, ref, torch.bfloat16, f"nt8p mode {mode} {M}x{N}x{K} / {kind}")
+        for k, (got, r) in extra.items():
+            _close(got, r, torch.bfloat16, f"nt8p mode {mode} / {kind} / {k}")
+        C0, _, extra0 = _run_nt(cuda, torch.bfloat16, M, N, K, kind, seed=3)
+        assert torch.equal(C, C0), f"phased 256^2 (mode {mode}) and 128^2 tiles differ bitwise at {M}x{N}x{K} / {kind}"
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_tn_phased_256_tile(cuda, mode):
+    """gemm_tn8p_kernel through st5_gemm_set_tn_phased (off by default): weight-gradient shapes with a K tail (3992 = 62 * 64 + 24),
+    accumulate-into-C (beta = 1 after the slab reduction) and the VALU bias-gradient column."""
+    L = hip.lib()
+    for (M, N, K) in [(768, 3072, 3992), (3072, 768, 8192), (256, 256, 512), (512, 1536, 20000)]:
+        g = torch.Generator().manual_seed(M + K)
+        dy = torch.randn(K, M, generator=g).to(torch.bfloat16).to(cuda)
+        x = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(cuda)
+        outs = []
+        for m in (mode, 0):
+            C = torch.full((M, N), 1.0, dtype=torch.float32, device=cuda)
+            db = torch.full((M,), 2.0, dtype=torch.float32, device=cuda)
+            hip.check(L.st5_gemm_set_tn_phased(m), "set_tn_phased")
+            try:
+                hip.gemm(hip.operand(dy, M), hip.operand(x, N), hip.operand(C, N), M, N, K, hip.BF16,
+                         flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32, beta=1.0, asum=db)
+                torch.cuda.synchronize()
+            finally:
+                hip.check(L.st5_gemm_set_tn_phased(0), "set_tn_phased")
+            outs.append((C, db))
+        ref = dy.float().t() @ x.float()
+        rb = dy.float().sum(0)
+        for tag, (C, db) in zip((f"tn8p mode {mode}", "tn 128^2"), outs):
+            _close(C - 1.0, ref, torch.bfloat16, f"{tag} {M}x{N}x{K}")
+            assert (db - 2.0 - rb).abs().max().item() <= 2e-2 * max(rb.abs().max().item(), math.sqrt(K)), tag
+        # the two kernels split K differently, so they agree to fp32 summation order, not bitwise
+        assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-3 * ref.abs().max().item()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # fused attention backward vs torch autograd (no dropout: torch cannot reproduce the counter RNG; the dropout masks of the
 # fused kernels are pinned against the unfused path, which test_ops_gpu.py pins against torch, in test_flash_gpu.py)
