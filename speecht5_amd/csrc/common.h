@@ -178,13 +178,22 @@ __device__ __forceinline__ unsigned long long resolve_seed(unsigned long long se
   if (seed >> 63) seed = *reinterpret_cast<const unsigned long long*>(seed & 0x0000FFFFFFFFFFFFull);
   return seed;
 }
-__device__ __forceinline__ unsigned int drop_block_key(unsigned long long seed, unsigned long long block) {
+// The seed part of the block key (loop-invariant).  Kernels that derive keys inside a loop that keeps LDS-DMA in flight call this ONCE in
+// front of the loop: resolving a seed slot is a global load, and the s_waitcnt vmcnt(0) behind it drains the DMA queue -- inside the
+// attention tile loops that was one full landing latency per key tile (and ~30 VALU instructions of 64-bit multiplies per tile).
+__device__ __forceinline__ unsigned int drop_seed_fold(unsigned long long seed) {
   const unsigned long long h = rng_hash64(resolve_seed(seed), 0ull);
-  unsigned int x = (unsigned int)block ^ (unsigned int)h ^ (unsigned int)(h >> 32) ^ __umul24((unsigned int)(block >> 32), 0x9E3779u);
+  return (unsigned int)h ^ (unsigned int)(h >> 32);
+}
+__device__ __forceinline__ unsigned int drop_block_key_folded(unsigned int seed_fold, unsigned long long block) {
+  unsigned int x = (unsigned int)block ^ seed_fold ^ __umul24((unsigned int)(block >> 32), 0x9E3779u);
   x ^= x >> 15; x = __umul24(x, 0x9E3779u);
   x ^= x >> 12; x = __umul24(x, 0x85EBCBu);
   x ^= x >> 15;
   return x;
+}
+__device__ __forceinline__ unsigned int drop_block_key(unsigned long long seed, unsigned long long block) {
+  return drop_block_key_folded(drop_seed_fold(seed), block);
 }
 // 2 x 16 random bits for elements (2*pair, 2*pair+1) of a block; pair in [0, 32)
 // pc = pair * 0x9E3779B1 (callers with a compile-time pair pass the product)

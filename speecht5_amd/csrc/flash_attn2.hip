@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void fwd_kernel(const Args a) {
   float m_run = -INFINITY, l_run = 0.f;
   constexpr bool drop = DROP;
   const unsigned int thresh = drop ? dropout_thresh(a.dropout_p) : 0u;
+  const unsigned int seedf = drop ? drop_seed_fold(a.seed) : 0u;   // (once, in front of the tile loop: see drop_seed_fold)
   const float inv_keep = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
   const float sc2 = a.scale * LOG2E;
   const int jmax = a.causal ? qi + (a.S - a.T) : 0x3fffffff;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void fwd_kernel(const Args a) {
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = m_run == -INFINITY ? 0.f : fast_exp2(m_run - m_use);
     float psum;
-    if constexpr (DROP) psum = tile_probs<true>(s0, s1, m_use, drop_block_key(a.seed, ctr_blk + (unsigned long long)jt), hoff, thresh);
+    if constexpr (DROP) psum = tile_probs<true>(s0, s1, m_use, drop_block_key_folded(seedf, ctr_blk + (unsigned long long)jt), hoff, thresh);
     else psum = tile_probs<false>(s0, s1, m_use, 0u, hoff, thresh);
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
   float acc_lo = 0.f, acc_hi = 0.f;
   constexpr bool drop = DROP;
   const unsigned int thresh = drop ? dropout_thresh(a.dropout_p) : 0u;
+  const unsigned int seedf = drop ? drop_seed_fold(a.seed) : 0u;   // (once, in front of the tile loop: see drop_seed_fold)
   const float inv_keep = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
   const float sc2 = a.scale * LOG2E;
   const int jmax = a.causal ? qi + (a.S - a.T) : 0x3fffffff;
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
     const int jrel = jmax - j0 - 4 * hi;
     const unsigned long long km = kmask >> (4 * hi);
     unsigned int key32 = 0u;
-    if (drop) key32 = drop_block_key(a.seed, ctr_blk + (unsigned long long)jt);
+    if (drop) key32 = drop_block_key_folded(seedf, ctr_blk + (unsigned long long)jt);
     const float buni = bmode == 1 ? blo : bhi;
     const int b0 = qi - j0 - 4 * hi + a.maxrel;   // unclamped bucket of key offset c = 0
     float csum = 0.f;
@@ -827,6 +829,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
   for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
   constexpr bool drop = DROP;
   const unsigned int thresh = drop ? dropout_thresh(a.dropout_p) : 0u;
+  const unsigned int seedf = drop ? drop_seed_fold(a.seed) : 0u;   // (once, in front of the tile loop: see drop_seed_fold)
   const float inv_keep = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
   const float sc2 = a.scale * LOG2E;
   const unsigned int pcl = ((unsigned int)(ki & 63) >> 1) * PAIR_MUL;
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
     if (tid < 128 && drop) {
       const int qq = q0t + (tid & 63);
       const unsigned long long row = (unsigned long long)bhT + (unsigned long long)(qq < a.T ? qq : a.T - 1);
-      dkey = drop_block_key(a.seed, row * (unsigned long long)(drop_row_stride(a.lds) >> 6) + (unsigned long long)((kblk >> 6) + (tid >> 6)));
+      dkey = drop_block_key_folded(seedf, row * (unsigned long long)(drop_row_stride(a.lds) >> 6) + (unsigned long long)((kblk >> 6) + (tid >> 6)));
     }
   };
   auto side_store = [&](char* buf) {

@@ -45,6 +45,23 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// Linear block number (after the XCD remap: every XCD walks a contiguous range of them, ~32 x blocks-per-CU at a time) -> tile
+// coordinates.  Row-major order makes the blocks that run together on an XCD cover few rows and ALL columns of tiles (64 blocks on
+// 24 columns: 3 A panels + 24 B panels stream through that XCD's L2 at once); walking column groups GEMM_GROUP_N wide instead (the
+// "grouped" order of every tiled GEMM) makes them cover an 8 x 8 patch: 16 panels for the same 64 tiles.
+#ifndef GEMM_GROUP_N
+#define GEMM_GROUP_N 8
+#endif
+__device__ __forceinline__ void tile_of(const int bid, const int tiles_n, const int ntiles, int& tm, int& tn) {
+  if (GEMM_GROUP_N == 0 || tiles_n <= GEMM_GROUP_N) { tm = bid / tiles_n; tn = bid - tm * tiles_n; return; }
+  const int tiles_m = ntiles / tiles_n;
+  const int gsz = GEMM_GROUP_N * tiles_m;
+  const int g = bid / gsz, r = bid - g * gsz;
+  const int tn0 = g * GEMM_GROUP_N;
+  const int gw = tiles_n - tn0 < GEMM_GROUP_N ? tiles_n - tn0 : GEMM_GROUP_N;
+  tm = r / gw; tn = tn0 + (r - tm * gw);
+}
+
 __device__ __forceinline__ unsigned int elem_bits(float v) { return __float_as_uint(v); }
 __device__ __forceinline__ unsigned int elem_bits(bf16_t v) {
   return (unsigned int)__builtin_bit_cast(unsigned short, v);
@@ -475,7 +492,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const st5_gemm_params
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
@@ -772,7 +790,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
   const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
@@ -801,23 +820,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[i] + (long long)kt * BK), (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, 0);
     }
   };
+  // (NBUF == 5: five 16 KB operand slots instead of whole stages, see the k-loop)
+  auto issue_a = [&](int kt, int slot) {
+    char* base = dsm + slot * TILE_BYTES + dst0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, 0);
+  };
+  auto issue_b = [&](int kt, int slot) {
+    char* base = dsm + slot * TILE_BYTES + dst0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, 0);
+  };
 
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
   const int nk = p.K / BK;
+  if constexpr (NBUF == 5) {
+    issue_a(0, 0); issue_b(0, 1);
+    if (nk > 1) issue_a(1, 2);
+  } else {
 #pragma unroll
-  for (int t = 0; t < NBUF - 1; ++t)
-    if (t < nk) issue(t, t);
+    for (int t = 0; t < NBUF - 1; ++t)
+      if (t < nk) issue(t, t);
+  }
   const int frow = lane & 31, fhalf = lane >> 5;
   const int arow0 = wr * 64 + frow, brow0 = wc * 64 + frow;
   const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)dsm;
   const unsigned a_addr0 = lds_off(arow0, fhalf), b_addr0 = lds_off(brow0, fhalf);
   GPROBE(0);
+  // NBUF == 5 ("2.5 stages", 80 KB: two blocks still share a CU): operand tiles go through a ring of five 16 KB slots in the order
+  // A(0) B(0) A(1) B(1) A(2) ..., tile number s in slot s % 5.  At the top of k-tile t the tiles 2t, 2t+1, 2t+2 are in flight; the wait
+  // leaves only A(t+1) outstanding, the barrier retires everybody's reads of A(t-1) / B(t-1), whose slots B(t+1) and A(t+2) then
+  // take: 48 KB per block in flight under the MFMAs (32 KB with two whole stages) and 16 KB instead of nothing across the wait --
+  // the operand fill of a CU is latency-bound (bytes in flight / landing latency), section 4.
+  int sa = 0;   // slot of A(kt); B(kt) sits in the next one
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed when at most the 8 loads of tile kt+1 are still outstanding
-    {
+    if constexpr (NBUF == 5) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      // tile kt has landed when at most the 8 loads of tile kt+1 are still outstanding
       int ahead = nk - 1 - kt;
       ahead = ahead < NBUF - 2 ? ahead : NBUF - 2;  // tiles allowed to stay in flight
       if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -828,19 +874,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
     __builtin_amdgcn_s_barrier();
     GPROBE(1);
 #if GEMM_ABL != 2
-    if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
+    // (tried and dropped: the eight LDS-DMA instructions two at a time behind the four MFMA groups instead of back to back in front of
+    // them -- 3-10 % slower on the wide-N shapes, profiles/r4_gemm_nt_experiments.txt)
+    if constexpr (NBUF == 5) {
+      if (kt + 1 < nk) issue_b(kt + 1, sa + 3 >= 5 ? sa - 2 : sa + 3);
+      if (kt + 2 < nk) issue_a(kt + 2, sa + 4 >= 5 ? sa - 1 : sa + 4);
+    } else {
+      if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
+    }
 #endif
     // Fragments double-buffered in registers: the four reads of k-group kg + 1 are issued before the MFMAs of group kg, and each group
     // waits only for its own reads (LDS returns in order: lgkmcnt(4) = "all but the four newest").  Written as inline asm because hipcc
     // keeps the source order "read, wait for everything, multiply" per group otherwise (and, given both sets, still waits with
     // lgkmcnt(0)) -- one exposed LDS round trip per k-group instead of one per k-tile.  addr(kg) = addr(0) ^ (kg << 5): the swizzle
     // XORs the chunk index, the k-group is bits 1-2 of it.
-    const unsigned cb = lds_base + (kt % NBUF) * 2 * TILE_BYTES;
-    const unsigned pa = cb + a_addr0, pb = cb + b_addr0;
+    unsigned pa, pb;
+    if constexpr (NBUF == 5) {
+      const int sb = sa + 1 >= 5 ? 0 : sa + 1;
+      pa = lds_base + sa * TILE_BYTES + a_addr0; pb = lds_base + sb * TILE_BYTES + b_addr0;
+      sa = sa + 2 >= 5 ? sa - 3 : sa + 2;
+    } else {
+      const unsigned cb = lds_base + (kt % NBUF) * 2 * TILE_BYTES;
+      pa = cb + a_addr0; pb = cb + TILE_BYTES + b_addr0;
+    }
     frag_t fa0[2], fa1[2], fb0[2], fb1[2];
 #define NT_READ(S, KG)                                                                                      \
-  fa0[S] = lds_read128_asm<frag_t, 0>(pa ^ ((KG) << 5)); fb0[S] = lds_read128_asm<frag_t, TILE_BYTES>(pb ^ ((KG) << 5));          \
-  fa1[S] = lds_read128_asm<frag_t, 4096>(pa ^ ((KG) << 5)); fb1[S] = lds_read128_asm<frag_t, TILE_BYTES + 4096>(pb ^ ((KG) << 5));
+  fa0[S] = lds_read128_asm<frag_t, 0>(pa ^ ((KG) << 5)); fb0[S] = lds_read128_asm<frag_t, 0>(pb ^ ((KG) << 5));          \
+  fa1[S] = lds_read128_asm<frag_t, 4096>(pa ^ ((KG) << 5)); fb1[S] = lds_read128_asm<frag_t, 4096>(pb ^ ((KG) << 5));
 #define NT_WAIT(S, CNT)                                                                                     \
   asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa0[S]), "+v"(fa1[S]), "+v"(fb0[S]), "+v"(fb1[S]) :: "memory");
 #if GEMM_ABL == 3
@@ -943,7 +1003,8 @@ __global__ __launch_bounds__(NT2) void gemm_nt256_kernel(const st5_gemm_params p
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
   const int m0 = tm * BM2, n0 = tn * BN2;
   const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
   const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
@@ -1131,7 +1192,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(const st5_gemm_params p,
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
   const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
   const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
@@ -1332,6 +1394,9 @@ namespace {
 // other stream's blocks are the latency cover and 128 KB blocks keep them off the CU: 37.70 -> 38.27 ms, so that mode turns
 // the deep ring off (st5_gemm_set_deep_ring(0, 2)).
 int g_deep_blocks = 256, g_deep_nbuf = 4;
+int g_nt_slots5 = 0;   // st5_gemm_set_nt_slots(5): grids of more than g_deep_blocks blocks on five operand slots (80 KB) instead of two stages
+                       // (64 KB).  Measured (profiles/r4_gemm_nt_slots.txt): no gain on any model shape (-4 % .. +3 %), so off -- more loads in
+                       // flight per block is not what the 128^2 kernel is short of.
 
 // The feature mask of a launch when one of the specialised instantiations covers it exactly, else -1 (run-time form).
 // The hot combinations of the training step (transformer_layer.py / multihead_attention.py call sites through functional.py):
@@ -1366,7 +1431,7 @@ int launch_glds_as(const st5_gemm_params& p, int c_vec_ok, dim3 grid, hipStream_
       return ST5_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_nt_glds_kernel<T, NBUF, FEAT>), grid, dim3(NTHREADS), (size_t)NBUF * 2 * TILE_BYTES, s, p, c_vec_ok);
+  hipLaunchKernelGGL((gemm_nt_glds_kernel<T, NBUF, FEAT>), grid, dim3(NTHREADS), (size_t)(NBUF == 5 ? 5 : NBUF * 2) * TILE_BYTES, s, p, c_vec_ok);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -1396,6 +1461,7 @@ int launch_glds(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     if (deep && g_deep_nbuf == 4) return launch_glds_feat<T, 4>(p, c_vec_ok, grid, s);
     if (deep) return launch_glds_feat<T, 3>(p, c_vec_ok, grid, s);
+    if (g_nt_slots5 && nk >= 2) return launch_glds_feat<T, 5>(p, c_vec_ok, grid, s);
   }
   return launch_glds_feat<T, 2>(p, c_vec_ok, grid, s);
 }
@@ -1457,7 +1523,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
   const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
@@ -1645,7 +1712,8 @@ __global__ __launch_bounds__(512) void gemm_tn8p_kernel(const st5_gemm_params p,
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
   const T* Ap = reinterpret_cast<const T*>(p.A.ptr);
   const T* Bp = reinterpret_cast<const T*>(p.B.ptr);
@@ -1936,7 +2004,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_mx8_kernel(const st5_gemm
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const unsigned char* Ap = reinterpret_cast<const unsigned char*>(p.A.ptr);
   const unsigned char* Bp = reinterpret_cast<const unsigned char*>(p.B.ptr);
@@ -2286,6 +2355,11 @@ extern "C" int st5_gemm_set_glds(int enabled) { g_use_glds = enabled != 0; retur
 /* NT block tile: 0 = per-problem choice (default), 1 = 128x128 always, 2 = 256x256 always (A/B measurements). */
 /* Block count the split-K choice of the fp32-output (weight-gradient) GEMMs aims for (default 384 = 1.5 per CU). */
 extern "C" int st5_gemm_set_splitk_target(int blocks) { if (blocks < 1 || blocks > 4096) return ST5_ERR_ARG; g_splitk_target = blocks; return ST5_OK; }
+/* 128^2 NT kernel, grids of more than one block per CU: 4 = two whole stages (default), 5 = ring of five 16 KB operand slots. */
+extern "C" int st5_gemm_set_nt_slots(int slots) {
+  if (slots != 4 && slots != 5) return ST5_ERR_ARG;
+  g_nt_slots5 = slots == 5; return ST5_OK;
+}
 /* 128^2 NT kernel: grids of at most `max_blocks` blocks run with an `nbuf`-stage operand ring (2 = off, 3, 4). */
 extern "C" int st5_gemm_set_deep_ring(int max_blocks, int nbuf) {
   if (max_blocks < 0 || nbuf < 2 || nbuf > 4) return ST5_ERR_ARG;

@@ -46,6 +46,7 @@ _SIGS = {
     "st5_gemm_set_nt_tile": (c_int, [c_int]),
     "st5_gemm_set_splitk_target": (c_int, [c_int]),
     "st5_gemm_set_deep_ring": (c_int, [c_int, c_int]),
+    "st5_gemm_set_nt_slots": (c_int, [c_int]),
     "st5_gemm_defer_splitk": (c_int, [c_int, c_void_p]),
     "st5_gemm_flush_splitk": (c_int, [c_void_p]),
     "st5_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,

@@ -13,6 +13,8 @@ bf = torch.bfloat16
 L = hip.lib()
 if os.environ.get("ST5_TN_PHASED"):
     L.st5_gemm_set_tn_phased(int(os.environ["ST5_TN_PHASED"]))
+if os.environ.get("ST5_NT_SLOTS"):
+    L.st5_gemm_set_nt_slots(int(os.environ["ST5_NT_SLOTS"]))
 if os.environ.get("ST5_NT_TILE"):
     L.st5_gemm_set_nt_tile(int(os.environ["ST5_NT_TILE"]))
 
