@@ -448,7 +448,7 @@ struct BwdArgs {
   int B, H, T, S, nb, maxrel, causal, lds;
   float scale, dropout_p;
   unsigned long long seed;
-  int dvec_in_dq;   // 1: the dq kernel computes D = dO . O itself and writes dvec for the dkv kernel that follows it on the same stream
+  int dvec_in_dq;   // 1 (dq and dkv on ONE stream): the dq kernel computes D = dO . O itself, writes dvec for the dkv kernel behind it, and clears dQP
 };
 
 __global__ __launch_bounds__(256) void dvec_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ dvec,
@@ -569,6 +569,16 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
     dsum = a.dvec[(long long)bh * a.T + qc];
   }
 
+  if (BIAS && a.dvec_in_dq) {
+    // dQP rows of this block's queries start as zeros (buckets whose key falls outside [0, S) are never written): cleared here with
+    // 16-byte stores instead of by a hipMemsetAsync over the whole array in front of every backward (24 fills of ~8 us per update).
+    // The dkv kernel (window buckets) runs behind this kernel on the same stream; this block's own end-bucket stores come after the
+    // tile loop, whose vmcnt(0) + barrier pairs order them behind these stores.
+    const int nrows = a.T - qblk < 128 ? a.T - qblk : 128;
+    uint4* zp = reinterpret_cast<uint4*>(a.dqp + ((long long)bh * a.T + qblk) * a.nb);
+    const int n16 = nrows * (a.nb >> 3);
+    for (int i = tid; i < n16; i += 256) zp[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   int nkeys = a.S;
   if (a.causal) {
     const int qmax = (qblk + 127 < a.T ? qblk + 127 : a.T - 1) + (a.S - a.T);
@@ -1126,11 +1136,11 @@ extern "C" int st5_flash_attn_bwd_2s(const void* q, int64_t q_ld, const void* k,
   a.B = B; a.H = H; a.T = T; a.S = S; a.nb = pe ? nb : 0; a.maxrel = maxrel; a.causal = causal; a.lds = lds;
   a.scale = scale; a.dropout_p = dropout_p; a.seed = seed;
   hipStream_t s = (hipStream_t)stream, s2 = (hipStream_t)stream2;
-  if (pe && hipMemsetAsync(dqp, 0, (size_t)B * H * T * nb * 2, s) != hipSuccess) return ST5_ERR_LAUNCH;
   const long long rows = (long long)B * H * T;
-  // one stream (the default): D = dO . O is computed by the dq kernel, which writes dvec for the dkv kernel behind it; with the
-  // helper stream (dq and dkv side by side) both need it up front
+  // one stream (the default): D = dO . O is computed by the dq kernel, which writes dvec for the dkv kernel behind it, and the dq
+  // kernel clears dQP; with the helper stream (dq and dkv side by side) both are needed up front
   a.dvec_in_dq = (s2 == nullptr || s2 == s) ? 1 : 0;
+  if (pe && !a.dvec_in_dq && hipMemsetAsync(dqp, 0, (size_t)B * H * T * nb * 2, s) != hipSuccess) return ST5_ERR_LAUNCH;
   if (!a.dvec_in_dq)
     hipLaunchKernelGGL(fa2::dvec_kernel, dim3((unsigned)((rows * 2 + 255) / 256)), dim3(256), 0, s, a.o, a.dout, dvec, a.o_ld, a.do_ld, H, T, rows);
   if (s2) { if (st5_stream_fork(s, s2) != ST5_OK) return ST5_ERR_LAUNCH; } else s2 = s;
