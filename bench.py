@@ -333,7 +333,7 @@ def main():
             rows = list(_csv.DictReader(open(os.path.join(here, "profiles", KERNEL_STATS_FILE))))
             upd_n = sum(int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"])
             nt_ns = sum(float(r["TotalDurationNs"]) for r in rows
-                        if "gemm_nt_glds_kernel" in r["Name"] or "gemm_nt256_kernel" in r["Name"]
+                        if "gemm_nt_glds_kernel" in r["Name"] or "gemm_nt256_kernel" in r["Name"] or "gemm_nt8p_kernel" in r["Name"]
                         or ("gemm_kernel" in r["Name"] and "Lb0ELb0" in r["Name"] and "DF16b" in r["Name"]))
             all_ns = sum(float(r["TotalDurationNs"]) for r in rows)
             if upd_n and nt_ns and flops > 0:
