@@ -189,19 +189,6 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
-        # tuning knobs for same-box A/B runs (tools/r4/bench_env_ab.sh); the library defaults are what ships
-        env = os.environ.get
-        if env("ST5_SPLITK_TARGET"):
-            check(L.st5_gemm_set_splitk_target(int(env("ST5_SPLITK_TARGET"))), "st5_gemm_set_splitk_target")
-        if env("ST5_NT_TILE"):
-            check(L.st5_gemm_set_nt_tile(int(env("ST5_NT_TILE"))), "st5_gemm_set_nt_tile")
-        if env("ST5_NT_SLOTS"):
-            check(L.st5_gemm_set_nt_slots(int(env("ST5_NT_SLOTS"))), "st5_gemm_set_nt_slots")
-        if env("ST5_DEEP_RING"):
-            b_, n_ = env("ST5_DEEP_RING").split(",")
-            check(L.st5_gemm_set_deep_ring(int(b_), int(n_)), "st5_gemm_set_deep_ring")
-        if env("ST5_LN_MAX_BLOCKS"):
-            check(L.st5_layernorm_set_max_blocks(int(env("ST5_LN_MAX_BLOCKS"))), "st5_layernorm_set_max_blocks")
     return _lib
 
 
