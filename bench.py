@@ -183,8 +183,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=8, help="speech clips (10 s) per GPU per step")
     ap.add_argument("--arch", default="base", choices=["base", "large"],
-                    help="large = t5_transformer_large (24 + 6 layers, d = 1024, pre-LN), same two micro-batches, bf16 GEMMs: a side "
-                         "measurement (BASELINE.json cfg 5 asks for fp8 GEMMs, which do not exist here); the headline is base")
+                    help="large = t5_transformer_large (24 + 6 layers, d = 1024, pre-LN), same two micro-batches: a side measurement "
+                         "(BASELINE.json configs[4]; with --dtype fp8 the forward / data-gradient GEMMs run on the MX-fp8 kernel); the "
+                         "headline is base")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying a captured HIP graph")
     ap.add_argument("--layerdrop", type=float, default=0.05, help="encoder / decoder LayerDrop (t5_transformer_base: 0.05)")
     ap.add_argument("--micro", default="in_turn", choices=["side_by_side", "in_turn_2buf", "in_turn"],
