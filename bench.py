@@ -242,7 +242,7 @@ def main():
         hip.lib().st5_gemm_set_deep_ring(*[int(v) for v in os.environ["ST5_DEEP_RING"].split(",")])
     if os.environ.get("ST5_SPLITK_TARGET"):   # A/B: block count the weight-gradient split-K aims for
         hip.lib().st5_gemm_set_splitk_target(int(os.environ["ST5_SPLITK_TARGET"]))
-    if os.environ.get("ST5_NT_SLOTS"):   # A/B: 5 = five-slot operand ring of the 128x128 NT kernel (default 4 = two stages)
+    if os.environ.get("ST5_NT_SLOTS"):   # A/B: 4 = two-stage operand ring of the 128x128 NT kernel (default 5 = five operand slots)
         hip.lib().st5_gemm_set_nt_slots(int(os.environ["ST5_NT_SLOTS"]))
     if os.environ.get("ST5_LN_MAX_BLOCKS"):   # A/B: block cap of the single-pass LayerNorm backward (default 256)
         hip.lib().st5_layernorm_set_max_blocks(int(os.environ["ST5_LN_MAX_BLOCKS"]))

@@ -109,8 +109,9 @@ int st5_gemm_set_splitk_target(int blocks);
 int st5_gemm_set_tn_phased(int mode);
 /* 128x128 NT kernel: grids of at most max_blocks blocks (one per CU) use an nbuf-stage operand ring (2 = never; default 256, 4). */
 int st5_gemm_set_deep_ring(int max_blocks, int nbuf);
-/* 128x128 NT kernel on grids of more than one block per CU: 4 (default) = two whole stages, 5 = operand tiles through a ring of five
- * 16 KB LDS slots (A and B of a k-step are separate ring entries: 2.5 k-steps of loads in flight, 80 KB, two blocks per CU; A/B only). */
+/* 128x128 NT kernel on grids of more than one block per CU: 5 (default) = operand tiles through a ring of five 16 KB LDS slots (A and B
+ * of a k-step are separate ring entries: 2.5 k-steps of loads in flight, 80 KB, two blocks per CU), 4 = two whole stages (64 KB).
+ * Bit-identical results; A/B switch. */
 int st5_gemm_set_nt_slots(int slots);
 /* Batch the slab reductions of split-K GEMMs (weight gradients): while enabled, a split-K st5_gemm only queues its reduction;
  * st5_gemm_flush_splitk launches ONE kernel that folds every queued reduction into its output (the outputs are complete

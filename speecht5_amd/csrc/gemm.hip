@@ -1394,9 +1394,10 @@ namespace {
 // other stream's blocks are the latency cover and 128 KB blocks keep them off the CU: 37.70 -> 38.27 ms, so that mode turns
 // the deep ring off (st5_gemm_set_deep_ring(0, 2)).
 int g_deep_blocks = 256, g_deep_nbuf = 4;
-int g_nt_slots5 = 0;   // st5_gemm_set_nt_slots(5): grids of more than g_deep_blocks blocks on five operand slots (80 KB) instead of two stages
-                       // (64 KB).  Measured (profiles/r4_gemm_nt_slots.txt): no gain on any model shape (-4 % .. +3 %), so off -- more loads in
-                       // flight per block is not what the 128^2 kernel is short of.
+int g_nt_slots5 = 1;   // grids of more than g_deep_blocks blocks on five operand slots (80 KB, 2.5 k-steps of loads in flight) instead of two
+                       // stages (64 KB); st5_gemm_set_nt_slots.  Per shape the difference is inside the noise (-4 % .. +3 %,
+                       // profiles/r4_gemm_nt_slots.txt); on the whole update it was -0.4 .. -0.9 % in three same-box pairs on two boxes
+                       // (profiles/r4_knob_ab.txt), so it is the default.  Results are bit-identical either way.
 
 // The feature mask of a launch when one of the specialised instantiations covers it exactly, else -1 (run-time form).
 // The hot combinations of the training step (transformer_layer.py / multihead_attention.py call sites through functional.py):
@@ -2069,19 +2070,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_mx8_kernel(const st5_gemm
       issue(kt + 1, (kt + 1) & 1);
     }
     const char* cur = dsm + (kt & 1) * 2 * TILE_BYTES;
+    // operand layout measured on the part (tools/probe/mx_layout_probe.hip, tests/test_fp8_gpu.py): lane (row, h = lane >> 5)
+    // supplies bytes k = 16h .. 16h+15 of the instruction's FIRST 32-block in registers 0-3 and k = 16h .. 16h+15 of its SECOND
+    // block in registers 4-7; the scale of block b comes from the lanes with h == b (byte 0 of their scale register).
+    // Both k-groups' fragments (g: bytes 64g .. 64g+63 of the tile rows = MX blocks 2g, 2g+1) are read before the first MFMA, so the
+    // second group's LDS round trip runs under the first group's MFMAs (the bf16 kernel's round-4 fragment pipelining).
+    i32x8 a0[2], a1[2], b0[2], b1[2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {   // k-group g: bytes 64g .. 64g+63 of the tile rows = MX blocks 2g, 2g+1
-      const int* sc = g == 0 ? sc0 : sc1;
-      // operand layout measured on the part (tools/probe/mx_layout_probe.hip, tests/test_fp8_gpu.py): lane (row, h = lane >> 5)
-      // supplies bytes k = 16h .. 16h+15 of the instruction's FIRST 32-block in registers 0-3 and k = 16h .. 16h+15 of its SECOND
-      // block in registers 4-7; the scale of block b comes from the lanes with h == b (byte 0 of their scale register)
+    for (int g = 0; g < 2; ++g) {
       const int ca = 4 * g + fhalf, cb = 4 * g + 2 + fhalf;
-      const i32x8 a0 = mx_frag2(cur, arow0, ca, cb), a1 = mx_frag2(cur, arow0 + 32, ca, cb);
-      const i32x8 b0 = mx_frag2(cur + TILE_BYTES, brow0, ca, cb), b1 = mx_frag2(cur + TILE_BYTES, brow0 + 32, ca, cb);
-      acc00 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b0, acc00, 0, 0, 0, sc[0], 0, sc[2]);
-      acc01 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b1, acc01, 0, 0, 0, sc[0], 0, sc[3]);
-      acc10 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b0, acc10, 0, 0, 0, sc[1], 0, sc[2]);
-      acc11 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b1, acc11, 0, 0, 0, sc[1], 0, sc[3]);
+      a0[g] = mx_frag2(cur, arow0, ca, cb); b0[g] = mx_frag2(cur + TILE_BYTES, brow0, ca, cb);
+      a1[g] = mx_frag2(cur, arow0 + 32, ca, cb); b1[g] = mx_frag2(cur + TILE_BYTES, brow0 + 32, ca, cb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int* sc = g == 0 ? sc0 : sc1;
+      acc00 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0[g], b0[g], acc00, 0, 0, 0, sc[0], 0, sc[2]);
+      acc01 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0[g], b1[g], acc01, 0, 0, 0, sc[0], 0, sc[3]);
+      acc10 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1[g], b0[g], acc10, 0, 0, 0, sc[1], 0, sc[2]);
+      acc11 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1[g], b1[g], acc11, 0, 0, 0, sc[1], 0, sc[3]);
     }
   }
   __syncthreads();
@@ -2111,44 +2119,39 @@ int launch_mx8_as(const st5_gemm_params& p, int c_vec_ok, const unsigned char* s
 
 // MX quantisation of a row-major bf16 matrix along its rows: per 32 consecutive elements one e8m0 scale byte
 // E = floor(log2(amax)) - 8 + 127 (the OCP MX rule for e4m3, whose largest binade is 2^8) and 32 e4m3 bytes of x * 2^(127 - E),
-// round-to-nearest-even, saturating at +-448.  One lane per block: 64 bytes in, 32 + 1 bytes out.
+// round-to-nearest-even, saturating at +-448.  Four lanes per block, 8 elements each: coalesced 16-byte loads and 8-byte stores
+// (the first version gave a lane a whole block: 64-byte stride between the lanes of every load instruction), the block maximum by
+// two quad shuffles.
 __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict__ x, long long ld, unsigned char* __restrict__ q, long long q_ld,
                                                         unsigned char* __restrict__ s, long long s_ld, long long rows, int cols) {
-  const int nb = cols >> 5;
-  const long long total = rows * nb;
+  const int ng = cols >> 3;                 // 8-element groups per row (a multiple of 4: cols % 32 == 0)
+  const long long total = rows * ng;        // (a multiple of 4, like every stride below: the 4 lanes of a block stay together)
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long row = i / nb;
-    const int b = (int)(i - row * nb);
-    const bf16_t* src = x + row * ld + b * 32;
-    float v[32];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float t8[8];
-      load8f<bf16_t>(src + 8 * j, t8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[8 * j + e] = t8[e];
-    }
+    const long long row = i / ng;
+    const int g = (int)(i - row * ng);
+    float v[8];
+    load8f<bf16_t>(x + row * ld + g * 8, v);
     float amax = 0.f;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
     int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;      // biased exponent of amax, minus emax(e4m3)
     E = E < 0 ? 0 : (E > 254 ? 254 : E);
     const float inv = __uint_as_float((unsigned int)(254 - E) << 23);    // 2^(127 - E)
-    u32x4 o0, o1;
+    u32x2 o;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 0; w < 2; ++w) {
       float f[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float t = v[4 * w + e] * inv; f[e] = fminf(fmaxf(t, -448.f), 448.f); }
       int pk = 0;
       pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
       pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
-      if (w < 4) o0[w] = (unsigned int)pk; else o1[w - 4] = (unsigned int)pk;
+      o[w] = (unsigned int)pk;
     }
-    unsigned char* dst = q + row * q_ld + b * 32;
-    *reinterpret_cast<u32x4*>(dst) = o0;
-    *reinterpret_cast<u32x4*>(dst + 16) = o1;
-    s[row * s_ld + b] = (unsigned char)E;
+    *reinterpret_cast<u32x2*>(q + row * q_ld + g * 8) = o;
+    if ((g & 3) == 0) s[row * s_ld + (g >> 2)] = (unsigned char)E;
   }
 }
 
@@ -2323,9 +2326,9 @@ extern "C" int st5_quant_mxfp8(const void* x, int64_t ld, void* q, int64_t q_ld,
   if (!x || !q || !s || rows < 0 || cols <= 0 || cols % 32) return ST5_ERR_ARG;
   if (rows == 0) return ST5_OK;
   if (!aligned(x, 16) || !aligned(q, 16) || ld % 8 || q_ld % 16) return ST5_ERR_ALIGN;
-  const long long total = (long long)rows * (cols / 32);
+  const long long total = (long long)rows * (cols / 8);
   long long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(quant_mx8_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16_t*)x, (long long)ld,
                      (unsigned char*)q, (long long)q_ld, (unsigned char*)s, (long long)s_ld, (long long)rows, (int)cols);
   HIP_CHECK_LAUNCH();
@@ -2355,7 +2358,7 @@ extern "C" int st5_gemm_set_glds(int enabled) { g_use_glds = enabled != 0; retur
 /* NT block tile: 0 = per-problem choice (default), 1 = 128x128 always, 2 = 256x256 always (A/B measurements). */
 /* Block count the split-K choice of the fp32-output (weight-gradient) GEMMs aims for (default 384 = 1.5 per CU). */
 extern "C" int st5_gemm_set_splitk_target(int blocks) { if (blocks < 1 || blocks > 4096) return ST5_ERR_ARG; g_splitk_target = blocks; return ST5_OK; }
-/* 128^2 NT kernel, grids of more than one block per CU: 4 = two whole stages (default), 5 = ring of five 16 KB operand slots. */
+/* 128^2 NT kernel, grids of more than one block per CU: 5 = ring of five 16 KB operand slots (default), 4 = two whole stages. */
 extern "C" int st5_gemm_set_nt_slots(int slots) {
   if (slots != 4 && slots != 5) return ST5_ERR_ARG;
   g_nt_slots5 = slots == 5; return ST5_OK;

@@ -177,16 +177,17 @@ def test_nt_phased_256_tile_forced(cuda, mode, kind):
 
 @pytest.mark.parametrize("kind", EPI)
 def test_nt_five_slot_ring_bit_equal_to_two_stages(cuda, kind):
-    """gemm_nt_glds_kernel<.., 5, ..> (five 16 KB operand slots; st5_gemm_set_nt_slots(5), an A/B mode) against the default two-stage
-    ring: same MFMA chain per element -> bit-equal; k-tile counts 2, 3, 5, 12 walk the slot ring through its wrap-arounds, M tail 3992."""
+    """gemm_nt_glds_kernel<.., 5, ..> (five 16 KB operand slots, the default for grids of more than one block per CU) against the
+    two-stage ring (st5_gemm_set_nt_slots(4)): same MFMA chain per element -> bit-equal; k-tile counts 2, 3, 5, 12 walk the slot ring
+    through its wrap-arounds, M tail 3992."""
     L = hip.lib()
     for (M, N, K) in [(3992, 3072, 768), (2304, 1024, 128), (2304, 768, 192), (4096, 768, 320)]:
-        C4, ref, extra4 = _run_nt(cuda, torch.bfloat16, M, N, K, kind, seed=4)
-        hip.check(L.st5_gemm_set_nt_slots(5), "set_nt_slots")
+        C5, ref, extra5 = _run_nt(cuda, torch.bfloat16, M, N, K, kind, seed=4)
+        hip.check(L.st5_gemm_set_nt_slots(4), "set_nt_slots")
         try:
-            C5, _, extra5 = _run_nt(cuda, torch.bfloat16, M, N, K, kind, seed=4)
+            C4, _, extra4 = _run_nt(cuda, torch.bfloat16, M, N, K, kind, seed=4)
         finally:
-            hip.check(L.st5_gemm_set_nt_slots(4), "set_nt_slots")
+            hip.check(L.st5_gemm_set_nt_slots(5), "set_nt_slots")
         _close(C5, ref, torch.bfloat16, f"five-slot ring {M}x{N}x{K} / {kind}")
         assert torch.equal(C5, C4), f"five-slot ring differs from two stages at {M}x{N}x{K} / {kind}"
         for k in extra5:
