@@ -270,6 +270,9 @@ __device__ __forceinline__ WinGeom win_geom(int qw0, int j0, int maxrel, int nb)
 // CUs; bwd_dq_kernel<true> was 7.9 k instructions with its 16-way run-time dispatch).
 template <bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void fwd_kernel(const Args a) {
+#ifdef FA2_PAD256   // discriminator build (tools/r4/sbs_arms.sh): no third wave beside this kernel's wave and another big one on a SIMD
+  ST5_PAD_TO_256_VGPRS();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kbuf = smem;                 // 2 x 8 KB
   char* vbuf = smem + 2 * TILE_B;    // 2 x 8 KB
@@ -530,6 +533,9 @@ __device__ __forceinline__ void read_bias_half(const int t, unsigned int (&braw)
 
 template <bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
+#ifdef FA2_PAD256   // discriminator build (tools/r4/sbs_arms.sh): no third wave beside this kernel's wave and another big one on a SIMD
+  ST5_PAD_TO_256_VGPRS();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kbuf = smem;                 // 2 x 8 KB
   char* vbuf = smem + 2 * TILE_B;    // 2 x 8 KB
@@ -810,7 +816,15 @@ __device__ __forceinline__ void dkv_sub(f32x16& s, const f32x16& dp, f32x16& pd,
 
 template <bool BIAS, bool DROP>
 __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
+#ifdef FA2_PAD256   // discriminator build (tools/r4/sbs_arms.sh): no third wave beside this kernel's wave and another big one on a SIMD
+  ST5_PAD_TO_256_VGPRS();
+#endif
+#ifdef FA2_DKV_HEAD_PAD   // discriminator build (tools/r4/sbs_arms.sh): the kernel's data starts 16 KB into its LDS allocation
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* const smem = smem_raw + 16 * 1024;
+#else
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* scratch = smem + 2 * QBUF_B + wave * KSCR_B;
@@ -1048,7 +1062,11 @@ int set_attrs() {
                        (const void*)fa2::bwd_dq_kernel<true, false>, (const void*)fa2::bwd_dq_kernel<false, false>, (const void*)fa2::bwd_dkv_kernel<true, true>,
                        (const void*)fa2::bwd_dkv_kernel<false, true>, (const void*)fa2::bwd_dkv_kernel<true, false>, (const void*)fa2::bwd_dkv_kernel<false, false>};
   for (const void* f : fns)
+#ifdef FA2_DKV_FAT_LDS
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
+#else
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
+#endif
   g_attr = true;
   return ST5_OK;
 }
@@ -1145,7 +1163,13 @@ extern "C" int st5_flash_attn_bwd_2s(const void* q, int64_t q_ld, const void* k,
     hipLaunchKernelGGL(fa2::dvec_kernel, dim3((unsigned)((rows * 2 + 255) / 256)), dim3(256), 0, s, a.o, a.dout, dvec, a.o_ld, a.do_ld, H, T, rows);
   if (s2) { if (st5_stream_fork(s, s2) != ST5_OK) return ST5_ERR_LAUNCH; } else s2 = s;
   const size_t shm_dq = (size_t)4 * fa2::TILE_B + (pe ? 4 * fa2::SCR_B : 0);
+#ifdef FA2_DKV_FAT_LDS   // discriminator build (tools/r4/sbs_arms.sh): 104+ KB per dkv block -> one per CU, and no GEMM block beside it
+  const size_t shm_dkv = (size_t)2 * fa2::QBUF_B + (pe ? 4 * fa2::KSCR_B : 0) + 48 * 1024;
+#elif defined(FA2_DKV_HEAD_PAD)
+  const size_t shm_dkv = (size_t)2 * fa2::QBUF_B + (pe ? 4 * fa2::KSCR_B : 0) + 16 * 1024;
+#else
   const size_t shm_dkv = (size_t)2 * fa2::QBUF_B + (pe ? 4 * fa2::KSCR_B : 0);
+#endif
   const dim3 gq((T + 127) / 128, B * H), gk((S + 127) / 128, B * H), blk(256);
   const bool dr = dropout_p > 0.f;
 #define FA2_BWD(BIAS_, DROP_)                                                                        \

@@ -22,6 +22,9 @@ def seed(k):
     torch.manual_seed(1000 + k)
 
 
+if os.environ.get("HUNT_FLASH_IMPL"):   # discriminator: 1 = first-generation attention kernels (bit-identical results, other LDS layout)
+    from speecht5_amd import hip as _hip
+    _hip.check(_hip.lib().st5_flash_attn_set_impl(int(os.environ["HUNT_FLASH_IMPL"])), "st5_flash_attn_set_impl")
 seed(0)
 _, _, model, upd = bench.make_update(cuda, torch.bfloat16, "base", 8, 0, graph=True, micro=mode, layerdrop=0.05, prefetch_host=False, wgrad_stream=False)
 upd.opt.clip = clip
