@@ -126,7 +126,9 @@ int st5_gemm_set_nt_slots(int slots);
 int st5_gemm_mxfp8(const st5_gemm_params* p, const uint8_t* a_scale, int64_t a_scale_ld, const uint8_t* b_scale, int64_t b_scale_ld,
                    void* stream);
 /* MX quantisation along rows of a bf16 matrix x [rows x cols] (ld elements, cols % 32 == 0): q = e4m3(x * 2^(127 - s)) bytes
- * (pitch q_ld), s[r][c / 32] = floor(log2(max|block|)) - 8 + 127 as e8m0 (pitch s_ld); round to nearest even, saturating. */
+ * (pitch q_ld), s[r][c / 32] = floor(log2(max|finite block elements|)) - 8 + 127 as e8m0 (pitch s_ld); round to nearest even, finite
+ * values saturating at +-448.  NaN / Inf propagate: the element becomes the e4m3 NaN code 0x7f and its block's scale the e8m0 NaN 0xff,
+ * so a diverged tensor still turns the GEMM output (and the loss / gradient norm behind it) non-finite. */
 int st5_quant_mxfp8(const void* x, int64_t ld, void* q, int64_t q_ld, uint8_t* s, int64_t s_ld, int64_t rows, int32_t cols, void* stream);
 int st5_gemm_defer_splitk(int enabled, void* stream);
 int st5_gemm_flush_splitk(void* stream);

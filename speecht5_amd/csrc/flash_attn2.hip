@@ -21,6 +21,16 @@
 #ifndef FA2_ABL
 #define FA2_ABL 0
 #endif
+// Discriminator builds for the side-by-side replay difference (tools/r5/sbs_arms.sh; results unchanged, timing only):
+//   FA2_DMA_NOP     every LDS-DMA keeps its address register alive and is followed by 16 idle cycles (does the engine read the
+//                   address registers late when another kernel's DMA traffic backs the queue up?)
+//   FA2_SUB1_SLEEP  the dkv kernel's one window read that follows its own vmcnt(0) WITHOUT a barrier in between sleeps ~256 cycles
+//                   first (is an LDS-DMA counted as landed before its LDS write is visible to the issuing wave?)
+#ifdef FA2_DMA_NOP
+#define FA2_AFTER_DMA(p) asm volatile("s_nop 7\n\ts_nop 7" ::"v"(p) : "memory")
+#else
+#define FA2_AFTER_DMA(p)
+#endif
 namespace fa2 {
 
 constexpr int HD = 64;
@@ -63,6 +73,7 @@ struct TileStager {
       row = row < nrows ? row : nrows - 1;
       const bf16_t* src = base + (long long)row * ld + lc[i];
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(tile + (i * 4 + wave) * 1024), 16, 0, 0);
+      FA2_AFTER_DMA(src);
     }
   }
 };
@@ -93,6 +104,7 @@ struct WinStager {
       c = c < 0 ? 0 : (c > nchunks_data + 1 ? nchunks_data + 1 : c);
       const bf16_t* src = qpb + (((pk[i] >> 4) + (unsigned int)c) << 3);
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(scratch + i * 1024), 16, 0, 0);
+      FA2_AFTER_DMA(src);
     }
   }
 };
@@ -584,6 +596,10 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
     uint4* zp = reinterpret_cast<uint4*>(a.dqp + ((long long)bh * a.T + qblk) * a.nb);
     const int n16 = nrows * (a.nb >> 3);
     for (int i = tid; i < n16; i += 256) zp[i] = make_uint4(0u, 0u, 0u, 0u);
+    // explicit order against this block's own end-bucket stores behind the tile loop: the loop's vmcnt(0) + barrier
+    // pairs would do it too, but only while a block has at least one key tile (causal with S < T can leave a query block none)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
   int nkeys = a.S;
   if (a.causal) {
@@ -772,6 +788,7 @@ struct KWinStager {
       c = c < 0 ? 0 : (c > nchunks_data + 1 ? nchunks_data + 1 : c);
       const bf16_t* src = qpb + (unsigned int)q * (unsigned int)nbp + (unsigned int)c * 8u;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(scratch + i * 1024), 16, 0, 0);
+      FA2_AFTER_DMA(src);
     }
   }
 };
@@ -888,31 +905,34 @@ __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
     wbc = wb8 >> 3;
     mis = bmin - wb8;
   };
-  // side values of a query tile: lse2, D, dropout block keys -> registers (threads < 128), later to LDS
-  float lse_v = 0.f, d_v = 0.f, end_v = 0.f;
+  // side values of a query tile: lse2, D, dropout block keys -> registers (threads < 128), later to LDS.  side_load() only ISSUES the
+  // global loads (clamped addresses, raw bits): every use of a loaded value -- the log2e scaling, the "past T" selects, the bf16 -> fp32
+  // widening -- sits in side_store() at the END of the iteration.  (Round 4's form scaled lse inside side_load, so hipcc waited
+  // vmcnt(0) right behind it: with the next tile's four LDS-DMA instructions just issued in front, every iteration began by waiting
+  // out the whole tile prefetch it had been issued to hide.)
+  float lse_raw = 0.f, d_raw = 0.f;
+  unsigned short end_raw = 0;
+  int side_q = 0;
   unsigned int dkey = 0u;
   auto side_load = [&](int q0t) {
+    side_q = q0t + (tid & 63);
+    const int qcl = side_q < a.T ? side_q : a.T - 1;
     if (tid < 64) {
-      const int qq = q0t + tid;
-      lse_v = qq < a.T ? a.lse[bhT + qq] * LOG2E : INFINITY;
-      d_v = qq < a.T ? a.dvec[bhT + qq] : 0.f;
+      lse_raw = a.lse[bhT + qcl];
+      d_raw = a.dvec[bhT + qcl];
     }
-    if (BIAS && tid >= 128) {   // clipped end buckets of the tile's queries: threads 128-191 the low end, 192-255 the high end
-      int qq = q0t + (tid & 63);
-      qq = qq < a.T ? qq : a.T - 1;
-      end_v = (float)qpb[(unsigned int)qq * (unsigned int)nbp + (tid < 192 ? 0u : (unsigned int)(QP_PAD + a.nb))];
-    }
+    if (BIAS && tid >= 128)   // clipped end buckets of the tile's queries: threads 128-191 the low end, 192-255 the high end
+      end_raw = reinterpret_cast<const unsigned short*>(qpb)[(unsigned int)qcl * (unsigned int)nbp + (tid < 192 ? 0u : (unsigned int)(QP_PAD + a.nb))];
     if (tid < 128 && drop) {
-      const int qq = q0t + (tid & 63);
-      const unsigned long long row = (unsigned long long)bhT + (unsigned long long)(qq < a.T ? qq : a.T - 1);
+      const unsigned long long row = (unsigned long long)bhT + (unsigned long long)qcl;
       dkey = drop_block_key_folded(seedf, row * (unsigned long long)(drop_row_stride(a.lds) >> 6) + (unsigned long long)((kblk >> 6) + (tid >> 6)));
     }
   };
   auto side_store = [&](char* buf) {
     float* st = reinterpret_cast<float*>(buf + 2 * TILE_B);
-    if (tid < 64) { st[tid] = lse_v; st[64 + tid] = d_v; }
+    if (tid < 64) { st[tid] = side_q < a.T ? lse_raw * LOG2E : INFINITY; st[64 + tid] = side_q < a.T ? d_raw : 0.f; }
     if (tid < 128) reinterpret_cast<unsigned int*>(st)[128 + tid] = dkey;
-    else if (BIAS) st[128 + tid] = end_v;    // [256 .. 319] low end, [320 .. 383] high end
+    else if (BIAS) reinterpret_cast<unsigned int*>(st)[128 + tid] = (unsigned int)end_raw << 16;    // [256 .. 319] low end, [320 .. 383] high end
   };
 
   int gmode = 3, gwbc = 0, gmis = 0;   // geometry of the sub-tile whose window is in flight / in the scratch
@@ -935,7 +955,18 @@ __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
     const char* qtl = buf; const char* otl = buf + TILE_B;
     const float* stv = reinterpret_cast<const float*>(buf + 2 * TILE_B);
     const unsigned int* keyv = reinterpret_cast<const unsigned int*>(buf + 2 * TILE_B) + 128 + (wave >> 1) * 64;
+    // vmcnt(0): this wave's share of tile qt (LDS-DMA) and its window have landed.  lgkmcnt(0): its ds_writes of the tile's side
+    // array (side_store at the bottom of the previous iteration) have EXECUTED before it arrives at the barrier.  The second wait is
+    // the root cause of rounds 3-4's cross-stream irreproducibility: __syncthreads()'s release fence asks for
+    // it, but hipcc (ROCm 7.2) drops it at this loop header -- the barrier was reached behind `s_waitcnt vmcnt(0)` alone (tools/
+    // barrier_audit.py finds exactly these kernels in the whole library) -- and with a block of ANOTHER launch's bias kernel on the
+    // CU (32 ds_read_u16 per lane and tile in the same SIMD's LDS queue) a wave on another SIMD read the side array before the
+    // write had executed: 20 % of the launches of tools/r5/dkv_pair.py had wrong dK / dV rows; 0 of 800 with this wait.
+#ifdef FA2_NO_LGKM_BARRIER   // (the round-4 form, for the reproducer's A/B arm only)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
     __syncthreads();   // tile qt (DMA + side values) visible; every wave is done with tile qt-1's buffer
     if (qt + 1 < nqt) {
       char* nb_ = smem + ((qt + 1) & 1) * QBUF_B;
@@ -952,6 +983,9 @@ __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
       unsigned int braw[16];   // fp32 bit patterns of the bias values
       if (BIAS && bmode == 0) {
         if (sub == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window issued during sub 0 (own DMA, own reads)
+#ifdef FA2_SUB1_SLEEP
+        if (sub == 1) asm volatile("s_sleep 4" ::: "memory");
+#endif
         const unsigned short* pw = reinterpret_cast<const unsigned short*>(scratch + rd_lane + mis * 2);
 #if FA2_ABL == 2
         for (int r = 0; r < 16; ++r) { braw[r] = 0x3c000000u + (r << 16); asm volatile("" : "+v"(braw[r])); }
@@ -1144,6 +1178,7 @@ extern "C" int st5_flash_attn_bwd_2s(const void* q, int64_t q_ld, const void* k,
   if (dtype != ST5_BF16 || head_dim != fa2::HD) return ST5_ERR_ARG;
   if (q_ld % 8 || k_ld % 8 || v_ld % 8 || o_ld % 8 || do_ld % 8 || dq_ld % 4 || dk_ld % 4 || dv_ld % 4) return ST5_ERR_ALIGN;
   if (pe && (!qp || !dqp || nb != 2 * maxrel || nb % 8 || nb > 1024)) return ST5_ERR_ARG;
+  if (pe && (reinterpret_cast<uintptr_t>(dqp) % 16) != 0) return ST5_ERR_ALIGN;   // the dq kernel clears dQP with 16-byte stores (rows are nb % 8 == 0 bf16 long)
   if ((long long)B * H * T * (pe ? nb + 16 : 1) >= (1ll << 31)) return ST5_ERR_ARG;
   if (set_attrs() != ST5_OK) return ST5_ERR_LAUNCH;
   fa2::BwdArgs a;

@@ -2119,7 +2119,7 @@ int launch_mx8_as(const st5_gemm_params& p, int c_vec_ok, const unsigned char* s
 
 // MX quantisation of a row-major bf16 matrix along its rows: per 32 consecutive elements one e8m0 scale byte
 // E = floor(log2(amax)) - 8 + 127 (the OCP MX rule for e4m3, whose largest binade is 2^8) and 32 e4m3 bytes of x * 2^(127 - E),
-// round-to-nearest-even, saturating at +-448.  Four lanes per block, 8 elements each: coalesced 16-byte loads and 8-byte stores
+// round-to-nearest-even, saturating FINITE values at +-448 (NaN / Inf propagate: see the kernel).  Four lanes per block, 8 elements each: coalesced 16-byte loads and 8-byte stores
 // (the first version gave a lane a whole block: 64-byte stride between the lanes of every load instruction), the block maximum by
 // two quad shuffles.
 __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict__ x, long long ld, unsigned char* __restrict__ q, long long q_ld,
@@ -2131,11 +2131,23 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict
     const int g = (int)(i - row * ng);
     float v[8];
     load8f<bf16_t>(x + row * ld + g * 8, v);
+    // Non-finite inputs PROPAGATE: fmaxf ignores a NaN and the clamp below would turn NaN / Inf into +-448, so a diverged
+    // activation or gradient would never reach the loss / the gradient norm in fp8 mode.  The block maximum is taken over the FINITE
+    // elements (an Inf must not push the scale to 2^120 and zero its 31 neighbours); a non-finite element gets the e4m3 NaN code
+    // 0x7f, and the block's scale byte becomes the e8m0 NaN 0xff (OCP MX: the whole block then dequantises to NaN).
     float amax = 0.f;
+    unsigned int nf = 0u;          // bit e: element e is NaN or Inf
 #pragma unroll
-    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    for (int e = 0; e < 8; ++e) {
+      const bool bad = (__float_as_uint(v[e]) & 0x7f800000u) == 0x7f800000u;
+      nf |= bad ? (1u << e) : 0u;
+      amax = fmaxf(amax, bad ? 0.f : fabsf(v[e]));
+    }
     amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
     amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    unsigned int nf_blk = nf != 0u ? 1u : 0u;
+    nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 1, 64);
+    nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 2, 64);
     int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;      // biased exponent of amax, minus emax(e4m3)
     E = E < 0 ? 0 : (E > 254 ? 254 : E);
     const float inv = __uint_as_float((unsigned int)(254 - E) << 23);    // 2^(127 - E)
@@ -2144,14 +2156,21 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict
     for (int w = 0; w < 2; ++w) {
       float f[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float t = v[4 * w + e] * inv; f[e] = fminf(fmaxf(t, -448.f), 448.f); }
+      for (int e = 0; e < 4; ++e) {
+        const float t = ((nf >> (4 * w + e)) & 1u) ? 0.f : v[4 * w + e] * inv;
+        f[e] = fminf(fmaxf(t, -448.f), 448.f);
+      }
       int pk = 0;
       pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
       pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
-      o[w] = (unsigned int)pk;
+      unsigned int u = (unsigned int)pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((nf >> (4 * w + e)) & 1u) u = (u & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
+      o[w] = u;
     }
     *reinterpret_cast<u32x2*>(q + row * q_ld + g * 8) = o;
-    if ((g & 3) == 0) s[row * s_ld + (g >> 2)] = (unsigned char)E;
+    if ((g & 3) == 0) s[row * s_ld + (g >> 2)] = nf_blk ? (unsigned char)0xff : (unsigned char)E;
   }
 }
 
@@ -2368,7 +2387,7 @@ extern "C" int st5_gemm_set_deep_ring(int max_blocks, int nbuf) {
   if (max_blocks < 0 || nbuf < 2 || nbuf > 4) return ST5_ERR_ARG;
   g_deep_blocks = max_blocks; g_deep_nbuf = nbuf; return ST5_OK;
 }
-/* Weight-gradient (TN) GEMMs without row split / segments: 1 (default) = phased 256^2 kernel, 2 = the same without the stagger of the
- * two m-halves, 0 = always the 128^2 LDS-DMA kernel (A/B measurements). */
+/* Weight-gradient (TN) GEMMs without row split / segments: 0 (default) = always the 128^2 LDS-DMA kernel; 1 = phased 256^2 kernel,
+ * 2 = the same without the stagger of the two m-halves (A/B measurements; the header documents the same default). */
 extern "C" int st5_gemm_set_tn_phased(int mode) { if (mode < 0 || mode > 2) return ST5_ERR_ARG; g_tn8p = mode; return ST5_OK; }
 extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 4) return ST5_ERR_ARG; g_nt_tile = mode; return ST5_OK; }

@@ -50,7 +50,10 @@ class FlatGradDataParallel:
         # ST5_DDP_FORCE_COLLECTIVES=1 runs the bucketed async all-reduce path even in a 1-rank group (used to exercise the
         # RCCL stream / event plumbing on a single-GPU box; a 1-rank all-reduce leaves the data unchanged)
         self.collectives = self.world > 1 or (os.environ.get("ST5_DDP_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
-        self.overlap_exchange = None    # decided at the first bucket trigger (exchange_overlap_allowed: RCCL needs NCCL_ALGO=Ring)
+        # May collectives run underneath the backward?  Decided ONCE, here, and agreed over the group: every rank must
+        # issue the same sequence of collectives -- per-bucket / per-range all-reduces when the answer is yes, one message behind
+        # the backward when it is no -- so a rank whose environment differs (NCCL_ALGO missing on one of them) pulls all to "no".
+        self.overlap_exchange = agreed_exchange_overlap(process_group, next(model.parameters()).device) if self.collectives else True
         groups = [g if isinstance(g, BucketGroup) else BucketGroup(list(g)) for g in
                   (bucket_groups if bucket_groups is not None else default_buckets(model))]
         nb = len(groups)
@@ -204,8 +207,6 @@ class FlatGradDataParallel:
         if not self.collectives or self._accumulating:
             return
         self._ready[bi] = True
-        if self.overlap_exchange is None:
-            self.overlap_exchange = exchange_overlap_allowed(self.pg)
         if self.overlap_exchange:           # else: finish() launches every bucket, in index order, behind the backward
             self._launch_in_order(False)
 
@@ -519,6 +520,22 @@ def exchange_overlap_allowed(pg=None, warn=True):
                       "(RCCL's tree / PreMulSum kernels contain packed-fp32 ops that are unsafe beside MFMA kernels on gfx950; "
                       "export NCCL_ALGO=Ring before the process group is created to get the overlapped exchange)")
     return ok
+
+
+def agreed_exchange_overlap(pg=None, device=None):
+    """exchange_overlap_allowed() of THIS rank, MIN-reduced over the group: the one answer every rank acts on."""
+    ok = exchange_overlap_allowed(pg)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(pg) == 1:
+        return ok
+    on_dev = dist.get_backend(pg) == "nccl"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_dev else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
+    agreed = bool(int(flag.item()))
+    if ok and not agreed:
+        import warnings
+        warnings.warn("speecht5_amd: another rank does not allow the overlapped gradient exchange (NCCL_ALGO differs between ranks): "
+                      "every rank falls back to one message behind the backward")
+    return agreed
 
 
 def _fusion_ordered_parameters(module):

@@ -61,7 +61,7 @@ class _Dictionary(list):
         d = cls()
         with open(path, encoding="utf-8") as f:
             for line in f:
-                line = line.rstrip("\n")
+                line = line.rstrip()       # (fairseq's add_from_file: line.rstrip() -- CRLF files and trailing blanks parse the same)
                 if not line:
                     continue
                 sym, _, count = line.rpartition(" ")

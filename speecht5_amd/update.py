@@ -53,10 +53,8 @@ class PretrainUpdate:
         # (ST5_EAGER_PHASED=1: the same three phases enqueued eagerly -- tools/diag/diag_phased.py, the tests' reference point)
         self.phased = ((self.split or (self.ddp.collectives and os.environ.get("ST5_EAGER_PHASED") == "1"))
                        and micro == "in_turn" and exchange == "phased" and len(self.micro) >= 1)
-        if self.phased:
-            from .ddp import exchange_overlap_allowed
-            if not exchange_overlap_allowed(self.ddp.pg):
-                self.phased = False      # one message behind the local phase: no collective beside the backward's kernels
+        if self.phased and not self.ddp.overlap_exchange:    # (decided once per group in FlatGradDataParallel, the same on every rank)
+            self.phased = False      # one message behind the local phase: no collective beside the backward's kernels
         self._ph = None
         self.n = 0            # update counter (fairseq's num_updates)
         self.sg = None

@@ -15,7 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(cuda, graph, micro, n_updates, layerdrop=0.05, batch=8, poison=False, exchange="phased"):
+def _run(cuda, graph, micro, n_updates, layerdrop=0.05, batch=8, poison=False, exchange="phased", info=None):
     import contextlib
     import bench
     from speecht5_amd import functional as Fn
@@ -24,6 +24,8 @@ def _run(cuda, graph, micro, n_updates, layerdrop=0.05, batch=8, poison=False, e
     try:
         _, _, model, upd = bench.make_update(cuda, torch.bfloat16, "base", batch, 0, graph=graph, micro=micro, layerdrop=layerdrop,
                                              exchange=exchange)   # prefetch_host: bench.make_update's default = what bench.py times
+        if info is not None:
+            info.update(phased=upd.phased, split=upd.split, overlap=upd.ddp.overlap_exchange)
         with poisoned_allocations() if poison else contextlib.nullcontext():
             if graph:
                 upd.prepare_graph()                     # two recorded updates
@@ -88,24 +90,45 @@ def test_side_by_side_measurement_mode_stays_close(cuda):
 
 
 def test_several_rank_forms_of_the_update_equal_the_one_rank_update(cuda):
-    """What `bench.py --gpus N` runs on several ranks, exercised here in a ONE-rank RCCL group (ST5_DDP_FORCE_COLLECTIVES): the
-    local phase replayed as three graphs cut at bucket boundaries with the completed bucket range all-reduced (async, on RCCL's
-    stream) after each (`exchange="phased"`), and as one graph + one all-reduce of the whole buffer (`"one_message"`); Adam
-    eagerly behind.  A one-rank all-reduce leaves the data unchanged, so both must reproduce the one-rank replayed update bit for
-    bit -- the cuts, the phase order, the collective plumbing and the eager tail change nothing in the arithmetic."""
+    """What `bench.py --gpus N` runs on several ranks, exercised here in a ONE-rank RCCL group (ST5_DDP_FORCE_COLLECTIVES) with
+    NCCL_ALGO=Ring exported BEFORE the group exists, as bench.py does: the local phase replayed as three graphs cut at bucket
+    boundaries with the completed bucket range all-reduced (async, on RCCL's stream) after each (`exchange="phased"`), and as one
+    graph + one all-reduce of the whole buffer (`"one_message"`); Adam eagerly behind.  A one-rank all-reduce leaves the data
+    unchanged, so every form must reproduce the one-rank replayed update bit for bit -- the cuts, the phase order, the collective
+    plumbing and the eager tail change nothing in the arithmetic.  Each arm ASSERTS the form it ran (without the
+    Ring setting all three arms silently ran the one-message form); the no-Ring fallback is its own arm."""
     import os
     import torch.distributed as dist
     ref = _run(cuda, True, "in_turn", 5)
+    saved = {k: os.environ.get(k) for k in ("NCCL_ALGO", "ST5_DDP_FORCE_COLLECTIVES", "ST5_EAGER_PHASED")}
+    os.environ["NCCL_ALGO"] = "Ring"
     os.environ["ST5_DDP_FORCE_COLLECTIVES"] = "1"
     os.environ["ST5_EAGER_PHASED"] = "1"
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29700 + os.getpid() % 200}", rank=0, world_size=1, device_id=cuda)
     try:
         for exchange in ("phased", "one_message"):
-            got = _run(cuda, True, "in_turn", 5, exchange=exchange)      # (2 recorded + 3 replayed updates)
+            info = {}
+            got = _run(cuda, True, "in_turn", 5, exchange=exchange, info=info)      # (2 recorded + 3 replayed updates)
+            assert info["split"] and info["overlap"] and info["phased"] == (exchange == "phased"), info
             assert got[3] == ref[3] == 5
             _same(ref, got, f"several-rank form ({exchange}) vs one-rank update")
-        eager = _run(cuda, False, "in_turn", 5, exchange="phased")      # the same phases enqueued eagerly (ST5_EAGER_PHASED)
+        info = {}
+        eager = _run(cuda, False, "in_turn", 5, exchange="phased", info=info)      # the same phases enqueued eagerly (ST5_EAGER_PHASED)
+        assert info["phased"] and not info["split"], info
         _same(ref, eager, "eager phased vs one-rank replay")
+        # without NCCL_ALGO=Ring the exchange must NOT go underneath the backward: "phased" degrades to one message, same numbers
+        os.environ["NCCL_ALGO"] = ""
+        info = {}
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = _run(cuda, True, "in_turn", 5, exchange="phased", info=info)
+        assert info["split"] and not info["overlap"] and not info["phased"], info
+        _same(ref, got, "no-Ring fallback (one message) vs one-rank update")
     finally:
         dist.destroy_process_group()
-        del os.environ["ST5_DDP_FORCE_COLLECTIVES"], os.environ["ST5_EAGER_PHASED"]
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -46,6 +46,37 @@ def test_quantiser_is_the_mx_rule_bit_for_bit(cuda, rows, cols, scale):
     assert torch.equal(q, rq), f"{int((q != rq).sum())} of {q.numel()} fp8 bytes differ"
 
 
+def test_quantiser_propagates_non_finite_inputs(cuda):
+    """a NaN or Inf must reach the GEMM output (and with it the loss / the gradient norm) instead of being clamped to
+    +-448: the element becomes the e4m3 NaN code 0x7f, its block's scale the e8m0 NaN 0xff, the OTHER elements of the block keep the
+    codes the finite block maximum gives them, and other blocks are untouched."""
+    torch.manual_seed(3)
+    x = torch.randn(16, 256, device=cuda).to(torch.bfloat16)
+    clean_q, clean_s = hip.quant_mxfp8(x)
+    bad = x.clone()
+    bad[2, 7] = float("nan")
+    bad[5, 40] = float("inf")
+    bad[5, 41] = float("-inf")
+    q, s = hip.quant_mxfp8(bad)
+    torch.cuda.synchronize()
+    assert int(s[2, 0]) == 0xff and int(s[5, 1]) == 0xff
+    assert int(q[2, 7]) == 0x7f and int(q[5, 40]) == 0x7f and int(q[5, 41]) == 0x7f
+    keep = torch.ones_like(s, dtype=torch.bool); keep[2, 0] = False; keep[5, 1] = False
+    assert torch.equal(s[keep], clean_s[keep])
+    other = torch.ones_like(q, dtype=torch.bool); other[2, :32] = False; other[5, 32:64] = False
+    assert torch.equal(q[other], clean_q[other])
+    # the finite neighbours of the Inf are NOT flushed to zero by an Inf-sized scale
+    assert int((q[5, 32:64] & 0x7f).ne(0).sum()) >= 28
+    # and the GEMM carries it to the output rows that consume the block
+    W = (torch.randn(64, 256, device=cuda) * 0.05).to(torch.bfloat16)
+    Wq, Ws = hip.quant_mxfp8(W)
+    C = torch.zeros(16, 64, dtype=torch.bfloat16, device=cuda)
+    hip.gemm_mxfp8(q, s, Wq, Ws, hip.operand(C, 64), 16, 64, 256)
+    torch.cuda.synchronize()
+    fin = torch.isfinite(C.float()).all(dim=1)
+    assert not bool(fin[2]) and not bool(fin[5]) and bool(fin[[0, 1, 3, 4] + list(range(6, 16))].all())
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 1024), (4096, 1024, 1024), (1000, 4096, 1024), (333, 520, 4096), (8192, 1024, 4096)])
 def test_mx_gemm_matches_fp32_matmul_of_the_dequantised_operands(cuda, M, N, K):
     torch.manual_seed(M + N)

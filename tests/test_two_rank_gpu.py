@@ -17,16 +17,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(nproc, exchange, out, port):
+def _launch(nproc, exchange, out, port, extra=()):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["OMP_NUM_THREADS"] = "8"
     worker = os.path.join(ROOT, "tests", "two_rank_worker.py")
     if nproc == 1:
-        cmd = [sys.executable, worker, "--exchange", exchange, "--out", out]
+        cmd = [sys.executable, worker, "--exchange", exchange, "--out", out] + list(extra)
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), worker, "--exchange", exchange, "--out", out]
+               "--master-port", str(port), worker, "--exchange", exchange, "--out", out] + list(extra)
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, f"{' '.join(cmd)}\n{r.stdout[-3000:]}\n{r.stderr[-6000:]}"
     return [json.load(open(f"{out}.rank{k}.json")) for k in range(nproc)]
@@ -42,3 +42,26 @@ def test_two_ranks_sharing_the_gpu_equal_the_one_rank_update(cuda, tmp_path):
         assert ranks[0]["t"] == ranks[1]["t"] == 4
         assert ranks[0]["digest"] == ranks[1]["digest"], f"{exchange}: the two ranks disagree ({ranks[0]['pnorm']} vs {ranks[1]['pnorm']})"
         assert ranks[0]["digest"] == one["digest"], f"{exchange}: two ranks != one rank ({ranks[0]['pnorm']} vs {one['pnorm']})"
+
+
+def test_two_ranks_with_their_own_data_exchange_exactly_the_sum_of_their_gradients(cuda, tmp_path):
+    """the same-data test above cannot see a reduction that mixes the ranks' buffers.  Here rank r holds its own
+    data and seeds, lr = 0 (parameters fixed), and the gradient buffer the optimizer step receives in the 4th update of the two-rank
+    REPLAYED run (phased and one-message exchange) must equal g_rank0 + g_rank1 of two one-rank eager runs, bit for bit (a sum of
+    two fp32 values does not depend on the order)."""
+    import torch
+    g = []
+    for r in (0, 1):
+        info = _launch(1, "phased", str(tmp_path / f"ref{r}"), 0, extra=["--no-graph", "--data-rank", str(r)])[0]
+        assert info["grad_calls"] == 4 and info["data_rank"] == r
+        g.append(torch.load(str(tmp_path / f"ref{r}") + ".rank0.grad.pt"))
+    assert not torch.equal(g[0], g[1]) and torch.isfinite(g[0]).all() and torch.isfinite(g[1]).all()
+    want = g[0] + g[1]
+    for i, exchange in enumerate(("phased", "one_message")):
+        out = str(tmp_path / f"own_{exchange}")
+        ranks = _launch(2, exchange, out, 29631 + i, extra=["--own-data"])
+        assert all(r["split"] and r["phased"] == (exchange == "phased") and r["grad_calls"] == 4 for r in ranks)
+        for k in (0, 1):
+            got = torch.load(f"{out}.rank{k}.grad.pt")
+            assert torch.equal(got, want), (f"{exchange}, rank {k}: exchanged buffer != g0 + g1 "
+                                            f"({int((got != want).sum())} of {got.numel()} sampled elements differ)")
