@@ -6,9 +6,11 @@
 
 One step = what one optimizer update of the reference recipe does with --update-freq 2 (SURVEY.md 3.1-3.2,
 8d cfg 2): forward+backward of ONE speech micro-batch (8 x 10 s synthetic 16 kHz clips, HuBERT-mask + NCE +
-mel decoder branch) and ONE text micro-batch (16 x 512 tokens, BART infilling) -- in turn on one stream, replayed as one HIP
-graph (`--micro side_by_side`: on two streams, faster but not bit-reproducible on this hardware) -- the gradient all-reduce over the ranks (RCCL: one message behind every replay; `--no-graph`: bucketed and
-overlapped with an eagerly enqueued backward), global-norm clip and the fused Adam update.  bf16 compute, fp32
+mel decoder branch) and ONE text micro-batch (16 x 512 tokens, BART infilling) -- side by side on two streams, replayed as one HIP
+graph (`--micro in_turn`: one after the other on one stream, the reference trainer's order; the SAME bits either way)
+-- the gradient all-reduce over the ranks (RCCL: one message behind every replay; `--micro in_turn --exchange phased`: in three bucket
+ranges underneath the last backward; `--no-graph`: bucketed and overlapped with an eagerly enqueued backward), global-norm clip and
+the fused Adam update.  bf16 compute, fp32
 master weights / statistics; dropout and LayerDrop active as t5_transformer_base ships them (0.1, attention 0.1, pre-net 0.5,
 post-net 0.5; encoder / decoder LayerDrop 0.05, models/speecht5.py:1397-1398 -- inside the replayed graph a dropped layer is
 selected away on the device, i.e. it still runs: no work is skipped in the timed region).  Inputs are resident in HBM.
@@ -115,7 +117,7 @@ def cpu_baseline(model, args, seconds=4.0, runs=5):
     return out
 
 
-def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, graph=True, micro="in_turn", layerdrop=0.05,
+def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, graph=True, micro="side_by_side", layerdrop=0.05,
                 wgrad_stream=None, prefetch_host=True, text_batch=16, text_len=512, seconds=10.0, exchange="phased"):
     """The update bench.py times, as an object (speecht5_amd/update.py): model, criterion, the two synthetic micro-batches of
     BASELINE.json cfg 2, FlatGradDataParallel + FusedAdam with the recipe's hyper-parameters.  tests/test_bench_update_gpu.py
@@ -188,9 +190,9 @@ def main():
                          "headline is base")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying a captured HIP graph")
     ap.add_argument("--layerdrop", type=float, default=0.05, help="encoder / decoder LayerDrop (t5_transformer_base: 0.05)")
-    ap.add_argument("--micro", default="in_turn", choices=["side_by_side", "in_turn_2buf", "in_turn"],
-                    help="how the update's two micro-batches are enqueued (speecht5_amd/update.py); in_turn = one stream, "
-                         "bit-reproducible; side_by_side = two streams, faster, not reproducible on this hardware (DESIGN.md 4a)")
+    ap.add_argument("--micro", default="side_by_side", choices=["side_by_side", "in_turn_2buf", "in_turn"],
+                    help="how the update's two micro-batches are enqueued (speecht5_amd/update.py): side_by_side = two streams (default, "
+                         "~20 %% faster); in_turn = one stream, the reference trainer's order.  Bit-identical results (DESIGN.md 4c)")
     ap.add_argument("--exchange", default="phased", choices=["phased", "one_message"],
                     help="several ranks, graph replay: phased = the local phase as 3 graphs, each completed bucket range all-reduced "
                          "under the next graph; one_message = one graph, then one all-reduce of the whole gradient buffer")
@@ -242,6 +244,8 @@ def main():
         hip.lib().st5_gemm_set_deep_ring(*[int(v) for v in os.environ["ST5_DEEP_RING"].split(",")])
     if os.environ.get("ST5_SPLITK_TARGET"):   # A/B: block count the weight-gradient split-K aims for
         hip.lib().st5_gemm_set_splitk_target(int(os.environ["ST5_SPLITK_TARGET"]))
+    if os.environ.get("ST5_TN_PHASED"):   # A/B: 1 / 2 = weight-gradient GEMMs on the phased 256x256 kernel (default 0 = the 128x128 kernel)
+        hip.lib().st5_gemm_set_tn_phased(int(os.environ["ST5_TN_PHASED"]))
     if os.environ.get("ST5_NT_SLOTS"):   # A/B: 4 = two-stage operand ring of the 128x128 NT kernel (default 5 = five operand slots)
         hip.lib().st5_gemm_set_nt_slots(int(os.environ["ST5_NT_SLOTS"]))
     if os.environ.get("ST5_LN_MAX_BLOCKS"):   # A/B: block cap of the single-pass LayerNorm backward (default 256)
@@ -283,10 +287,14 @@ def main():
         # roofline leg of the graph mode: the replayed launches carry no events, so the SAME update is enqueued once more
         # eagerly, outside the timed region, with HIP events around every st5_gemm launch (same kernels, shapes, streams; the
         # fixed-shape / device-side-LayerDrop forms the graph is made of)
+        # -- with the micro-batches IN TURN on one stream, whatever the timed mode: a launch's event pair then brackets that kernel
+        # alone (side by side, the other stream's kernels share the chip during it and the rate would be the pair's, not the kernel's)
         from speecht5_amd import functional as Fn
         hip.profiler.enabled = True
         Fn._S.force_static = True
+        timed_mode, upd.mode = upd.mode, "in_turn"
         upd.eager_update()
+        upd.mode = timed_mode
         Fn._S.force_static = False
         torch.cuda.synchronize()
         hip.profiler.enabled = False
@@ -351,7 +359,8 @@ def main():
     roof = {"bound": "mfma", "kernel": f"NT-form st5_gemm launches <{a.dtype}> (Linear / attention-projection / conv forward and data-gradient GEMMs; "
                       f"`traffic` is per launch of {NT_KERNEL_NAME})",
             "note": ("launch durations: HIP events around every st5_gemm launch of ONE eagerly enqueued update after the timed region "
-                     "(replayed launches carry no events), micro-batches enqueued as in the timed steps (config.micro_batches)"
+                     "(replayed launches carry no events) with the micro-batches in turn on one stream, so that every event pair brackets "
+                     "one kernel alone"
                      if use_graph else
                      "launch durations are measured inside the step, i.e. beside the weight-gradient stream's kernels "
                      "(ST5_WGRAD_STREAM=0 gives the isolated rate, ~8 % higher)"),

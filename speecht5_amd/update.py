@@ -1,22 +1,25 @@
 """One optimizer update of the pre-training recipe (`--update-freq 2`: a speech micro-batch and a text micro-batch, SURVEY.md
-3.1-3.2) the way bench.py times it: forward + backward of both micro-batches (in turn on one stream by default), the gradient
-exchange over the ranks, global-norm clip and the fused Adam step -- enqueued eagerly or replayed as a HIP graph.  bench.py and tests/test_bench_update_gpu.py build their step from THIS class, so the thing that is timed is the
-thing whose results are checked.
+3.1-3.2) the way bench.py times it: forward + backward of both micro-batches, the gradient exchange over the ranks, global-norm clip
+and the fused Adam step -- enqueued eagerly or replayed as a HIP graph.  bench.py and tests/test_bench_update_gpu.py build their step
+from THIS class, so the thing that is timed is the thing whose results are checked.
 
 Modes (what the reference's trainer does in turn -- tasks/speecht5.py:519-556 called once per micro-batch by fairseq's
 Trainer.train_step, gradients summed, one optimizer step -- is `micro="in_turn"`; the other modes reorder execution, never
-arithmetic):
+arithmetic: every mode produces the SAME bits, tests/test_bench_update_gpu.py and tests/test_replay_long_gpu.py):
 
-  micro      "in_turn"       (default) one stream, one gradient buffer, ddp.accumulate: the reference trainer's order.  Results are
-                             reproducible bit for bit and replay == eager enqueue (tests/test_bench_update_gpu.py, full size)
+  micro      "side_by_side"  (default) both micro-batches on two streams, forward and backward, two gradient buffers summed inside the
+                             Adam kernel (a + b == b + a bit for bit).  31.5 ms per update against 39.5 in turn on one MI355X: the
+                             two branches fill each other's tile-quantisation tails and launch gaps.  Rounds 3-4 kept this mode off
+                             because ~1 % of its replays differed; round 5 found the cause -- one missing `s_waitcnt lgkmcnt(0)` in
+                             front of a barrier of the attention backward -- and 300 replayed updates now
+                             reproduce the in-turn trajectory bit for bit in every process
+             "in_turn"       one stream, one gradient buffer, ddp.accumulate: the reference trainer's order
              "in_turn_2buf"  two streams / two gradient buffers, the second backward ordered behind the first
-             "side_by_side"  both micro-batches on two streams, forward and backward.  ~25 % faster on one rank, but NOT
-                             reproducible on this hardware: kernels of the two streams that share a CU perturb each other
-                              -- kept as a measurement mode
   graph      True: the update (one rank) or its local phase (several ranks) is captured once and replayed
-  several ranks, graph: the captured part is the LOCAL phase (zero_grad, both micro-batches); exchange = "phased" (default) cuts
-             it into three graphs and all-reduces each completed bucket range under the next one, "one_message" keeps one
-             graph and one all-reduce of the whole buffer behind it; Adam follows eagerly
+  several ranks, graph: the captured part is the LOCAL phase (zero_grad, both micro-batches); with micro="in_turn",
+             exchange="phased" cuts it into three graphs and all-reduces each completed bucket range under the next one;
+             otherwise ("one_message", and always with the micro-batches side by side) one graph and one all-reduce of the whole
+             buffer behind it; Adam follows eagerly
 """
 import os
 
@@ -28,7 +31,7 @@ from . import functional as Fn
 
 class PretrainUpdate:
     def __init__(self, task, model, criterion, micro_batches, *, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0,
-                 graph=True, micro="in_turn", wgrad_stream=None, prefetch_host=True, device=None, lr_fn=None, exchange="phased"):
+                 graph=True, micro="side_by_side", wgrad_stream=None, prefetch_host=True, device=None, lr_fn=None, exchange="phased"):
         from .ddp import FlatGradDataParallel, FusedAdam
         assert micro in ("side_by_side", "in_turn_2buf", "in_turn")
         self.task, self.model, self.crit, self.micro = task, model, criterion, list(micro_batches)
@@ -36,8 +39,8 @@ class PretrainUpdate:
         self.use_graph = graph
         self.device = device if device is not None else next(model.parameters()).device
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        # every form of cross-stream kernel concurrency is OFF by default: the micro-batches in turn, no
-        # weight-gradient stream, no attention helper stream -- one stream, results reproducible bit for bit, replay == eager
+        # no weight-gradient stream, no attention helper stream: beside two micro-batch streams they cost time (42.0 against 31.5 ms,
+        # profiles/r5_replay_hunt.txt); results are the same bits with and without them
         if wgrad_stream is None:
             wgrad_stream = False
         self.ddp = FlatGradDataParallel(model, wgrad_stream=wgrad_stream)

@@ -41,4 +41,4 @@ def test_flags_of_the_driver_contract_parse(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "3", "--steps", "4", "--warmup", "2"])
     bench.main()
     assert got["config"] == 3 and got["steps"] == 4 and got["warmup"] == 2 and got["gpus"] == 1
-    assert got["exchange"] == "phased" and got["micro"] == "in_turn" and got["layerdrop"] == 0.05
+    assert got["exchange"] == "phased" and got["micro"] == "side_by_side" and got["layerdrop"] == 0.05
