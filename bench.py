@@ -117,6 +117,28 @@ def cpu_baseline(model, args, seconds=4.0, runs=5):
     return out
 
 
+def box_info():
+    """Which box this line was measured on (the pool's boxes differ by up to 20 % for the same commit, profiles/r4_knob_ab.txt): device
+    name, CU count, and the clocks / power cap rocm-smi reports at the end of the run -- so a slow line is attributable."""
+    import socket
+    import subprocess
+    info = {"host": socket.gethostname()}
+    try:
+        p = torch.cuda.get_device_properties(0)
+        info.update(device=p.name, cus=p.multi_processor_count, hbm_gb=round(p.total_memory / 2 ** 30))
+    except Exception:
+        pass
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=15)
+        d = json.loads(r.stdout)
+        c0 = d.get("card0", {})
+        keep = {k: v for k, v in c0.items() if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "power", "junction", "edge"))}
+        info["rocm_smi_card0"] = dict(list(keep.items())[:12])
+    except Exception as e:
+        info["rocm_smi_card0"] = f"unavailable ({type(e).__name__})"
+    return info
+
+
 def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, graph=True, micro="side_by_side", layerdrop=0.05,
                 wgrad_stream=None, prefetch_host=True, text_batch=16, text_len=512, seconds=10.0, exchange="phased"):
     """The update bench.py times, as an object (speecht5_amd/update.py): model, criterion, the two synthetic micro-batches of
@@ -171,7 +193,31 @@ def config3(a):
                         "step": {"gemm_tflop_per_update": tts["gemm"]["gemm_tflop"], "tflops": tts["step_tflops"], "frac_of_peak": tts["step_frac_of_peak"]},
                         "all_variants": tts["gemm"]["by_variant"]},
            "vocoder": voc}
-    print(json.dumps(out))
+    emit(out)
+
+
+_RESULT_FD = None
+_AS_SCRIPT = False     # set by `python bench.py`: only then is the process's stdout descriptor re-pointed
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner from C when a
+    process group comes up or goes down), so file descriptor 1 is pointed at stderr for the whole run and the result line goes to
+    the saved original descriptor (emit)."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_RESULT_FD, line)
 
 
 def main():
@@ -201,6 +247,8 @@ def main():
                          "(32 texts x 100 tokens -> 600 mel frames, guided attention, replayed) + full-size HiFi-GAN on the same "
                          "32 x 600 frames, one GPU")
     a = ap.parse_args()
+    if _AS_SCRIPT and ("WORLD_SIZE" in os.environ or a.gpus == 1):   # (not in the parent that only re-executes itself under torch.distributed.run)
+        quiet_stdout()
     if a.config == 3:
         return config3(a)
 
@@ -298,6 +346,26 @@ def main():
         Fn._S.force_static = False
         torch.cuda.synchronize()
         hip.profiler.enabled = False
+    local_ms = None
+    if use_graph and split_update and upd.sg is not None and upd.sg.graph is not None:
+        # the captured local phase alone (zero_grad + both micro-batches; idempotent: it starts from cleared buffers), 5 replays
+        torch.cuda.synchronize()
+        with torch.cuda.stream(upd.sg.stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            upd.ddp.flat.zero_()
+            if upd.ddp.flat2 is not None:
+                upd.ddp.flat2.zero_()
+            e0.record()
+            for _ in range(5):
+                upd.sg.graph.replay()
+            e1.record()
+        torch.cuda.synchronize()
+        local_ms = round(e0.elapsed_time(e1) / 5, 3)
+        upd.ddp.flat.zero_()
+        if upd.ddp.flat2 is not None:
+            upd.ddp.flat2.zero_()
+        upd.ddp._pair_pending = False
+        upd.ddp._grads_zeroed = True
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -412,14 +480,24 @@ def main():
                           "dropout": 0.1, "layerdrop": a.layerdrop,
                           "layerdrop_form": ("device-side select (every layer runs)" if use_graph else "host skip") if a.layerdrop > 0 else "off"},
                "roofline": roof}
+        # what the ranks exchange per update and how (so that a scaling curve can be read): message sizes, payload,
+        # the RCCL algorithm in force, and the time of the replayed local phase alone (ms_per_step minus it = exposed exchange + Adam)
+        if split_update or world > 1:
+            msgs = upd.ddp.exchange_plan(phased=bool(getattr(upd, "phased", False)), cuts=upd.cut_buckets() if getattr(upd, "phased", False) else None)
+            out["config"]["exchange"] = {"form": "phased" if getattr(upd, "phased", False) else ("one_message" if split_update else "bucketed, overlapped with an eager backward"),
+                                         "backend": dist.get_backend() if dist.is_initialized() else None,
+                                         "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "payload": "fp32 gradients, sum; mean over ranks and micro-batches inside Adam",
+                                         "message_bytes": msgs, "local_phase_ms": local_ms}
+        out["config"]["box"] = box_info()
         if shared:
             out["config"]["note"] = f"FUNCTIONAL CHECK ONLY: {world} ranks share {ndev} GPU(s), gradients exchanged over gloo"
         if world == 1 and not a.no_cpu_baseline and a.arch == "base":
             out["cpu_baseline"] = cpu_baseline(model, args)
-        print(json.dumps(out))
+        emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
+    _AS_SCRIPT = True
     main()

@@ -381,6 +381,20 @@ class FlatGradDataParallel:
             self._works.append(dist.all_reduce(self.flat[s:e], group=self.pg, async_op=True))
         self._next = hi + 1
 
+    def exchange_plan(self, phased=False, cuts=None):
+        """Bytes of every all-reduce message of one update, in launch order: the bucket ranges of the phased exchange (cuts =
+        PretrainUpdate.cut_buckets()), the buckets of the eager overlapped path, or the whole buffer (one message)."""
+        es = self.flat.element_size()
+        if phased and cuts is not None:
+            out, lo = [], 0
+            for hi in list(cuts) + [len(self.buckets) - 1]:
+                hi = min(hi, len(self.buckets) - 1)
+                if hi >= lo:
+                    out.append((self.buckets[hi][1] - self.buckets[lo][0]) * es)
+                    lo = hi + 1
+            return out
+        return [self.flat.numel() * es]
+
     def wait_reductions(self):
         for w in self._works:
             w.wait()

@@ -71,6 +71,15 @@ def test_benched_update_replayed_equals_eager_and_reproduces(cuda):
     _same(ref, turn, "replayed in turn vs eager in turn")
 
 
+def test_benched_update_at_the_cfg4_per_gpu_batch(cuda):
+    """BASELINE.json configs[3] (cfg 4): 32 x 10 s clips per GPU (`bench.py --batch 32`).  The same equality at that size: 2 recorded + 2
+    replayed side-by-side updates == 4 eager in-turn updates, bit for bit (no graph-capture test existed at B = 32)."""
+    ref = _run(cuda, False, "in_turn", 4, batch=32)
+    got = _run(cuda, True, "side_by_side", 4, batch=32)
+    assert ref[3] == got[3] == 4 and torch.isfinite(got[0]).all()
+    _same(ref, got, "B = 32: replayed side by side vs eager in turn")
+
+
 def test_default_form_is_side_by_side(cuda):
     import inspect
     import bench

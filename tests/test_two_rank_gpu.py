@@ -44,6 +44,16 @@ def test_two_ranks_sharing_the_gpu_equal_the_one_rank_update(cuda, tmp_path):
         assert ranks[0]["digest"] == one["digest"], f"{exchange}: two ranks != one rank ({ranks[0]['pnorm']} vs {one['pnorm']})"
 
 
+def test_two_ranks_side_by_side_micro_batches_equal_the_one_rank_update(cuda, tmp_path):
+    """The DEFAULT form on several ranks (`bench.py --gpus N`): micro-batches side by side on two streams inside the replayed local
+    phase (two gradient buffers, summed before the exchange), one all-reduce of the whole buffer behind it, Adam eagerly.  Same data
+    on both ranks, so it must equal the one-rank in-turn update bit for bit."""
+    one = _launch(1, "phased", str(tmp_path / "one"), 0)[0]
+    ranks = _launch(2, "one_message", str(tmp_path / "sbs"), 29651, extra=["--micro", "side_by_side"])
+    assert all(r["split"] and not r["phased"] for r in ranks)
+    assert ranks[0]["digest"] == ranks[1]["digest"] == one["digest"], (ranks[0]["pnorm"], ranks[1]["pnorm"], one["pnorm"])
+
+
 def test_two_ranks_with_their_own_data_exchange_exactly_the_sum_of_their_gradients(cuda, tmp_path):
     """the same-data test above cannot see a reduction that mixes the ranks' buffers.  Here rank r holds its own
     data and seeds, lr = 0 (parameters fixed), and the gradient buffer the optimizer step receives in the 4th update of the two-rank

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--updates", type=int, default=4)
     ap.add_argument("--out", required=True)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--micro", default="in_turn")
     ap.add_argument("--own-data", action="store_true")
     ap.add_argument("--data-rank", type=int, default=None, help="one-rank reference run over rank R's data and seeds")
     a = ap.parse_args()
@@ -39,7 +40,7 @@ def main():
     from speecht5_amd import functional as Fn
     # small cfg-2-shaped update: Base, speech 2 x 4 s + text 4 x 128 (every rank: rank 0's data and seeds)
     drank = a.data_rank if a.data_rank is not None else (rank if a.own_data else 0)
-    _, _, model, upd = bench.make_update(dev, torch.bfloat16, "base", 2, drank, graph=not a.no_graph, micro="in_turn", layerdrop=0.05,
+    _, _, model, upd = bench.make_update(dev, torch.bfloat16, "base", 2, drank, graph=not a.no_graph, micro=a.micro, layerdrop=0.05,
                                          text_batch=4, text_len=128, seconds=4.0, exchange=a.exchange)
     info = {"rank": rank, "world": world, "phased": bool(upd.phased), "split": bool(upd.split), "data_rank": drank}
     grads = []
