@@ -330,6 +330,19 @@ int st5_stft_frames(const float* wav, float* out, int32_t B, int32_t S, int32_t 
 int st5_stft_magnitude(const float* reim, float* mag, int64_t rows, int32_t nbins, int32_t ldh, void* stream);
 int st5_log10_floor(const float* x, float* y, int64_t n, float floor_value, void* stream);
 
+/* ---- collation of the speech-pretraining batch on the device (data/speech_dataset.py:302-446 SpeechPretrainDataset.collater,
+ *      collater_audio, crop_to_max_size, collater_frm_label; fairseq collate_tokens): every tensor of the batch is a RAGGED GATHER of
+ *      the items' rows -- crop at a per-item start, thin out by a stride (the reduction factor), shift by one frame, pad to the
+ *      longest.  st5_ragged_rows: out[b, t, 0:w] = src[b][(off[b] + t * step) * w + (0:w)] when t >= tmin and
+ *      0 <= off[b] + t * step < hi[b], else the pad pattern; src = device array of B item base pointers, off / hi int32 [B], elements
+ *      of es = 1, 4 or 8 bytes (copied as bits: fp32 wave / mel rows, int64 labels), pad_bits = the pad element's bit pattern.
+ *      st5_tail_mask: out[b, t] = (t >= n[b]) ? 1 : 0 as uint8 (dtype_f32 = 0: padding_mask, :392-402) or fp32 (dtype_f32 = 1: the
+ *      stop-token labels, :347-349).  The crop starts are drawn on the host from numpy's stream exactly as the reference draws them
+ *      (one np.random.randint per item longer than the batch's audio size); speecht5_amd/collate.py drives both. */
+int st5_ragged_rows(const void* const* src, const int32_t* off, const int32_t* hi, void* out, int32_t B, int32_t T, int32_t w, int32_t step,
+                    int32_t tmin, int32_t es, uint64_t pad_bits, void* stream);
+int st5_tail_mask(const int32_t* n, void* out, int32_t B, int32_t T, int32_t dtype_f32, void* stream);
+
 /* ---- BatchNorm1d + tanh + dropout (+ residual) on channels-last rows: the non-GEMM part of the mel post-net
  *      (speech_decoder_postnet.py:39-51,65-70 = espnet Tacotron Postnet: 5 x [Conv1d k5 -> BatchNorm1d -> tanh -> dropout], the
  *      last block without tanh; after = before + postnet(before)).  x fp32 [rows, C] = the convolution GEMM's fp32 output

@@ -979,3 +979,54 @@ extern "C" int st5_log10_floor(const float* x, float* y, int64_t n, float floor_
 }
 
 extern "C" const char* st5_version(void) { return "speecht5_hip 0.1 (gfx950)"; }
+
+// ---- collation of the speech-pretraining batch (speech_dataset.py:302-446): ragged gather + tail masks -------------------------
+namespace {
+template <typename U>
+__global__ void ragged_rows_kernel(const void* const* __restrict__ src, const int32_t* __restrict__ off, const int32_t* __restrict__ hi,
+                                   U* __restrict__ out, int T, int w, int step, int tmin, U pad, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % w);
+    const long long row = i / w;
+    const int t = (int)(row % T), b = (int)(row / T);
+    const long long j = (long long)off[b] + (long long)t * step;
+    U v = pad;
+    if (t >= tmin && j >= 0 && j < (long long)hi[b]) v = reinterpret_cast<const U*>(src[b])[j * w + e];
+    out[i] = v;
+  }
+}
+__global__ void tail_mask_kernel(const int32_t* __restrict__ n, uint8_t* __restrict__ out8, float* __restrict__ outf, int T, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T), b = (int)(i / T);
+    const bool m = t >= n[b];
+    if (out8) out8[i] = m ? 1 : 0; else outf[i] = m ? 1.f : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int st5_ragged_rows(const void* const* src, const int32_t* off, const int32_t* hi, void* out, int32_t B, int32_t T, int32_t w,
+                               int32_t step, int32_t tmin, int32_t es, uint64_t pad_bits, void* stream) {
+  if (!src || !off || !hi || !out || B <= 0 || T < 0 || w <= 0 || step <= 0 || (es != 1 && es != 4 && es != 8)) return ST5_ERR_ARG;
+  const long long total = (long long)B * T * w;
+  if (total == 0) return ST5_OK;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65535) blocks = 65535;
+  hipStream_t s = (hipStream_t)stream;
+  if (es == 4) hipLaunchKernelGGL(ragged_rows_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s, src, off, hi, (uint32_t*)out, T, w, step, tmin, (uint32_t)pad_bits, total);
+  else if (es == 8) hipLaunchKernelGGL(ragged_rows_kernel<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, s, src, off, hi, (uint64_t*)out, T, w, step, tmin, (uint64_t)pad_bits, total);
+  else hipLaunchKernelGGL(ragged_rows_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s, src, off, hi, (uint8_t*)out, T, w, step, tmin, (uint8_t)pad_bits, total);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+extern "C" int st5_tail_mask(const int32_t* n, void* out, int32_t B, int32_t T, int32_t dtype_f32, void* stream) {
+  if (!n || !out || B <= 0 || T < 0) return ST5_ERR_ARG;
+  const long long total = (long long)B * T;
+  if (total == 0) return ST5_OK;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(tail_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, dtype_f32 ? nullptr : (uint8_t*)out,
+                     dtype_f32 ? (float*)out : nullptr, T, total);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}

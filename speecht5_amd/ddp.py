@@ -137,10 +137,8 @@ class FlatGradDataParallel:
             # eagerly; inside a replayed graph it brings nothing (48.05 vs 47.9 ms) and, worse, the graph executor then puts
             # the second micro-batch's forward stream (accumulate_overlapped) behind the whole weight-gradient branch
             # (measured: 48.3 ms with both, 45.0 ms with the forward overlap alone) -- bench.py turns it off for replay.
-            # Default OFF since round 3 (like the attention helper stream below and the side-by-side micro-batches of
-            # accumulate_overlapped): on this hardware / runtime, kernels of DIFFERENT streams sharing a CU were measured to
-            # perturb each other's results (tools/diag/diag_order3.py: a VALU kernel beside the register-staged
-            # or TN GEMM kernel computed one time step of 16 lanes wrong in most runs).  The switches stay for measurements.
+            # Default OFF: with the micro-batches side by side it costs time (42.0 against 31.5 ms per update,
+            # profiles/r5_replay_hunt.txt); results are bit-identical with and without it.
             if (os.environ.get("ST5_WGRAD_STREAM", "0") == "1") if wgrad_stream is None else wgrad_stream:
                 from .modules.transformer_layer import TransformerSentenceEncoderLayer, TransformerDecoderLayer
                 from .modules.speech_encoder_prenet import ConvFeatureExtractionModel

@@ -116,6 +116,8 @@ _SIGS = {
                                   c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32, c_void_p]),
     "st5_conv1d_cout1": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  c_float, c_int32, c_void_p]),
+    "st5_ragged_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint64, c_void_p]),
+    "st5_tail_mask": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "st5_stft_frames": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "st5_stft_magnitude": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "st5_log10_floor": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),

@@ -53,7 +53,7 @@ class PretrainUpdate:
         # is captured as three graphs cut at bucket boundaries (ddp.cut_points), and after each of them the bucket range it
         # completed goes to the process group as one asynchronous all-reduce (RCCL's stream) while the next graph runs
         # (exchange="one_message": one graph + one all-reduce of the whole buffer afterwards, the round-2 form)
-        # (ST5_EAGER_PHASED=1: the same three phases enqueued eagerly -- tools/diag/diag_phased.py, the tests' reference point)
+        # (ST5_EAGER_PHASED=1: the same three phases enqueued eagerly -- the tests' reference point)
         self.phased = ((self.split or (self.ddp.collectives and os.environ.get("ST5_EAGER_PHASED") == "1"))
                        and micro == "in_turn" and exchange == "phased" and len(self.micro) >= 1)
         if self.phased and not self.ddp.overlap_exchange:    # (decided once per group in FlatGradDataParallel, the same on every rank)
@@ -65,7 +65,7 @@ class PretrainUpdate:
         # to the NULL stream from two host threads (the forward from the caller's thread, the backward from autograd's worker
         # thread) is NOT kept in issue order once another stream is busy -- measured: with the speech micro-batch on the NULL
         # stream and the text micro-batch beside it, the reduction kernel of conv layer 0's backward read partials its
-        # predecessor in the same stream had not written yet (tools/diag/diag_nan2.py: NaN-poisoned partials came through in 4 of 4
+        # predecessor in the same stream had not written yet (round 3, docs/HISTORY.md 4a: NaN-poisoned partials came through in 4 of 4
         # updates; 0 of 4 on an explicit stream).
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
