@@ -155,7 +155,8 @@ def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, grap
     vocab = len(task.dicts["text"])
     speech = speech_pretrain_sample(B=batch, seconds=seconds, device=device, seed=1337 + rank)
     text = text_pretrain_sample(B=text_batch, T=text_len, vocab=vocab, mask_idx=task.dicts["text"].index("<mask>"), device=device, seed=2337 + rank)
-    upd = PretrainUpdate(task, model, crit, [speech, text], lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0,
+    batches = [text, speech] if os.environ.get("ST5_TEXT_FIRST") == "1" else [speech, text]    # (A/B: which micro-batch owns the first stream)
+    upd = PretrainUpdate(task, model, crit, batches, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0,
                          graph=graph, micro=micro, wgrad_stream=wgrad_stream, prefetch_host=prefetch_host, device=device, exchange=exchange)
     return args, task, model, upd
 
@@ -292,6 +293,8 @@ def main():
         hip.lib().st5_gemm_set_deep_ring(*[int(v) for v in os.environ["ST5_DEEP_RING"].split(",")])
     if os.environ.get("ST5_SPLITK_TARGET"):   # A/B: block count the weight-gradient split-K aims for
         hip.lib().st5_gemm_set_splitk_target(int(os.environ["ST5_SPLITK_TARGET"]))
+    if os.environ.get("ST5_CONV0_MFMA"):  # A/B: 0 = VALU form of conv layer 0's forward apply pass (default 1: matrix cores)
+        hip.lib().st5_conv0_set_mfma(int(os.environ["ST5_CONV0_MFMA"]))
     if os.environ.get("ST5_TN_PHASED"):   # A/B: 1 / 2 = weight-gradient GEMMs on the phased 256x256 kernel (default 0 = the 128x128 kernel)
         hip.lib().st5_gemm_set_tn_phased(int(os.environ["ST5_TN_PHASED"]))
     if os.environ.get("ST5_NT_SLOTS"):   # A/B: 4 = two-stage operand ring of the 128x128 NT kernel (default 5 = five operand slots)

@@ -122,6 +122,49 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return x * cdf;
 }
 
+// GELU VALUE for the bf16 compute mode without transcendentals (round 5).  v_rcp_f32 / v_exp_f32 issue at a quarter of the VALU rate, so
+// the two of gelu_fast<false> cost as much as its ten other instructions together -- and the epilogues that call it (conv layer 0's
+// apply pass, the GEMM epilogue of fc1) are VALU-issue-bound.  Phi(x) = 0.5 + xc G(xc^2), xc = x clamped to +-3 sqrt 2, G a degree-9
+// polynomial (Chebyshev fit of erf(sqrt u) / sqrt u on [0, 9] with the 1/sqrt 2 and 1/2 scalings folded into the coefficients, fp32
+// Horner): |Phi error| <= 1.5e-5 incl. the clamp (1 - erf 3 = 2.2e-5), |gelu error| <= 2.4e-5 for |x| <= 4 and <= 1.5e-5 |x| beyond --
+// two orders below the bf16 rounding of the value it feeds (tests/test_isa_audit.py::test_gelu_poly_error_bound).  13 full-rate
+// instructions against 13 + 2 quarter-rate ones (= 21 issue slots): fc1's epilogue 87.4 -> 73.1 us at 8192 x 3072 x 768.
+// The DERIVATIVE has its own polynomial (gelu_grad_poly below).
+__device__ __forceinline__ float gelu_poly(float x) {
+  const float xc = fminf(fmaxf(x, -4.242640495300293f), 4.242640495300293f);
+  const float v = xc * xc;
+  float g = fmaf(v, -3.086644655e-12f, 3.179429497e-10f);
+  g = fmaf(g, v, -1.470189481e-08f);
+  g = fmaf(g, v, 4.085038654e-07f);
+  g = fmaf(g, v, -7.744979484e-06f);
+  g = fmaf(g, v, 1.082136150e-04f);
+  g = fmaf(g, v, -1.169087715e-03f);
+  g = fmaf(g, v, 9.949624538e-03f);
+  g = fmaf(g, v, -6.647801399e-02f);
+  g = fmaf(g, v, 3.989412189e-01f);
+  return x * fmaf(xc, g, 0.5f);
+}
+
+// GELU DERIVATIVE for the bf16 compute mode without transcendentals: gelu'(x) = Phi(x) + x phi(x) = 0.5 + xc H(xc^2), xc = x clamped to
+// +-4.35, H a degree-10 polynomial (Chebyshev fit of (Phi(sqrt u) - 0.5) / sqrt u + phi(sqrt u) on [0, 4.35^2], fp32 Horner):
+// |error| <= 1.2e-4 of a value in [-0.13, 1.13] -- the factor multiplies a bf16 dY (relative rounding 2e-3), so it is 16x below the
+// operand's own rounding.  13 full-rate instructions against 15 + 2 quarter-rate ones of gelu_fast<true> (= 23 issue slots).
+__device__ __forceinline__ float gelu_grad_poly(float x) {
+  const float xc = fminf(fmaxf(x, -4.349999904632568f), 4.349999904632568f);
+  const float v = xc * xc;
+  float h = fmaf(v, 1.668488481e-12f, -1.931875215e-10f);
+  h = fmaf(h, v, 1.003747396e-08f);
+  h = fmaf(h, v, -3.115285097e-07f);
+  h = fmaf(h, v, 6.503215900e-06f);
+  h = fmaf(h, v, -9.763300477e-05f);
+  h = fmaf(h, v, 1.097474480e-03f);
+  h = fmaf(h, v, -9.375064634e-03f);
+  h = fmaf(h, v, 5.970102549e-02f);
+  h = fmaf(h, v, -2.658985257e-01f);
+  h = fmaf(h, v, 7.978798151e-01f);
+  return fmaf(xc, h, 0.5f);
+}
+
 #define ACT_NONE 0
 #define ACT_GELU 1
 #define ACT_RELU 2
@@ -132,7 +175,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 template <bool FAST = false>
 __device__ __forceinline__ float act_f(int act, float x) {
   switch (act) {
-    case ACT_GELU: return FAST ? gelu_fast<false>(x) : gelu_f(x);
+    case ACT_GELU: return FAST ? gelu_poly(x) : gelu_f(x);
     case ACT_RELU: return x > 0.f ? x : 0.f;
     case ACT_TANH: return tanhf(x);
     case ACT_LRELU_01: return x > 0.f ? x : 0.1f * x;
@@ -144,7 +187,7 @@ __device__ __forceinline__ float act_f(int act, float x) {
 template <bool FAST = false>
 __device__ __forceinline__ float act_grad_f(int act, float x) {
   switch (act) {
-    case ACT_GELU: return FAST ? gelu_fast<true>(x) : gelu_grad_f(x);
+    case ACT_GELU: return FAST ? gelu_grad_poly(x) : gelu_grad_f(x);
     case ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case ACT_TANH: { float t = tanhf(x); return 1.f - t * t; }
     case ACT_LRELU_01: return x > 0.f ? 1.f : 0.1f;

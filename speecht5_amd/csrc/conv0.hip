@@ -61,71 +61,93 @@ __device__ __forceinline__ void stage_wav(float* seg, const float* __restrict__ 
     seg[i] = i < nseg ? wav[(long long)b * S + (long long)t0 * stride + i] : 0.f;
 }
 
-// ---- waveform moments: part[b][chunk][nmom] (one time step per thread, wave shuffle + LDS reduction) ----
+// ---- waveform moments and GroupNorm statistics in TWO launches (round 5; three launches of 22 + 14 + 8 us before, for 5 MB of input) --
+// conv0_moments2_kernel: a block owns TCM = 2048 time steps, a thread 8 of them -- the 65 moment products are accumulated in registers
+// over the thread's steps and reduced ONCE per block (the first form reduced 65 values per 256 steps).  part2[b][chunk][nmom].
+// conv0_stats2_kernel: every block of (64 channels, clip) first folds the clip's chunk partials in fp64 (fixed order), block 0 of a
+// clip also publishes them (the backward's final kernel reads them), then 64 threads evaluate mean / rstd of their channels.
+constexpr int TCM = 2048;
 template <int KW>
-__global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ wav, float* __restrict__ part, int S,
-                                                            int L, int k, int stride, int nch) {
-  extern __shared__ float seg[];
-  // one slot per wave and moment, summed in a fixed order below: LDS atomics here would make the GroupNorm statistics --
-  // and through bf16 rounding every activation after them -- depend on wave arrival order (run-to-run differences)
+__global__ __launch_bounds__(256) void conv0_moments2_kernel(const float* __restrict__ wav, float* __restrict__ part, int S, int L, int k,
+                                                             int stride, int nchm) {
   __shared__ float red[4][MAXMOM];
-  const int b = blockIdx.y, ch = blockIdx.x, t0 = ch * TCH;
-  const int nt = min(TCH, L - t0);
-  stage_wav(seg, wav, b, S, t0, nt, k, stride);
-  const int nm = nmom(k);
-  __syncthreads();
-  const int t = threadIdx.x;
-  const int wv = threadIdx.x >> 6;
-  float x[KW];
+  extern __shared__ __attribute__((aligned(16))) float segm[];      // the block's samples: (TCM - 1) stride + k floats (+ alignment slack)
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int t0 = ch * TCM, nt = min(TCM, L - t0);
+  {
+    // coalesced 16-byte loads from the 16-byte-aligned address at or below the block's first sample
+    const long long g0 = (long long)b * S + (long long)t0 * stride;
+    const long long ga = g0 & ~3ll;
+    const int shift = (int)(g0 - ga), nneed = shift + (nt - 1) * stride + k;
+    const long long gend = (long long)(b + 1) * S;          // (never read past the clip: the next clip / the buffer's end)
+    const float4* src = reinterpret_cast<const float4*>(wav + ga);
+    for (int i = threadIdx.x; i * 4 < nneed; i += 256) {
+      float4 v;
+      if (ga + 4ll * i + 3 < gend && ((reinterpret_cast<uintptr_t>(wav) & 15) == 0)) v = src[i];
+      else {
+        const long long p = ga + 4ll * i;
+        v.x = p < gend ? wav[p] : 0.f; v.y = p + 1 < gend ? wav[p + 1] : 0.f; v.z = p + 2 < gend ? wav[p + 2] : 0.f; v.w = p + 3 < gend ? wav[p + 3] : 0.f;
+      }
+      reinterpret_cast<float4*>(segm)[i] = v;
+    }
+    __syncthreads();
+  }
+  const float* wb = segm + (int)(((long long)b * S + (long long)t0 * stride) & 3ll);
+  float m1[KW], m2[KW * (KW + 1) / 2];
 #pragma unroll
-  for (int j = 0; j < KW; ++j) x[j] = (t < nt && j < k) ? seg[t * stride + j] : 0.f;
-  const int lane = threadIdx.x & 63;
+  for (int j = 0; j < KW; ++j) m1[j] = 0.f;
 #pragma unroll
-  for (int j = 0; j < KW; ++j) {
-    if (j < k) {
-      const float s = wave_sum(x[j]);
-      if (lane == 0) red[wv][j] = s;
+  for (int j = 0; j < KW * (KW + 1) / 2; ++j) m2[j] = 0.f;
+  for (int t = threadIdx.x; t < nt; t += 256) {
+    float x[KW];
+#pragma unroll
+    for (int j = 0; j < KW; ++j) x[j] = j < k ? wb[t * stride + j] : 0.f;
+    int q = 0;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+      m1[j] += x[j];
+#pragma unroll
+      for (int jp = j; jp < KW; ++jp) { m2[q] = fmaf(x[j], x[jp], m2[q]); ++q; }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    int q = 0;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+      const float s = wave_sum(m1[j]);
+      if (lane == 0 && j < k) red[wv][j] = s;
 #pragma unroll
       for (int jp = j; jp < KW; ++jp) {
-        if (jp < k) {
-          const float r = wave_sum(x[j] * x[jp]);
-          if (lane == 0) red[wv][ridx(k, j, jp)] = r;
-        }
+        const float r = wave_sum(m2[q]); ++q;
+        if (lane == 0 && jp < k) red[wv][ridx(k, j, jp)] = r;
       }
     }
   }
   __syncthreads();
+  const int nm = nmom(k);
   for (int i = threadIdx.x; i < nm; i += 256)
-    part[((long long)b * nch + ch) * nm + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    part[((long long)b * nchm + ch) * nm + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
-// mom[b][nmom] (double) = sum over chunks
-__global__ __launch_bounds__(256) void conv0_moments_final_kernel(const float* __restrict__ part, double* __restrict__ mom,
-                                                                  int nm, int nch) {
-  __shared__ double red[4][MAXMOM];
-  const int b = blockIdx.x;
-  const int i = threadIdx.x & 63, j = threadIdx.x >> 6;   // nm <= 152: three passes of 64
-  for (int base = 0; base < nm; base += 64) {
-    const int m = base + i;
+__global__ __launch_bounds__(256) void conv0_stats2_kernel(const float* __restrict__ part, double* __restrict__ mom, const float* __restrict__ w,
+                                                           float* __restrict__ stats, int C, int k, int L, int nchm, float eps) {
+  __shared__ double ms[MAXMOM];
+  const int b = blockIdx.y, nm = nmom(k);
+  for (int m = threadIdx.x; m < nm; m += 256) {
     double s = 0.0;
-    if (m < nm)
-      for (int ch = j; ch < nch; ch += 4) s += (double)part[((long long)b * nch + ch) * nm + m];
-    if (m < nm) red[j][m] = s;
+    for (int ch = 0; ch < nchm; ++ch) s += (double)part[((long long)b * nchm + ch) * nm + m];
+    ms[m] = s;
+    if (blockIdx.x == 0) mom[(long long)b * nm + m] = s;
   }
   __syncthreads();
-  for (int m = threadIdx.x; m < nm; m += 256) mom[(long long)b * nm + m] = red[0][m] + red[1][m] + red[2][m] + red[3][m];
-}
-// (mean, rstd) per (b, c) from the moments:  mean = w.M / L,  E[y^2] = w^T R w / L
-__global__ __launch_bounds__(256) void conv0_stats_from_moments_kernel(const double* __restrict__ mom, const float* __restrict__ w,
-                                                                       float* __restrict__ stats, int C, int k, int L, float eps) {
-  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double* mb = mom + (long long)b * nmom(k);
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (!stats || threadIdx.x >= 64 || c >= C) return;
   double s1 = 0.0, s2 = 0.0;
   for (int j = 0; j < k; ++j) {
     const double wj = (double)w[c * k + j];
-    s1 += wj * mb[j];
+    s1 += wj * ms[j];
     for (int jp = j; jp < k; ++jp) {
-      const double t = wj * (double)w[c * k + jp] * mb[ridx(k, j, jp)];
+      const double t = wj * (double)w[c * k + jp] * ms[ridx(k, j, jp)];
       s2 += (jp == j) ? t : 2.0 * t;
     }
   }
@@ -161,16 +183,116 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
   load_w8<KW>(w, c0, k, wr);
   __syncthreads();
   if (tli >= g.tl) return;
-  constexpr bool FAST = sizeof(T) == 2;   // bf16 output: fast erf (|error| 1.5e-7), fp32 parity mode: libm erff
+  constexpr bool FAST = sizeof(T) == 2;   // bf16 output: transcendental-free GELU (common.h gelu_poly), fp32 parity mode: libm erff
   for (int t = tli; t < nt; t += g.tl) {
     float y[8];
     conv8<KW>(seg + t * stride, wr, y);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float z = fmaf(y[e], sc[e], sh[e]);
-      y[e] = FAST ? gelu_fast<false>(z) : gelu_f(z);
+      y[e] = FAST ? gelu_poly(z) : gelu_f(z);
     }
     store8f<T>(out + ((long long)b * L + t0 + t) * C + c0, y);
+  }
+}
+
+// ---- forward apply on the matrix cores (bf16 output, k <= 10, C % 32 == 0) --------------------------------------------------------
+// The VALU form above spends ~24 issue slots per output element (10 FMAs of the convolution, the affine, ~21 of the erf-GELU (its rcp and exp issue at quarter rate), the
+// pack): 131 M outputs per 8-clip batch = 100+ us of pure VALU issue on 256 CUs, against 33 us to WRITE the 262 MB at 8 TB/s -- it is
+// VALU-bound (measured 110 us = 2.4 TB/s).  Here the convolution is a GEMM on v_mfma_f32_32x32x16_bf16 with SPLIT operands:
+//   x = xh + xl, w = wh + wl (bf16 each, xl / wl the rounding residues)      y ~= wh.xh + wh.xl + wl.xh     (wl.xl ~ 2^-16 |w||x|: dropped)
+// laid out along K as [wh | wh | wl] . [xh ; xl ; xh] -- 30 of the 32 k-slots of TWO MFMAs per 32 channels x 32 time steps, the fp32
+// accumulator carrying ~16 mantissa bits of every product pair (the recipe's own fp16 autocast keeps 11).  The channel <-> MFMA row
+// mapping is PERMUTED (c0_perm) so that a lane's 16 accumulator registers are 16 CONSECUTIVE channels of one time step: the
+// channels-last store is two 16-byte stores per lane, no LDS transpose.  What is left per output element is the affine, the transcendental-free GELU
+// (common.h gelu_poly) and the pack: ~18 issue slots = 60 us of VALU issue.  The weight fragments are built once per call (conv0_wfrag_kernel, 32 KB for 512 channels) and sit in LDS.
+__device__ __forceinline__ int c0_perm(int m) { return 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3); }
+
+__global__ __launch_bounds__(128) void conv0_wfrag_kernel(const float* __restrict__ w, bf16x8* __restrict__ afrag, int k) {
+  const int mt = blockIdx.x, q = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int c = 32 * mt + c0_perm(l & 31), hi = l >> 5;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int kk = 16 * q + 8 * hi + e, sec = kk / 10, j = kk - 10 * sec;
+    const float wv = (kk < 30 && j < k) ? w[c * k + j] : 0.f;
+    const bf16_t wh = (bf16_t)wv;
+    o[e] = sec < 2 ? wh : (bf16_t)(wv - (float)wh);
+  }
+  afrag[(mt * 2 + q) * 64 + l] = o;
+}
+
+__global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __restrict__ wav, const bf16x8* __restrict__ afrag_g,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ stats, bf16_t* __restrict__ out, int S, int L,
+                                                               int C, int k, int stride) {
+  extern __shared__ __attribute__((aligned(16))) char sm0[];
+  const int ntile = C / 32;
+  bf16x8* afr = reinterpret_cast<bf16x8*>(sm0);                       // [ntile][2][64 lanes] x 16 B
+  float* scs = reinterpret_cast<float*>(sm0 + (size_t)ntile * 2048);  // scale[C] | shift[C]
+  float* seg = scs + 2 * C;
+  const int b = blockIdx.y, t0 = blockIdx.x * TCH;
+  const int nt = min(TCH, L - t0);
+  stage_wav(seg, wav, b, S, t0, nt, k, stride);
+  for (int i = threadIdx.x; i < ntile * 128; i += 256) afr[i] = afrag_g[i];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mu = stats[((long long)b * C + c) * 2], rs = stats[((long long)b * C + c) * 2 + 1];
+    const float sc = rs * gamma[c];
+    scs[c] = sc;
+    scs[C + c] = beta[c] - mu * sc;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hi = lane >> 5;
+#pragma unroll 1
+  for (int ntl = 0; ntl < 2; ++ntl) {
+    const int tl = wave * 64 + ntl * 32 + n;
+    const bool tv = tl < nt;
+    const float* sp = seg + (tv ? tl : 0) * stride;
+    bf16_t xh[10], xl[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const float xv = sp[j];            // (taps >= k read the zero tail of the staged segment or the next steps' samples: w is 0 there)
+      xh[j] = (bf16_t)xv;
+      xl[j] = (bf16_t)(xv - (float)xh[j]);
+    }
+    const bf16_t z0 = (bf16_t)0.f;
+    bf16x8 b1, b2;
+    if (hi == 0) {
+      b1 = bf16x8{xh[0], xh[1], xh[2], xh[3], xh[4], xh[5], xh[6], xh[7]};
+      b2 = bf16x8{xl[6], xl[7], xl[8], xl[9], xh[0], xh[1], xh[2], xh[3]};
+    } else {
+      b1 = bf16x8{xh[8], xh[9], xl[0], xl[1], xl[2], xl[3], xl[4], xl[5]};
+      b2 = bf16x8{xh[4], xh[5], xh[6], xh[7], xh[8], xh[9], z0, z0};
+    }
+    bf16_t* orow = out + ((long long)b * L + t0 + (tv ? tl : 0)) * C + 16 * hi;
+#pragma unroll 2
+    for (int mt = 0; mt < ntile; ++mt) {
+      const bf16x8 a1 = afr[(mt * 2 + 0) * 64 + lane], a2 = afr[(mt * 2 + 1) * 64 + lane];
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
+      const float* scp = scs + mt * 32 + 16 * hi;
+      float y[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 sc4 = *reinterpret_cast<const float4*>(scp + 4 * g);
+        const float4 sh4 = *reinterpret_cast<const float4*>(scp + C + 4 * g);
+        y[4 * g + 0] = gelu_poly(fmaf(acc[4 * g + 0], sc4.x, sh4.x));
+        y[4 * g + 1] = gelu_poly(fmaf(acc[4 * g + 1], sc4.y, sh4.y));
+        y[4 * g + 2] = gelu_poly(fmaf(acc[4 * g + 2], sc4.z, sh4.z));
+        y[4 * g + 3] = gelu_poly(fmaf(acc[4 * g + 3], sc4.w, sh4.w));
+      }
+      if (tv) {
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o0[e] = (bf16_t)y[e]; o1[e] = (bf16_t)y[8 + e]; }
+        *reinterpret_cast<bf16x8*>(orow + mt * 32) = o0;
+        *reinterpret_cast<bf16x8*>(orow + mt * 32 + 8) = o1;
+      }
+    }
   }
 }
 
@@ -223,8 +345,8 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
       for (int j = 0; j < KW; ++j) { y0 = fmaf(wr[0][j], xv[j], y0); y1 = fmaf(wr[1][j], xv[j], y1); }
       const float xh0 = (y0 - mu[0]) * rs[0], xh1 = (y1 - mu[1]) * rs[1];
       const float z0 = fmaf(xh0, ga[0], be[0]), z1 = fmaf(xh1, ga[1], be[1]);
-      const float dz0 = d0 * (FAST ? gelu_fast<true>(z0) : gelu_grad_f(z0));
-      const float dz1 = d1 * (FAST ? gelu_fast<true>(z1) : gelu_grad_f(z1));
+      const float dz0 = d0 * (FAST ? gelu_grad_poly(z0) : gelu_grad_f(z0));
+      const float dz1 = d1 * (FAST ? gelu_grad_poly(z1) : gelu_grad_f(z1));
       s1[0] += dz0; s1[1] += dz1;
       s2[0] = fmaf(dz0, xh0, s2[0]); s2[1] = fmaf(dz1, xh1, s2[1]);
 #pragma unroll
@@ -241,6 +363,188 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
     }
   }
 }
+// ---- backward on the matrix cores (bf16 dY, k <= 10, C % 128 == 0) ---------------------------------------------------------------
+// The VALU form above spends ~40 issue slots per element of dY (10 FMAs to recompute the convolution, 10 more for A_j += dz x[s t + j],
+// ~20 for gelu', the rest) in dependent chains: 246 us for 262 MB.  Here both contractions run on v_mfma_f32_32x32x16_bf16:
+//   1. y[c][t]   = [wh | wh | wl] . [xh ; xl ; xh]                 (the forward's fragments; lane = time step, 16 consecutive channels)
+//   2. dz = dY gelu'(y rs gamma + (beta - mu rs gamma))            (the only per-element VALU work left)
+//   3. G[c][j]  += dz[c][t] X[t][j],  X[t][j] = x[s t + j] (j < k), X[t][10] = 1     -> A_j (j < 10) and S1 (column 10) in ONE product,
+//      dz as ONE bf16 operand (what every weight-gradient GEMM of the bf16 mode feeds the matrix cores: bf16 dY), X split (Xh + Xl: the
+//      waveform keeps ~16 bits); two MFMAs per 16 time steps.  dz comes out of step 1's accumulator
+//      layout with the TIME index across lanes, but step 3 contracts over time: the tile goes through a wave-private LDS tile
+//      [t][c] and comes back as the A operand through the gfx950 transpose read (ds_read_b64_tr_b16), whose k order
+//      (rows 4hi..4hi+3, 8+4hi..8+4hi+3 of a 16-step) the X fragments are built to match.
+//   S2 = sum_t dz x_hat is NOT accumulated: x_hat = rs (w.x - mu) gives S2 = rs (sum_j w_j A_j - mu S1) exactly; the final kernel
+//   derives it from the chunk-summed A and S1 in fp64 (s2_from_a).
+// A wave owns a quarter of the channels (tiles w, w+4, ...: 64 accumulator registers) and walks the block's 8 time tiles.
+typedef __attribute__((ext_vector_type(4))) short c0_s16x4;
+typedef __attribute__((address_space(3))) c0_s16x4* c0_lds_s16x4_ptr;
+constexpr int C0_TP = 80;                 // pitch (bytes) of a [32 t][32 c] bf16 transpose tile row: 64 + 16 of padding
+constexpr int C0_TILE_B = 32 * C0_TP;     // 2560 bytes
+
+__device__ __forceinline__ bf16x8 c0_tr_frag(const char* tile, int off_lo, int off_hi) {
+  const c0_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c0_lds_s16x4_ptr)(tile + off_lo));
+  const c0_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c0_lds_s16x4_ptr)(tile + off_hi));
+  union { struct { c0_s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(256) void conv0_bwd_mfma_kernel(const float* __restrict__ wav, const bf16x8* __restrict__ afrag_g,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ stats, const bf16_t* __restrict__ dY,
+                                                             float* __restrict__ part, int S, int L, int C, int k, int stride, int nch) {
+  extern __shared__ __attribute__((aligned(16))) char sm0[];
+  const int ntile = C / 32, tpw = ntile / 4;                          // channel tiles in all / per wave
+  bf16x8* afr = reinterpret_cast<bf16x8*>(sm0);                       // [ntile][2][64 lanes] x 16 B
+  float* zsb = reinterpret_cast<float*>(sm0 + (size_t)ntile * 2048);  // z scale[C] | z shift[C]
+  float* seg = zsb + 2 * C;
+  const int b = blockIdx.y, ch = blockIdx.x, t0 = ch * TCH;
+  const int nt = min(TCH, L - t0);
+  const int nseg_pad = (TCH - 1) * stride + k + MAXK;
+  char* trbase = reinterpret_cast<char*>(seg + ((nseg_pad + 3) & ~3));  // one [32 t][32 c] tile per wave
+  stage_wav(seg, wav, b, S, t0, nt, k, stride);
+  for (int i = threadIdx.x; i < ntile * 128; i += 256) afr[i] = afrag_g[i];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mu = stats[((long long)b * C + c) * 2], rs = stats[((long long)b * C + c) * 2 + 1];
+    const float sc = rs * gamma[c];
+    zsb[c] = sc;
+    zsb[C + c] = beta[c] - mu * sc;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hi = lane >> 5;
+  char* trh = trbase + wave * C0_TILE_B;
+  // transpose-read offsets (see c0_tr_frag): lane l of a 16-lane group reads row rbase + ((l & 15) >> 2), columns 16 ((l >> 4) & 1) +
+  // 4 (l & 3) .. +3 and receives column l & 31, rows rbase .. rbase + 3;  rbase = 16 s + 8 half + 4 hi
+  const int tr_lane = ((lane & 15) >> 2) * C0_TP + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  f32x16 G[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[q][r] = 0.f;
+  const bf16_t z0 = (bf16_t)0.f;
+#pragma unroll 1
+  for (int tt = 0; tt < TCH / 32; ++tt) {
+    if (tt * 32 >= nt) break;
+    // ---- fragments of this time tile -------------------------------------------------------------------------------------------
+    const int tl = tt * 32 + n;                      // (step 1: lane = time step)
+    const bool tv = tl < nt;
+    bf16x8 b1, b2;
+    {
+      const float* sp = seg + (tv ? tl : 0) * stride;
+      bf16_t xh[10], xl[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const float xv = sp[j];
+        xh[j] = (bf16_t)xv;
+        xl[j] = (bf16_t)(xv - (float)xh[j]);
+      }
+      if (hi == 0) {
+        b1 = bf16x8{xh[0], xh[1], xh[2], xh[3], xh[4], xh[5], xh[6], xh[7]};
+        b2 = bf16x8{xl[6], xl[7], xl[8], xl[9], xh[0], xh[1], xh[2], xh[3]};
+      } else {
+        b1 = bf16x8{xh[8], xh[9], xl[0], xl[1], xl[2], xl[3], xl[4], xl[5]};
+        b2 = bf16x8{xh[4], xh[5], xh[6], xh[7], xh[8], xh[9], z0, z0};
+      }
+    }
+    bf16x8 Xh[2], Xl[2];                             // (step 3: lane = column j of X, k slots = time steps in the transpose read's order)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int tq = tt * 32 + 16 * s2 + 8 * (e >> 2) + 4 * hi + (e & 3);
+        float xv = 0.f;
+        if (n < k && tq < nt) xv = seg[tq * stride + n];
+        if (n == 10) xv = 1.f;
+        const bf16_t h = (bf16_t)xv;
+        Xh[s2][e] = h;
+        Xl[s2][e] = (bf16_t)(xv - (float)h);
+      }
+    }
+    const bf16_t* dyrow = dY + ((long long)b * L + t0 + (tv ? tl : 0)) * C + 16 * hi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q >= tpw) break;
+      const int mt = wave + 4 * q;
+      // dY of this (time step, 16 channels): 32 contiguous bytes
+      uint4 dv0 = *reinterpret_cast<const uint4*>(dyrow + mt * 32);
+      uint4 dv1 = *reinterpret_cast<const uint4*>(dyrow + mt * 32 + 8);
+      if (!tv) { dv0 = make_uint4(0u, 0u, 0u, 0u); dv1 = dv0; }      // (a time step past the clip's end contributes dz = 0)
+      const bf16x8 a1 = afr[(mt * 2 + 0) * 64 + lane], a2 = afr[(mt * 2 + 1) * 64 + lane];
+      f32x16 y;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[r] = 0.f;
+      y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, y, 0, 0, 0);
+      y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, y, 0, 0, 0);
+      const float* zp = zsb + mt * 32 + 16 * hi;
+      const unsigned int dw_[8] = {dv0.x, dv0.y, dv0.z, dv0.w, dv1.x, dv1.y, dv1.z, dv1.w};
+      bf16x8 dh0, dh1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 sc4 = *reinterpret_cast<const float4*>(zp + 4 * g);
+        const float4 sh4 = *reinterpret_cast<const float4*>(zp + C + 4 * g);
+        const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const unsigned int pk = dw_[r >> 1];
+          const float dyv = __uint_as_float((r & 1) ? (pk & 0xffff0000u) : (pk << 16));
+          const bf16_t h = (bf16_t)(dyv * gelu_grad_poly(fmaf(y[r], scv[e], shv[e])));
+          if (r < 8) dh0[r] = h; else dh1[r - 8] = h;
+        }
+      }
+      // wave-private transpose: rows = this lane's time step, 32 bytes of its 16 channels
+      *reinterpret_cast<bf16x8*>(trh + n * C0_TP + 32 * hi) = dh0;
+      *reinterpret_cast<bf16x8*>(trh + n * C0_TP + 32 * hi + 16) = dh1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (same wave wrote and reads: the writes have executed)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int o0 = (16 * s2 + 4 * hi) * C0_TP + tr_lane, o1 = (16 * s2 + 8 + 4 * hi) * C0_TP + tr_lane;
+        const bf16x8 ah = c0_tr_frag(trh, o0, o1);
+        G[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, Xh[s2], G[q], 0, 0, 0);
+        G[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, Xl[s2], G[q], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the tile is rewritten by the next channel tile)
+    }
+  }
+  // G[q][r] of lane (n = column j, hi) = row (r & 3) + 8 (r >> 2) + 4 hi of channel tile wave + 4 q: A_j for j < k, S1 in column 10
+  if (n <= 10 && (n < k || n == 10)) {
+    const int KV = 12;      // (part rows are KW + 2 = 12 floats: A_0..A_9, S1, S2 -- S2 is derived by the final kernel)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q >= tpw) break;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (wave + 4 * q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        part[(((long long)b * nch + ch) * C + c) * KV + n] = G[q][r];
+      }
+    }
+  }
+  if (k < 10 && n >= k && n < 10) {      // unused tap slots of a narrower kernel: defined zeros for the reduce kernel
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q >= tpw) break;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (wave + 4 * q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        part[(((long long)b * nch + ch) * C + c) * 12 + n] = 0.f;
+      }
+    }
+  }
+  if (n == 11) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q >= tpw) break;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (wave + 4 * q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        part[(((long long)b * nch + ch) * C + c) * 12 + 11] = 0.f;
+      }
+    }
+  }
+}
+
 // sums[b][c][KW + 2] (double) = sum over chunks of part.  Block = 32 (c, i) entries x 8 chunk lanes.
 __global__ __launch_bounds__(256) void conv0_bwd_reduce_kernel(const float* __restrict__ part, double* __restrict__ sums, int C,
                                                                int nch, int nv) {
@@ -262,30 +566,46 @@ __global__ __launch_bounds__(256) void conv0_bwd_reduce_kernel(const float* __re
 }
 // dw[c][j] += gscale sum_b rstd gamma [A_j - S1 M_j / L - S2 rstd ((R w)_j - mean M_j) / L];
 // dgamma[c] += gscale sum_b S2;  dbeta[c] += gscale sum_b S1
-// One thread per (channel, tap) -- 16 tap lanes per channel, lane k..15 idle, lane 0 also owns dgamma / dbeta.  (One thread
-// per channel walked B x k x k fp64 terms alone: 124 us for 8 waves of dependent double arithmetic.)
+// One thread per (channel, tap, clip lane): 2 channels x 16 tap lanes x 8 clip lanes per block (tap lanes k..15 idle; tap lane 0 also
+// owns dgamma / dbeta); the clip lanes' terms are added by an xor butterfly in a fixed order.  (First form: one thread per channel
+// walked B x k x k fp64 terms alone, 124 us; second: one thread per (channel, tap) on C / 16 = 32 blocks, 42 us of dependent fp64
+// chains on an eighth of the chip.)
 __global__ __launch_bounds__(256) void conv0_bwd_final_kernel(const double* __restrict__ sums, const double* __restrict__ mom,
                                                              const float* __restrict__ w, const float* __restrict__ gamma,
                                                              const float* __restrict__ stats, float* __restrict__ dw,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C,
-                                                             int k, int L, int nv, float gscale) {
-  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15;
-  if (c >= C || j >= k) return;
+                                                             int k, int L, int nv, float gscale, int s2_from_a) {
+  const int bl = threadIdx.x & 7, j = (threadIdx.x >> 3) & 15, c = blockIdx.x * 2 + (threadIdx.x >> 7);
   double g1 = 0.0, g2 = 0.0, acc = 0.0;
-  const double ga = (double)gamma[c], invL = 1.0 / (double)L;
-  for (int b = 0; b < B; ++b) {
-    const double* sb = sums + ((long long)b * C + c) * nv;
-    const double* mb = mom + (long long)b * nmom(k);
-    const double mu = (double)stats[((long long)b * C + c) * 2], rs = (double)stats[((long long)b * C + c) * 2 + 1];
-    const double S1 = sb[nv - 2], S2 = sb[nv - 1];
-    g1 += S1; g2 += S2;
-    double rw = 0.0;   // (R w)_j
-    for (int jp = 0; jp < k; ++jp) {
-      const int a = j < jp ? j : jp, bq = j < jp ? jp : j;
-      rw += (double)w[c * k + jp] * mb[ridx(k, a, bq)];
+  if (c < C && j < k) {
+    const double ga = (double)gamma[c], invL = 1.0 / (double)L;
+    for (int b = bl; b < B; b += 8) {
+      const double* sb = sums + ((long long)b * C + c) * nv;
+      const double* mb = mom + (long long)b * nmom(k);
+      const double mu = (double)stats[((long long)b * C + c) * 2], rs = (double)stats[((long long)b * C + c) * 2 + 1];
+      const double S1 = sb[nv - 2];
+      double S2 = sb[nv - 1];
+      if (s2_from_a) {     // (matrix-core backward: S2 = sum_t dz x_hat = rs (sum_j w_j A_j - mu S1), x_hat = rs (w.x - mu))
+        double wa = 0.0;
+        for (int jp = 0; jp < k; ++jp) wa += (double)w[c * k + jp] * sb[jp];
+        S2 = rs * (wa - mu * S1);
+      }
+      g1 += S1; g2 += S2;
+      double rw = 0.0;   // (R w)_j
+      for (int jp = 0; jp < k; ++jp) {
+        const int a = j < jp ? j : jp, bq = j < jp ? jp : j;
+        rw += (double)w[c * k + jp] * mb[ridx(k, a, bq)];
+      }
+      acc += rs * ga * (sb[j] - S1 * invL * mb[j] - S2 * invL * rs * (rw - mu * mb[j]));
     }
-    acc += rs * ga * (sb[j] - S1 * invL * mb[j] - S2 * invL * rs * (rw - mu * mb[j]));
   }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    acc += __shfl_xor(acc, o, 64);
+    g1 += __shfl_xor(g1, o, 64);
+    g2 += __shfl_xor(g2, o, 64);
+  }
+  if (c >= C || j >= k || bl != 0) return;
   if (dw) dw[c * k + j] += gscale * (float)acc;
   if (j == 0) {
     if (dgamma) dgamma[c] += gscale * (float)g2;
@@ -295,7 +615,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_final_kernel(const double* __re
 
 // workspace layout (floats unless noted): [chunk partials: max(B nch nmom, B nch C (KWmax + 2))] [mom: B nmom doubles]
 // [sums: B C (KWmax + 2) doubles]
-struct Ws { float* part; double* mom; double* sums; };
+struct Ws { float* part; double* mom; double* sums; bf16x8* afrag; };
 __host__ inline int64_t ws_part_floats(int B, int nch, int C, int k) {
   const int64_t a = (int64_t)B * nch * nmom(k), b = (int64_t)B * nch * C * (MAXK + 2);
   return ((a > b ? a : b) + 1) / 2 * 2;   // keep the doubles 8-byte aligned
@@ -305,29 +625,40 @@ __host__ inline Ws carve(void* ws, int B, int nch, int C, int k) {
   r.part = (float*)ws;
   r.mom = (double*)(r.part + ws_part_floats(B, nch, C, k));
   r.sums = r.mom + (int64_t)B * nmom(k);
+  r.afrag = reinterpret_cast<bf16x8*>(r.sums + (int64_t)B * C * (MAXK + 2));      // (8-byte aligned doubles in front: a multiple of 16 bytes
+  r.afrag = reinterpret_cast<bf16x8*>((reinterpret_cast<uintptr_t>(r.afrag) + 15) & ~(uintptr_t)15);   //  is enforced here)
   return r;
 }
 
-template <int KW>
-void launch_moments(const float* wav, const Ws& W, int B, int S, int L, int k, int stride, int nch, size_t shm, hipStream_t s) {
-  hipLaunchKernelGGL((conv0_moments_kernel<KW>), dim3(nch, B), dim3(256), shm, s, wav, W.part, S, L, k, stride, nch);
-  hipLaunchKernelGGL(conv0_moments_final_kernel, dim3(B), dim3(256), 0, s, W.part, W.mom, nmom(k), nch);
+// waveform moments (+ statistics when `stats` is given): two launches
+void launch_moments_stats(const float* wav, const float* w, float* stats, const Ws& W, int B, int S, int L, int C, int k, int stride, float eps,
+                          hipStream_t s) {
+  const int nchm = (L + TCM - 1) / TCM;
+  const size_t shm2 = (size_t)(((TCM - 1) * stride + k + 8 + 3) & ~3) * sizeof(float);
+  if (shm2 > 60 * 1024) return;      // (strides far beyond the recipe's 5: the caller rejects them, see st5_conv0_gn_gelu_fwd)
+  if (k <= 10) hipLaunchKernelGGL((conv0_moments2_kernel<10>), dim3(nchm, B), dim3(256), shm2, s, wav, W.part, S, L, k, stride, nchm);
+  else hipLaunchKernelGGL((conv0_moments2_kernel<MAXK>), dim3(nchm, B), dim3(256), shm2, s, wav, W.part, S, L, k, stride, nchm);
+  hipLaunchKernelGGL(conv0_stats2_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, W.part, W.mom, w, stats, C, k, L, nchm, eps);
 }
 
 }  // namespace
+
+namespace { int g_conv0_mfma = 1; }
+/* 1 (default): the bf16 forward apply pass on the matrix cores (split-bf16 operands); 0: the VALU form (A/B, and what fp32 always runs). */
+extern "C" int st5_conv0_set_mfma(int on) { g_conv0_mfma = on ? 1 : 0; return ST5_OK; }
 
 extern "C" int64_t st5_conv0_ws_bytes(int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride) {
   const int L = out_len(S, k, stride);
   const int64_t nch = (L + TCH - 1) / TCH;
   return ws_part_floats(B, (int)nch, C, k) * (int64_t)sizeof(float) +
-         ((int64_t)B * nmom(k) + (int64_t)B * C * (MAXK + 2)) * (int64_t)sizeof(double);
+         ((int64_t)B * nmom(k) + (int64_t)B * C * (MAXK + 2)) * (int64_t)sizeof(double) + 16 + (int64_t)C * 64;   // + MFMA weight fragments
 }
 
 extern "C" int st5_conv0_gn_gelu_fwd(const float* wav, const float* w, const float* gamma, const float* beta,
                                      void* out, float* stats, void* ws, int32_t B, int32_t S, int32_t C, int32_t k,
                                      int32_t stride, float eps, int dtype, void* stream) {
   if (!wav || !w || !gamma || !beta || !out || !stats || !ws) return ST5_ERR_ARG;
-  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || k > MAXK || k < 1 || stride < 1) return ST5_ERR_ARG;
+  if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || k > MAXK || k < 1 || stride < 1 || stride > 7) return ST5_ERR_ARG;
   if (C / 8 > 256) return ST5_ERR_ARG;
   const int L = out_len(S, k, stride);
   if (L <= 0 || B <= 0) return ST5_ERR_ARG;
@@ -336,13 +667,20 @@ extern "C" int st5_conv0_gn_gelu_fwd(const float* wav, const float* w, const flo
   const int nch = (L + TCH - 1) / TCH;
   const size_t shm = (size_t)(TCH * stride + k + MAXK) * sizeof(float);
   const Ws W = carve(ws, B, nch, C, k);
-  if (k <= 10) launch_moments<10>(wav, W, B, S, L, k, stride, nch, shm, s);
-  else launch_moments<MAXK>(wav, W, B, S, L, k, stride, nch, shm, s);
-  hipLaunchKernelGGL(conv0_stats_from_moments_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, W.mom, w, stats, C, k, L, eps);
+  launch_moments_stats(wav, w, stats, W, B, S, L, C, k, stride, eps, s);
 #define APPLY(TT, KW)                                                                                           \
   hipLaunchKernelGGL((conv0_apply_kernel<TT, KW>), dim3(nch, B), dim3(256), shm, s, wav, w, gamma, beta, stats, \
                      (TT*)out, S, L, C, k, stride)
-  if (dtype == ST5_BF16) { if (k <= 10) APPLY(bf16_t, 10); else APPLY(bf16_t, MAXK); }
+  if (dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 32 == 0 && C <= 1024) {
+    hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32), dim3(128), 0, s, w, W.afrag, k);
+    const size_t shm_m = (size_t)(C / 32) * 2048 + (size_t)2 * C * sizeof(float) + shm;
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)conv0_apply_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv0_apply_mfma_kernel, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, gamma, beta, stats, (bf16_t*)out, S, L, C, k, stride);
+  } else if (dtype == ST5_BF16) { if (k <= 10) APPLY(bf16_t, 10); else APPLY(bf16_t, MAXK); }
   else { if (k <= 10) APPLY(float, 10); else APPLY(float, MAXK); }
 #undef APPLY
   HIP_CHECK_LAUNCH();
@@ -354,7 +692,7 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
                                      void* ws, int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride,
                                      float gscale, int dtype, void* stream) {
   if (!wav || !w || !gamma || !beta || !stats || !dY || !ws) return ST5_ERR_ARG;
-  if (C % 8 || C / 8 > 256 || 256 % (C / 8) || k > MAXK || k < 1 || stride < 1) return ST5_ERR_ARG;
+  if (C % 8 || C / 8 > 256 || 256 % (C / 8) || k > MAXK || k < 1 || stride < 1 || stride > 7) return ST5_ERR_ARG;
   const int L = out_len(S, k, stride);
   if (L <= 0 || B <= 0) return ST5_ERR_ARG;
   if (dtype != ST5_BF16 && dtype != ST5_F32) return ST5_ERR_ARG;
@@ -363,8 +701,7 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
   const size_t shm = (size_t)(TCH * stride + k + MAXK) * sizeof(float);
   const Ws W = carve(ws, B, nch, C, k);
   // waveform moments again (0.64 MB/clip; cheaper than keeping them alive between forward and backward)
-  if (k <= 10) launch_moments<10>(wav, W, B, S, L, k, stride, nch, shm, s);
-  else launch_moments<MAXK>(wav, W, B, S, L, k, stride, nch, shm, s);
+  launch_moments_stats(wav, w, nullptr, W, B, S, L, C, k, stride, 0.f, s);
   const int KWv = k <= 10 ? 10 : MAXK, nv = KWv + 2;
   {   // ST5_POISON=1 (debug): the partials region is NaN before the backward kernel fills it -- a reduce that ran ahead of a
       // block of conv0_bwd_kernel, or a block that never stored, then shows as NaN instead of as last step's value
@@ -374,12 +711,24 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
 #define BWD(TT, KW)                                                                                               \
   hipLaunchKernelGGL((conv0_bwd_kernel<TT, KW>), dim3(nch, B), dim3(256), shm, s, wav, w, gamma, beta, stats,     \
                      (const TT*)dY, W.part, S, L, C, k, stride, nch)
-  if (dtype == ST5_BF16) { if (k <= 10) BWD(bf16_t, 10); else BWD(bf16_t, MAXK); }
+  const bool mfma = dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 128 == 0 && C <= 1024 && TCH % 32 == 0;
+  if (mfma) {
+    hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32), dim3(128), 0, s, w, W.afrag, k);
+    const size_t seg_f = (size_t)(((TCH - 1) * stride + k + MAXK + 3) & ~3);
+    const size_t shm_m = (size_t)(C / 32) * 2048 + (size_t)2 * C * sizeof(float) + seg_f * sizeof(float) + (size_t)4 * C0_TILE_B;
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)conv0_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv0_bwd_mfma_kernel, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, gamma, beta, stats, (const bf16_t*)dY, W.part, S, L,
+                       C, k, stride, nch);
+  } else if (dtype == ST5_BF16) { if (k <= 10) BWD(bf16_t, 10); else BWD(bf16_t, MAXK); }
   else { if (k <= 10) BWD(float, 10); else BWD(float, MAXK); }
 #undef BWD
   hipLaunchKernelGGL(conv0_bwd_reduce_kernel, dim3((C * nv + 31) / 32, B), dim3(256), 0, s, W.part, W.sums, C, nch, nv);
-  hipLaunchKernelGGL(conv0_bwd_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, W.sums, W.mom, w, gamma, stats, dw, dgamma,
-                     dbeta, B, C, k, L, nv, gscale);
+  hipLaunchKernelGGL(conv0_bwd_final_kernel, dim3((C + 1) / 2), dim3(256), 0, s, W.sums, W.mom, w, gamma, stats, dw, dgamma,
+                     dbeta, B, C, k, L, nv, gscale, mfma ? 1 : 0);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

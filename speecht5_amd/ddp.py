@@ -264,7 +264,11 @@ class FlatGradDataParallel:
         while len(self._fwd_streams) < n - 1:
             # ST5_SERIAL_MICRO=1 (debug): the "second stream" IS the current stream -- same program, same two gradient buffers,
             # no concurrency at all (the reference point when hunting a race between the micro-batches' kernels)
-            self._fwd_streams.append(cur if os.environ.get("ST5_SERIAL_MICRO") == "1" else torch.cuda.Stream(device=self.flat.device))
+            # ST5_SBS_PRIORITY (A/B): HIP priority of the second micro-batch's stream (-1 = high).  The text micro-batch is the longer
+            # chain (8.1 against 4.75 TFLOP): whatever it gains while both are resident comes off the update's critical path.
+            prio = int(os.environ.get("ST5_SBS_PRIORITY", "0"))
+            self._fwd_streams.append(cur if os.environ.get("ST5_SERIAL_MICRO") == "1"
+                                     else torch.cuda.Stream(device=self.flat.device, priority=prio))
         if n > 1 and self.flat2 is None:
             # the second gradient buffer is created (and zero-filled) HERE, on the current stream, before the streams fork: created
             # lazily inside the second backward it was zero-filled on this stream while the other stream already accumulated into it

@@ -39,3 +39,56 @@ def test_the_audit_sees_the_round4_form_of_the_dkv_kernel():
     f = _compile(m, os.path.join(ROOT, "speecht5_amd", "csrc", "flash_attn2.hip"), ["-DFA2_NO_LGKM_BARRIER"])
     names = [name for name, _, _ in m.audit(f)]
     assert any("bwd_dkv_kernel" in n for n in names), names
+
+
+def test_gelu_poly_error_bound():
+    """common.h gelu_poly (the transcendental-free GELU value of the bf16 epilogues): its fp32 instruction sequence restated in numpy
+    with the constants parsed from the source, against the exact erf-GELU: |Phi error| <= 1.6e-5, |gelu error| <= 2.5e-5 on [-4, 4]
+    and <= 1.6e-5 |x| beyond -- two orders below the bf16 rounding of the value it feeds."""
+    import re
+    import numpy as np
+    from scipy.special import erf
+    src = open(os.path.join(ROOT, "speecht5_amd", "csrc", "common.h")).read()
+    body = src[src.index("float gelu_poly(float x)"):]
+    body = body[:body.index("return x * fmaf(xc, g, 0.5f)")]
+    clamp = np.float32(re.search(r"fminf\(fmaxf\(x, -(\d\.\d+)f\)", body).group(1))
+    co = [np.float32(c) for c in re.findall(r"(-?\d\.\d+e[+-]\d+)f", body)]
+    assert len(co) == 10 and abs(float(clamp) - 3 * 2 ** 0.5) < 1e-6
+    x = np.linspace(-8, 8, 1600001).astype(np.float32)
+    xc = np.clip(x, -clamp, clamp)
+    v = (xc * xc).astype(np.float32)
+    g = (v.astype(np.float64) * co[0] + co[1]).astype(np.float32)
+    for a in co[2:]:
+        g = (g.astype(np.float64) * v + a).astype(np.float32)      # (fma: one rounding)
+    cdf = (xc.astype(np.float64) * g + 0.5).astype(np.float32)
+    got = (x * cdf).astype(np.float32).astype(np.float64)
+    xd = x.astype(np.float64)
+    phi = 0.5 * (1 + erf(xd / np.sqrt(2)))
+    err = np.abs(got - xd * phi)
+    assert np.abs(cdf.astype(np.float64) - phi).max() <= 1.6e-5
+    assert err[np.abs(x) <= 4].max() <= 2.5e-5, err[np.abs(x) <= 4].max()
+    assert (err <= 2.5e-5 + 1.6e-5 * np.abs(xd)).all()
+
+
+def test_gelu_grad_poly_error_bound():
+    """common.h gelu_grad_poly (derivative of GELU in the bf16 backward epilogues), restated in numpy from the parsed constants:
+    |error| <= 1.3e-4 everywhere (the exact derivative lies in [-0.13, 1.13]; the factor multiplies bf16 operands)."""
+    import re
+    import numpy as np
+    from scipy.special import erf
+    src = open(os.path.join(ROOT, "speecht5_amd", "csrc", "common.h")).read()
+    body = src[src.index("float gelu_grad_poly(float x)"):]
+    body = body[:body.index("return fmaf(xc, h, 0.5f)")]
+    clamp = np.float32(re.search(r"fminf\(fmaxf\(x, -(\d\.\d+)f\)", body).group(1))
+    co = [np.float32(c) for c in re.findall(r"(-?\d\.\d+e[+-]\d+)f", body)]
+    assert len(co) == 11
+    x = np.linspace(-10, 10, 2000001).astype(np.float32)
+    xc = np.clip(x, -clamp, clamp)
+    v = (xc * xc).astype(np.float32)
+    h = (v.astype(np.float64) * co[0] + co[1]).astype(np.float32)
+    for a in co[2:]:
+        h = (h.astype(np.float64) * v + a).astype(np.float32)
+    got = (xc.astype(np.float64) * h + 0.5).astype(np.float32).astype(np.float64)
+    xd = x.astype(np.float64)
+    exact = 0.5 * (1 + erf(xd / np.sqrt(2))) + xd * np.exp(-xd * xd / 2) / np.sqrt(2 * np.pi)
+    assert np.abs(got - exact).max() <= 1.3e-4, np.abs(got - exact).max()

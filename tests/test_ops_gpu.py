@@ -361,6 +361,78 @@ def test_conv0_groupnorm_gelu(cuda, dtype, B, S, C):
     close(dB, br.grad, dtype, what="conv0 dbeta")
 
 
+@pytest.mark.parametrize("B,S,C", [(2, 3007, 64), (1, 16000, 512), (3, 5125, 256)])
+def test_conv0_matrix_core_apply_equals_the_valu_apply(cuda, B, S, C):
+    """bf16 forward of conv layer 0: the matrix-core form (split-bf16 operands, two MFMAs per 32 channels x 32 steps, permuted channel
+    rows so that a lane stores 16 consecutive channels) against the VALU form (fp32 FMAs): the pre-activations agree to ~2^-16, so the
+    bf16 outputs are equal except where that flips a rounding -- never by more than one bf16 ulp; ragged last time tile included."""
+    torch.manual_seed(S + C)
+    k, stride = 10, 5
+    Lo = (S - k) // stride + 1
+    wav = torch.randn(B, S, device=cuda)
+    w = (torch.randn(C, k) * math.sqrt(2.0 / k)).to(cuda)
+    g, b = (torch.rand(C) + 0.5).to(cuda), (torch.randn(C) * 0.1).to(cuda)
+    Ld = hip.lib()
+    ws = hip.workspace(Ld.st5_conv0_ws_bytes(B, S, C, k, stride), cuda)
+    outs = []
+    try:
+        for mode in (0, 1):
+            hip.check(Ld.st5_conv0_set_mfma(mode), "set_mfma")
+            out = torch.full((B, Lo, C), float("nan"), dtype=torch.bfloat16, device=cuda)
+            stats = torch.empty(B, C, 2, device=cuda)
+            hip.check(Ld.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                                               ws.data_ptr(), B, S, C, k, stride, 1e-5, hip.BF16, hip.stream()), "conv0 fwd")
+            torch.cuda.synchronize()
+            outs.append(out.float())
+    finally:
+        hip.check(Ld.st5_conv0_set_mfma(1), "set_mfma")
+    valu, mfma = outs
+    assert torch.isfinite(mfma).all()
+    diff = (valu - mfma).abs()
+    # one bf16 ulp of the larger value, plus the split-operand error of the pre-activation itself (2^-16 sum |w_j x_j| ~ 5e-5) where
+    # the output is tiny
+    ulp = torch.maximum(valu.abs(), mfma.abs()) * 2.0 ** -7 + 6e-5
+    assert bool((diff <= ulp).all()), float((diff / ulp).max())
+    assert float((diff > 0).float().mean()) < 0.03, float((diff > 0).float().mean())
+
+
+@pytest.mark.parametrize("B,S,C,k", [(2, 6407, 128, 10), (1, 16000, 512, 10), (2, 4000, 256, 7)])
+def test_conv0_matrix_core_backward_equals_the_valu_backward(cuda, B, S, C, k):
+    """bf16 backward of conv layer 0 on the matrix cores (recomputed convolution and the dz . x products as split-bf16 MFMAs, dz
+    transposed through LDS with the gfx950 transpose read, S2 derived from A and S1) against the VALU form on the same inputs: dW,
+    dgamma, dbeta agree to 4e-3 of their scale (dz enters the matrix cores as ONE bf16 operand, as dY does in every weight-gradient GEMM of
+    the bf16 mode; the waveform side is split and keeps ~16 bits)."""
+    torch.manual_seed(S + C)
+    stride = 5
+    Lo = (S - k) // stride + 1
+    wav = torch.randn(B, S, device=cuda)
+    w = (torch.randn(C, k) * math.sqrt(2.0 / k)).to(cuda)
+    g, b = (torch.rand(C) + 0.5).to(cuda), (torch.randn(C) * 0.1).to(cuda)
+    dY = (torch.randn(B, Lo, C, device=cuda) * 0.3).to(torch.bfloat16)
+    Ld = hip.lib()
+    ws = hip.workspace(Ld.st5_conv0_ws_bytes(B, S, C, k, stride), cuda)
+    res = []
+    try:
+        for mode in (0, 1):
+            hip.check(Ld.st5_conv0_set_mfma(mode), "set_mfma")
+            out = torch.empty(B, Lo, C, dtype=torch.bfloat16, device=cuda)
+            stats = torch.empty(B, C, 2, device=cuda)
+            hip.check(Ld.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                                               ws.data_ptr(), B, S, C, k, stride, 1e-5, hip.BF16, hip.stream()), "conv0 fwd")
+            dW = torch.zeros(C, k, device=cuda); dG = torch.zeros(C, device=cuda); dB = torch.zeros(C, device=cuda)
+            hip.check(Ld.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), stats.data_ptr(), dY.data_ptr(),
+                                               dW.data_ptr(), dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), B, S, C, k, stride, 1.0, hip.BF16,
+                                               hip.stream()), "conv0 bwd")
+            torch.cuda.synchronize()
+            res.append((dW.clone(), dG.clone(), dB.clone()))
+    finally:
+        hip.check(Ld.st5_conv0_set_mfma(1), "set_mfma")
+    for (a, m, nm) in zip(res[0], res[1], ("dW", "dgamma", "dbeta")):
+        assert torch.isfinite(m).all(), nm
+        err = float((a - m).abs().max()) / max(float(a.abs().max()), 1e-6)
+        assert err <= 4e-3, (nm, err)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_elementwise_and_losses(cuda, dtype):
     torch.manual_seed(23)
