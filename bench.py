@@ -117,6 +117,43 @@ def cpu_baseline(model, args, seconds=4.0, runs=5):
     return out
 
 
+def conv0_device_time(device, B, reps=20):
+    """ms per st5_conv0_gn_gelu_fwd / _bwd call at the benched shape (B x 160 000 samples -> 512 channels, bf16), back-to-back calls."""
+    from speecht5_amd import hip
+    L_ = hip.lib()
+    S, C, k, stride = 160000, 512, 10, 5
+    Lo = (S - k) // stride + 1
+    wav = torch.randn(B, S, device=device)
+    w = torch.randn(C, k, device=device) * 0.4
+    g, b_ = torch.ones(C, device=device), torch.zeros(C, device=device)
+    out = torch.empty(B, Lo, C, dtype=torch.bfloat16, device=device)
+    dy = (torch.randn(B, Lo, C, device=device) * 0.1).to(torch.bfloat16)
+    stats = torch.empty(B, C, 2, device=device)
+    dw, dg, db = torch.zeros(C, k, device=device), torch.zeros(C, device=device), torch.zeros(C, device=device)
+    ws = hip.workspace(L_.st5_conv0_ws_bytes(B, S, C, k, stride), device)
+
+    def fwd():
+        hip.check(L_.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b_.data_ptr(), out.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                                            B, S, C, k, stride, 1e-5, hip.BF16, hip.stream()), "conv0 fwd")
+
+    def bwd():
+        hip.check(L_.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b_.data_ptr(), stats.data_ptr(), dy.data_ptr(), dw.data_ptr(),
+                                            dg.data_ptr(), db.data_ptr(), ws.data_ptr(), B, S, C, k, stride, 1.0, hip.BF16, hip.stream()), "conv0 bwd")
+    res = {}
+    for nm, fn in (("conv0_gn_gelu_fwd", fwd), ("conv0_gn_gelu_bwd", bwd)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[nm] = round(e0.elapsed_time(e1) / reps, 4)
+    return res
+
+
 def box_info():
     """Which box this line was measured on (the pool's boxes differ by up to 20 % for the same commit, profiles/r4_knob_ab.txt): device
     name, CU count, and the clocks / power cap rocm-smi reports at the end of the run -- so a slow line is attributable."""
@@ -341,9 +378,11 @@ def main():
         # -- with the micro-batches IN TURN on one stream, whatever the timed mode: a launch's event pair then brackets that kernel
         # alone (side by side, the other stream's kernels share the chip during it and the rate would be the pair's, not the kernel's)
         from speecht5_amd import functional as Fn
-        hip.profiler.enabled = True
         Fn._S.force_static = True
         timed_mode, upd.mode = upd.mode, "in_turn"
+        upd.eager_update()           # (untimed: the in-turn form launches kernel instantiations the side-by-side steps never used --
+        torch.cuda.synchronize()     #  their one-time set-up must not land inside an event pair of the sampled update)
+        hip.profiler.enabled = True
         upd.eager_update()
         upd.mode = timed_mode
         Fn._S.force_static = False
@@ -456,6 +495,17 @@ def main():
                      "frac_of_8TBps": round(b_ / t_ / 8e12, 4) if t_ > 0 else None}
         if rfl.get(name):
             hbm[name]["tflops"] = round(rfl[name] / t_ / 1e12, 1) if t_ > 0 else None
+    # conv layer 0 once more, as DEVICE time: the figures above bracket one eagerly enqueued call each (4 / 6 small launches whose host
+    # gaps the events include); here 20 forward and 20 backward calls are enqueued back to back on the same shapes, events around the
+    # whole train -- the queue runs ahead of the GPU, so the quotient is the kernels' own time per call, as inside a replayed graph
+    if world == 1 and a.arch == "base" and "conv0_gn_gelu_fwd" in hbm:
+        try:
+            c0 = conv0_device_time(device, a.batch)
+            for nm, ms in c0.items():
+                mb = hbm[nm]["algorithmic_MB"]
+                hbm[nm].update(device_ms=ms, device_GBps=round(mb / ms, 1), device_frac_of_8TBps=round(mb / ms / 8e3, 4))
+        except Exception as e:      # (a measurement extra must never cost the line)
+            hbm["conv0_device_time_error"] = repr(e)
     front = [hbm.pop(k) for k in ("conv_frontend_fwd", "conv_frontend_bwd") if k in hbm]
     if len(front) == 2:
         fb, ft = sum(f["algorithmic_MB"] for f in front), sum(f["ms"] for f in front)

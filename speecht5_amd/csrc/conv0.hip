@@ -54,19 +54,33 @@ __device__ __forceinline__ void conv8(const float* __restrict__ segp, const floa
   }
 }
 
+// The block's samples -> LDS.  All of a thread's loads are issued before the first store (a plain `for` with the bounds test inside
+// made every iteration wait for its own global round trip: 6-10 sequential latencies at the head of every block).
 __device__ __forceinline__ void stage_wav(float* seg, const float* __restrict__ wav, int b, int S, int t0, int nt, int k,
                                           int stride) {
-  const int nseg = (nt - 1) * stride + k;
-  for (int i = threadIdx.x; i < nseg + MAXK; i += 256)
-    seg[i] = i < nseg ? wav[(long long)b * S + (long long)t0 * stride + i] : 0.f;
+  const int nseg = (nt - 1) * stride + k, ntot = nseg + MAXK;
+  const float* src = wav + (long long)b * S + (long long)t0 * stride;
+  for (int base = 0; base < ntot; base += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256 + threadIdx.x;
+      v[u] = i < nseg ? src[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256 + threadIdx.x;
+      if (i < ntot) seg[i] = v[u];
+    }
+  }
 }
 
 // ---- waveform moments and GroupNorm statistics in TWO launches (round 5; three launches of 22 + 14 + 8 us before, for 5 MB of input) --
-// conv0_moments2_kernel: a block owns TCM = 2048 time steps, a thread 8 of them -- the 65 moment products are accumulated in registers
+// conv0_moments2_kernel: a block owns TCM = 1024 time steps, a thread 4 of them -- the 65 moment products are accumulated in registers
 // over the thread's steps and reduced ONCE per block (the first form reduced 65 values per 256 steps).  part2[b][chunk][nmom].
 // conv0_stats2_kernel: every block of (64 channels, clip) first folds the clip's chunk partials in fp64 (fixed order), block 0 of a
 // clip also publishes them (the backward's final kernel reads them), then 64 threads evaluate mean / rstd of their channels.
-constexpr int TCM = 2048;
+constexpr int TCM = 1024;
 template <int KW>
 __global__ __launch_bounds__(256) void conv0_moments2_kernel(const float* __restrict__ wav, float* __restrict__ part, int S, int L, int k,
                                                              int stride, int nchm) {
@@ -81,14 +95,24 @@ __global__ __launch_bounds__(256) void conv0_moments2_kernel(const float* __rest
     const int shift = (int)(g0 - ga), nneed = shift + (nt - 1) * stride + k;
     const long long gend = (long long)(b + 1) * S;          // (never read past the clip: the next clip / the buffer's end)
     const float4* src = reinterpret_cast<const float4*>(wav + ga);
-    for (int i = threadIdx.x; i * 4 < nneed; i += 256) {
-      float4 v;
-      if (ga + 4ll * i + 3 < gend && ((reinterpret_cast<uintptr_t>(wav) & 15) == 0)) v = src[i];
-      else {
+    const bool al16 = (reinterpret_cast<uintptr_t>(wav) & 15) == 0;
+    for (int base = 0; base * 4 < nneed; base += 256 * 4) {      // (four 16-byte loads in flight per thread)
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + threadIdx.x;
         const long long p = ga + 4ll * i;
-        v.x = p < gend ? wav[p] : 0.f; v.y = p + 1 < gend ? wav[p + 1] : 0.f; v.z = p + 2 < gend ? wav[p + 2] : 0.f; v.w = p + 3 < gend ? wav[p + 3] : 0.f;
+        if (i * 4 < nneed && al16 && p + 3 < gend) v[u] = src[i];
+        else {
+          v[u].x = (i * 4 < nneed && p < gend) ? wav[p] : 0.f; v[u].y = (i * 4 < nneed && p + 1 < gend) ? wav[p + 1] : 0.f;
+          v[u].z = (i * 4 < nneed && p + 2 < gend) ? wav[p + 2] : 0.f; v[u].w = (i * 4 < nneed && p + 3 < gend) ? wav[p + 3] : 0.f;
+        }
       }
-      reinterpret_cast<float4*>(segm)[i] = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 256 + threadIdx.x;
+        if (i * 4 < nneed) reinterpret_cast<float4*>(segm)[i] = v[u];
+      }
     }
     __syncthreads();
   }
@@ -132,12 +156,23 @@ __global__ __launch_bounds__(256) void conv0_moments2_kernel(const float* __rest
 __global__ __launch_bounds__(256) void conv0_stats2_kernel(const float* __restrict__ part, double* __restrict__ mom, const float* __restrict__ w,
                                                            float* __restrict__ stats, int C, int k, int L, int nchm, float eps) {
   __shared__ double ms[MAXMOM];
+  __shared__ double ps[4][MAXMOM];
   const int b = blockIdx.y, nm = nmom(k);
-  for (int m = threadIdx.x; m < nm; m += 256) {
-    double s = 0.0;
-    for (int ch = 0; ch < nchm; ++ch) s += (double)part[((long long)b * nchm + ch) * nm + m];
-    ms[m] = s;
-    if (blockIdx.x == 0) mom[(long long)b * nm + m] = s;
+  {   // chunk partials -> fp64 sums: four wave-sized groups take every fourth chunk (fixed order), folded in a fixed order
+    const int grp = threadIdx.x >> 6, ml = threadIdx.x & 63;
+    for (int base = 0; base < nm; base += 64) {
+      const int m = base + ml;
+      double sacc = 0.0;
+      if (m < nm)
+        for (int ch = grp; ch < nchm; ch += 4) sacc += (double)part[((long long)b * nchm + ch) * nm + m];
+      if (m < nm) ps[grp][m] = sacc;
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < nm; m += 256) {
+      const double sacc = (ps[0][m] + ps[1][m]) + (ps[2][m] + ps[3][m]);
+      ms[m] = sacc;
+      if (blockIdx.x == 0) mom[(long long)b * nm + m] = sacc;
+    }
   }
   __syncthreads();
   const int c = blockIdx.x * 64 + threadIdx.x;
@@ -197,50 +232,53 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
 }
 
 // ---- forward apply on the matrix cores (bf16 output, k <= 10, C % 32 == 0) --------------------------------------------------------
-// The VALU form above spends ~24 issue slots per output element (10 FMAs of the convolution, the affine, ~21 of the erf-GELU (its rcp and exp issue at quarter rate), the
-// pack): 131 M outputs per 8-clip batch = 100+ us of pure VALU issue on 256 CUs, against 33 us to WRITE the 262 MB at 8 TB/s -- it is
-// VALU-bound (measured 110 us = 2.4 TB/s).  Here the convolution is a GEMM on v_mfma_f32_32x32x16_bf16 with SPLIT operands:
-//   x = xh + xl, w = wh + wl (bf16 each, xl / wl the rounding residues)      y ~= wh.xh + wh.xl + wl.xh     (wl.xl ~ 2^-16 |w||x|: dropped)
-// laid out along K as [wh | wh | wl] . [xh ; xl ; xh] -- 30 of the 32 k-slots of TWO MFMAs per 32 channels x 32 time steps, the fp32
-// accumulator carrying ~16 mantissa bits of every product pair (the recipe's own fp16 autocast keeps 11).  The channel <-> MFMA row
-// mapping is PERMUTED (c0_perm) so that a lane's 16 accumulator registers are 16 CONSECUTIVE channels of one time step: the
-// channels-last store is two 16-byte stores per lane, no LDS transpose.  What is left per output element is the affine, the transcendental-free GELU
-// (common.h gelu_poly) and the pack: ~18 issue slots = 60 us of VALU issue.  The weight fragments are built once per call (conv0_wfrag_kernel, 32 KB for 512 channels) and sit in LDS.
+// The VALU form above spends ~31 issue slots per output element (10 FMAs of the convolution, the affine, ~21 of the erf-GELU whose rcp
+// and exp issue at quarter rate, the pack): 131 M outputs per 8-clip batch = 100 us of pure VALU issue on 256 CUs, against 33 us to
+// WRITE the 262 MB at 8 TB/s -- it was VALU-bound (measured 110-117 us = 2.3 TB/s).  Here the convolution AND the GroupNorm affine are
+// one GEMM on v_mfma_f32_32x32x16_bf16 with SPLIT operands:
+//   x = xh + xl, sc w = ah + al (bf16 each, xl / al the rounding residues, sc = rstd gamma)     z ~= ah.xh + ah.xl + al.xh + sh
+// laid out along K as [ah | ah | al | shh shl] . [xh ; xl ; xh ; 1 1] -- all 32 k-slots of TWO MFMAs per 32 channels x 32 time steps
+// (the shift sh = beta - mean sc rides in the two slots the 3 x 10 taps leave free), the fp32 accumulator carrying ~16 mantissa bits
+// of every product (the recipe's own fp16 autocast keeps 11; the dropped al.xl is ~2^-16 |w||x|).  The channel <-> MFMA row mapping is
+// PERMUTED (c0_perm) so that a lane's 16 accumulator registers are 16 CONSECUTIVE channels of one time step: the channels-last store
+// is two 16-byte stores per lane, no LDS transpose.  What is left per output element is the transcendental-free GELU (common.h
+// gelu_poly) and the pack: ~15 issue slots.  The fragments depend on the clip (its statistics): conv0_wfrag_kernel builds them once per
+// call (B x 32 KB for 512 channels); a block keeps its clip's 32 KB in LDS.
 __device__ __forceinline__ int c0_perm(int m) { return 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3); }
 
-__global__ __launch_bounds__(128) void conv0_wfrag_kernel(const float* __restrict__ w, bf16x8* __restrict__ afrag, int k) {
-  const int mt = blockIdx.x, q = threadIdx.x >> 6, l = threadIdx.x & 63;
+__global__ __launch_bounds__(128) void conv0_wfrag_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ stats, bf16x8* __restrict__ afrag, int C, int k) {
+  // afrag[b][tile][2][64 lanes]: the GroupNorm affine is folded in -- rows hold sc w (sc = rstd gamma, split in bf16 high / low parts)
+  // and the two spare k slots (30, 31) hold the shift sh = beta - mean sc (high / low part) against ones on the x side: the MFMA pair
+  // returns z = sc (w . x) + sh, the GELU argument, directly
+  const int mt = blockIdx.x, b = blockIdx.y, q = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int c = 32 * mt + c0_perm(l & 31), hi = l >> 5;
+  const float mu = stats[((long long)b * C + c) * 2], rs = stats[((long long)b * C + c) * 2 + 1];
+  const float sc = rs * gamma[c], sh = beta[c] - mu * sc;
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int kk = 16 * q + 8 * hi + e, sec = kk / 10, j = kk - 10 * sec;
-    const float wv = (kk < 30 && j < k) ? w[c * k + j] : 0.f;
-    const bf16_t wh = (bf16_t)wv;
-    o[e] = sec < 2 ? wh : (bf16_t)(wv - (float)wh);
+    float v = (kk < 30 && j < k) ? sc * w[c * k + j] : 0.f;
+    if (kk >= 30) v = sh;
+    const bf16_t vh = (bf16_t)v;
+    const bool low = sec == 2 && kk < 30 || kk == 31;
+    o[e] = low ? (bf16_t)(v - (float)vh) : vh;
   }
-  afrag[(mt * 2 + q) * 64 + l] = o;
+  afrag[((long long)(b * gridDim.x + mt) * 2 + q) * 64 + l] = o;
 }
 
 __global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __restrict__ wav, const bf16x8* __restrict__ afrag_g,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               const float* __restrict__ stats, bf16_t* __restrict__ out, int S, int L,
-                                                               int C, int k, int stride) {
+                                                               bf16_t* __restrict__ out, int S, int L, int C, int k, int stride) {
   extern __shared__ __attribute__((aligned(16))) char sm0[];
   const int ntile = C / 32;
-  bf16x8* afr = reinterpret_cast<bf16x8*>(sm0);                       // [ntile][2][64 lanes] x 16 B
-  float* scs = reinterpret_cast<float*>(sm0 + (size_t)ntile * 2048);  // scale[C] | shift[C]
-  float* seg = scs + 2 * C;
+  bf16x8* afr = reinterpret_cast<bf16x8*>(sm0);                       // [ntile][2][64 lanes] x 16 B (this clip's)
+  float* seg = reinterpret_cast<float*>(sm0 + (size_t)ntile * 2048);
   const int b = blockIdx.y, t0 = blockIdx.x * TCH;
   const int nt = min(TCH, L - t0);
   stage_wav(seg, wav, b, S, t0, nt, k, stride);
-  for (int i = threadIdx.x; i < ntile * 128; i += 256) afr[i] = afrag_g[i];
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float mu = stats[((long long)b * C + c) * 2], rs = stats[((long long)b * C + c) * 2 + 1];
-    const float sc = rs * gamma[c];
-    scs[c] = sc;
-    scs[C + c] = beta[c] - mu * sc;
-  }
+  const bf16x8* afb = afrag_g + (long long)b * ntile * 128;
+  for (int i = threadIdx.x; i < ntile * 128; i += 256) afr[i] = afb[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, hi = lane >> 5;
@@ -256,17 +294,16 @@ __global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __re
       xh[j] = (bf16_t)xv;
       xl[j] = (bf16_t)(xv - (float)xh[j]);
     }
-    const bf16_t z0 = (bf16_t)0.f;
+    const bf16_t one = (bf16_t)1.f;
     bf16x8 b1, b2;
     if (hi == 0) {
       b1 = bf16x8{xh[0], xh[1], xh[2], xh[3], xh[4], xh[5], xh[6], xh[7]};
       b2 = bf16x8{xl[6], xl[7], xl[8], xl[9], xh[0], xh[1], xh[2], xh[3]};
     } else {
       b1 = bf16x8{xh[8], xh[9], xl[0], xl[1], xl[2], xl[3], xl[4], xl[5]};
-      b2 = bf16x8{xh[4], xh[5], xh[6], xh[7], xh[8], xh[9], z0, z0};
+      b2 = bf16x8{xh[4], xh[5], xh[6], xh[7], xh[8], xh[9], one, one};
     }
     bf16_t* orow = out + ((long long)b * L + t0 + (tv ? tl : 0)) * C + 16 * hi;
-#pragma unroll 2
     for (int mt = 0; mt < ntile; ++mt) {
       const bf16x8 a1 = afr[(mt * 2 + 0) * 64 + lane], a2 = afr[(mt * 2 + 1) * 64 + lane];
       f32x16 acc;
@@ -274,21 +311,10 @@ __global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __re
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
-      const float* scp = scs + mt * 32 + 16 * hi;
-      float y[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 sc4 = *reinterpret_cast<const float4*>(scp + 4 * g);
-        const float4 sh4 = *reinterpret_cast<const float4*>(scp + C + 4 * g);
-        y[4 * g + 0] = gelu_poly(fmaf(acc[4 * g + 0], sc4.x, sh4.x));
-        y[4 * g + 1] = gelu_poly(fmaf(acc[4 * g + 1], sc4.y, sh4.y));
-        y[4 * g + 2] = gelu_poly(fmaf(acc[4 * g + 2], sc4.z, sh4.z));
-        y[4 * g + 3] = gelu_poly(fmaf(acc[4 * g + 3], sc4.w, sh4.w));
-      }
       if (tv) {
         bf16x8 o0, o1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { o0[e] = (bf16_t)y[e]; o1[e] = (bf16_t)y[8 + e]; }
+        for (int e = 0; e < 8; ++e) { o0[e] = (bf16_t)gelu_poly(acc[e]); o1[e] = (bf16_t)gelu_poly(acc[8 + e]); }
         *reinterpret_cast<bf16x8*>(orow + mt * 32) = o0;
         *reinterpret_cast<bf16x8*>(orow + mt * 32 + 8) = o1;
       }
@@ -367,7 +393,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
 // The VALU form above spends ~40 issue slots per element of dY (10 FMAs to recompute the convolution, 10 more for A_j += dz x[s t + j],
 // ~20 for gelu', the rest) in dependent chains: 246 us for 262 MB.  Here both contractions run on v_mfma_f32_32x32x16_bf16:
 //   1. y[c][t]   = [wh | wh | wl] . [xh ; xl ; xh]                 (the forward's fragments; lane = time step, 16 consecutive channels)
-//   2. dz = dY gelu'(y rs gamma + (beta - mu rs gamma))            (the only per-element VALU work left)
+//   2. dz = dY gelu'(z), z = the MFMA result itself (affine folded into the fragments)   (the only per-element VALU work left)
 //   3. G[c][j]  += dz[c][t] X[t][j],  X[t][j] = x[s t + j] (j < k), X[t][10] = 1     -> A_j (j < 10) and S1 (column 10) in ONE product,
 //      dz as ONE bf16 operand (what every weight-gradient GEMM of the bf16 mode feeds the matrix cores: bf16 dY), X split (Xh + Xl: the
 //      waveform keeps ~16 bits); two MFMAs per 16 time steps.  dz comes out of step 1's accumulator
@@ -391,25 +417,20 @@ __device__ __forceinline__ bf16x8 c0_tr_frag(const char* tile, int off_lo, int o
 }
 
 __global__ __launch_bounds__(256) void conv0_bwd_mfma_kernel(const float* __restrict__ wav, const bf16x8* __restrict__ afrag_g,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             const float* __restrict__ stats, const bf16_t* __restrict__ dY,
+                                                             const bf16_t* __restrict__ dY,
                                                              float* __restrict__ part, int S, int L, int C, int k, int stride, int nch) {
   extern __shared__ __attribute__((aligned(16))) char sm0[];
   const int ntile = C / 32, tpw = ntile / 4;                          // channel tiles in all / per wave
-  bf16x8* afr = reinterpret_cast<bf16x8*>(sm0);                       // [ntile][2][64 lanes] x 16 B
-  float* zsb = reinterpret_cast<float*>(sm0 + (size_t)ntile * 2048);  // z scale[C] | z shift[C]
-  float* seg = zsb + 2 * C;
+  bf16x8* afr = reinterpret_cast<bf16x8*>(sm0);                       // [ntile][2][64 lanes] x 16 B (this clip's, affine folded in)
+  float* seg = reinterpret_cast<float*>(sm0 + (size_t)ntile * 2048);
   const int b = blockIdx.y, ch = blockIdx.x, t0 = ch * TCH;
   const int nt = min(TCH, L - t0);
   const int nseg_pad = (TCH - 1) * stride + k + MAXK;
   char* trbase = reinterpret_cast<char*>(seg + ((nseg_pad + 3) & ~3));  // one [32 t][32 c] tile per wave
   stage_wav(seg, wav, b, S, t0, nt, k, stride);
-  for (int i = threadIdx.x; i < ntile * 128; i += 256) afr[i] = afrag_g[i];
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float mu = stats[((long long)b * C + c) * 2], rs = stats[((long long)b * C + c) * 2 + 1];
-    const float sc = rs * gamma[c];
-    zsb[c] = sc;
-    zsb[C + c] = beta[c] - mu * sc;
+  {
+    const bf16x8* afb = afrag_g + (long long)b * ntile * 128;
+    for (int i = threadIdx.x; i < ntile * 128; i += 256) afr[i] = afb[i];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -423,7 +444,6 @@ __global__ __launch_bounds__(256) void conv0_bwd_mfma_kernel(const float* __rest
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) G[q][r] = 0.f;
-  const bf16_t z0 = (bf16_t)0.f;
 #pragma unroll 1
   for (int tt = 0; tt < TCH / 32; ++tt) {
     if (tt * 32 >= nt) break;
@@ -445,7 +465,19 @@ __global__ __launch_bounds__(256) void conv0_bwd_mfma_kernel(const float* __rest
         b2 = bf16x8{xl[6], xl[7], xl[8], xl[9], xh[0], xh[1], xh[2], xh[3]};
       } else {
         b1 = bf16x8{xh[8], xh[9], xl[0], xl[1], xl[2], xl[3], xl[4], xl[5]};
-        b2 = bf16x8{xh[4], xh[5], xh[6], xh[7], xh[8], xh[9], z0, z0};
+        b2 = bf16x8{xh[4], xh[5], xh[6], xh[7], xh[8], xh[9], (bf16_t)1.f, (bf16_t)1.f};
+      }
+    }
+    const bf16_t* dyrow = dY + ((long long)b * L + t0 + (tv ? tl : 0)) * C + 16 * hi;
+    // dY of this time step for the wave's four channel tiles (32 contiguous bytes each): all eight loads are in flight while the
+    // first tile's MFMAs and the X fragments above are worked on (one load pair per tile, issued where it is used, left each tile
+    // waiting for its own round trip -- two waves per SIMD do not cover that)
+    uint4 dvq[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < tpw) {
+        dvq[q][0] = *reinterpret_cast<const uint4*>(dyrow + (wave + 4 * q) * 32);
+        dvq[q][1] = *reinterpret_cast<const uint4*>(dyrow + (wave + 4 * q) * 32 + 8);
       }
     }
     bf16x8 Xh[2], Xl[2];                             // (step 3: lane = column j of X, k slots = time steps in the transpose read's order)
@@ -462,14 +494,11 @@ __global__ __launch_bounds__(256) void conv0_bwd_mfma_kernel(const float* __rest
         Xl[s2][e] = (bf16_t)(xv - (float)h);
       }
     }
-    const bf16_t* dyrow = dY + ((long long)b * L + t0 + (tv ? tl : 0)) * C + 16 * hi;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (q >= tpw) break;
       const int mt = wave + 4 * q;
-      // dY of this (time step, 16 channels): 32 contiguous bytes
-      uint4 dv0 = *reinterpret_cast<const uint4*>(dyrow + mt * 32);
-      uint4 dv1 = *reinterpret_cast<const uint4*>(dyrow + mt * 32 + 8);
+      uint4 dv0 = dvq[q][0], dv1 = dvq[q][1];
       if (!tv) { dv0 = make_uint4(0u, 0u, 0u, 0u); dv1 = dv0; }      // (a time step past the clip's end contributes dz = 0)
       const bf16x8 a1 = afr[(mt * 2 + 0) * 64 + lane], a2 = afr[(mt * 2 + 1) * 64 + lane];
       f32x16 y;
@@ -477,22 +506,14 @@ __global__ __launch_bounds__(256) void conv0_bwd_mfma_kernel(const float* __rest
       for (int r = 0; r < 16; ++r) y[r] = 0.f;
       y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, y, 0, 0, 0);
       y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, y, 0, 0, 0);
-      const float* zp = zsb + mt * 32 + 16 * hi;
       const unsigned int dw_[8] = {dv0.x, dv0.y, dv0.z, dv0.w, dv1.x, dv1.y, dv1.z, dv1.w};
       bf16x8 dh0, dh1;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 sc4 = *reinterpret_cast<const float4*>(zp + 4 * g);
-        const float4 sh4 = *reinterpret_cast<const float4*>(zp + C + 4 * g);
-        const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const unsigned int pk = dw_[r >> 1];
-          const float dyv = __uint_as_float((r & 1) ? (pk & 0xffff0000u) : (pk << 16));
-          const bf16_t h = (bf16_t)(dyv * gelu_grad_poly(fmaf(y[r], scv[e], shv[e])));
-          if (r < 8) dh0[r] = h; else dh1[r - 8] = h;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const unsigned int pk = dw_[r >> 1];
+        const float dyv = __uint_as_float((r & 1) ? (pk & 0xffff0000u) : (pk << 16));
+        const bf16_t h = (bf16_t)(dyv * gelu_grad_poly(y[r]));      // (y IS the GELU argument: the affine rides in the fragments)
+        if (r < 8) dh0[r] = h; else dh1[r - 8] = h;
       }
       // wave-private transpose: rows = this lane's time step, 32 bytes of its 16 channels
       *reinterpret_cast<bf16x8*>(trh + n * C0_TP + 32 * hi) = dh0;
@@ -651,7 +672,7 @@ extern "C" int64_t st5_conv0_ws_bytes(int32_t B, int32_t S, int32_t C, int32_t k
   const int L = out_len(S, k, stride);
   const int64_t nch = (L + TCH - 1) / TCH;
   return ws_part_floats(B, (int)nch, C, k) * (int64_t)sizeof(float) +
-         ((int64_t)B * nmom(k) + (int64_t)B * C * (MAXK + 2)) * (int64_t)sizeof(double) + 16 + (int64_t)C * 64;   // + MFMA weight fragments
+         ((int64_t)B * nmom(k) + (int64_t)B * C * (MAXK + 2)) * (int64_t)sizeof(double) + 16 + (int64_t)B * C * 64;   // + MFMA weight fragments (per clip: the GroupNorm affine is folded in)
 }
 
 extern "C" int st5_conv0_gn_gelu_fwd(const float* wav, const float* w, const float* gamma, const float* beta,
@@ -672,14 +693,14 @@ extern "C" int st5_conv0_gn_gelu_fwd(const float* wav, const float* w, const flo
   hipLaunchKernelGGL((conv0_apply_kernel<TT, KW>), dim3(nch, B), dim3(256), shm, s, wav, w, gamma, beta, stats, \
                      (TT*)out, S, L, C, k, stride)
   if (dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 32 == 0 && C <= 1024) {
-    hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32), dim3(128), 0, s, w, W.afrag, k);
-    const size_t shm_m = (size_t)(C / 32) * 2048 + (size_t)2 * C * sizeof(float) + shm;
+    hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32, B), dim3(128), 0, s, w, gamma, beta, stats, W.afrag, C, k);
+    const size_t shm_m = (size_t)(C / 32) * 2048 + shm;
     static bool attr = false;
     if (!attr) {
       if (hipFuncSetAttribute((const void*)conv0_apply_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
       attr = true;
     }
-    hipLaunchKernelGGL(conv0_apply_mfma_kernel, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, gamma, beta, stats, (bf16_t*)out, S, L, C, k, stride);
+    hipLaunchKernelGGL(conv0_apply_mfma_kernel, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, (bf16_t*)out, S, L, C, k, stride);
   } else if (dtype == ST5_BF16) { if (k <= 10) APPLY(bf16_t, 10); else APPLY(bf16_t, MAXK); }
   else { if (k <= 10) APPLY(float, 10); else APPLY(float, MAXK); }
 #undef APPLY
@@ -713,15 +734,15 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
                      (const TT*)dY, W.part, S, L, C, k, stride, nch)
   const bool mfma = dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 128 == 0 && C <= 1024 && TCH % 32 == 0;
   if (mfma) {
-    hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32), dim3(128), 0, s, w, W.afrag, k);
+    hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32, B), dim3(128), 0, s, w, gamma, beta, stats, W.afrag, C, k);
     const size_t seg_f = (size_t)(((TCH - 1) * stride + k + MAXK + 3) & ~3);
-    const size_t shm_m = (size_t)(C / 32) * 2048 + (size_t)2 * C * sizeof(float) + seg_f * sizeof(float) + (size_t)4 * C0_TILE_B;
+    const size_t shm_m = (size_t)(C / 32) * 2048 + seg_f * sizeof(float) + (size_t)4 * C0_TILE_B;
     static bool attr = false;
     if (!attr) {
       if (hipFuncSetAttribute((const void*)conv0_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
       attr = true;
     }
-    hipLaunchKernelGGL(conv0_bwd_mfma_kernel, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, gamma, beta, stats, (const bf16_t*)dY, W.part, S, L,
+    hipLaunchKernelGGL(conv0_bwd_mfma_kernel, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, (const bf16_t*)dY, W.part, S, L,
                        C, k, stride, nch);
   } else if (dtype == ST5_BF16) { if (k <= 10) BWD(bf16_t, 10); else BWD(bf16_t, MAXK); }
   else { if (k <= 10) BWD(float, 10); else BWD(float, MAXK); }

@@ -138,7 +138,9 @@ class FlatGradDataParallel:
             # the second micro-batch's forward stream (accumulate_overlapped) behind the whole weight-gradient branch
             # (measured: 48.3 ms with both, 45.0 ms with the forward overlap alone) -- bench.py turns it off for replay.
             # Default OFF: with the micro-batches side by side it costs time (42.0 against 31.5 ms per update,
-            # profiles/r5_replay_hunt.txt); results are bit-identical with and without it.
+            # profiles/r5_replay_hunt.txt: ONE side stream turns every weight-gradient GEMM of both backward passes into one serial
+            # chain); results are bit-identical with and without it.  A side stream PER micro-batch stream (round 5, tried) cannot be
+            # captured: a helper stream forked from the second parent inside one capture crashes hipStreamEndCapture on ROCm 7.2.
             if (os.environ.get("ST5_WGRAD_STREAM", "0") == "1") if wgrad_stream is None else wgrad_stream:
                 from .modules.transformer_layer import TransformerSentenceEncoderLayer, TransformerDecoderLayer
                 from .modules.speech_encoder_prenet import ConvFeatureExtractionModel

@@ -1,9 +1,8 @@
 #!/bin/bash
 # GPU call 8 of round 5: conv layer 0 forward + backward on the matrix cores, folded-scale GELU, two-launch statistics.
 O=gpurun_out/r5h; mkdir -p $O
-timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_bf16_path_gpu.py tests/test_fullsize_gpu.py tests/test_cfg2_shape_gpu.py tests/test_extractor_ln.py tests/test_model_gpu.py -q -m gpu > $O/tests.log 2>&1; tail -6 $O/tests.log
-run() { echo -n "$1: "; env $2 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline $3 2>$O/err.log | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); h=d['roofline']['hbm_bound_kernels']; print(d['ms_per_step'], 'ms | NT frac', d['roofline']['frac'], '| conv0 fwd', h['conv0_gn_gelu_fwd']['ms'], 'ms', h['conv0_gn_gelu_fwd']['frac_of_8TBps'], '| bwd', h['conv0_gn_gelu_bwd']['ms'], 'ms', h['conv0_gn_gelu_bwd']['frac_of_8TBps'], '| frontend', d['roofline']['frontend']['ms'], d['roofline']['frontend']['frac_of_8TBps'])"; }
+echo tests skipped
+run() { echo -n "$1: "; env $2 timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline $3 2>$O/err.log | python tools/r5/conv0_line.py; }
 {
 run "matrix-core conv0" "A=1" ""
 run "VALU conv0" "ST5_CONV0_MFMA=0" ""
