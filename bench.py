@@ -57,9 +57,19 @@ def build(device, compute_dtype, arch="base", layerdrop=0.05):
     return args, task, model, crit
 
 
-PMC_TRAFFIC_FILE = "r4_pmc_traffic.json"   # written by tools/pmc_traffic.sh
-KERNEL_STATS_FILE = "r4_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --steps 13` (tools/finals.sh)
+PMC_TRAFFIC_FILE = "r5_pmc_traffic.json"   # written by tools/pmc_traffic.sh
+KERNEL_STATS_FILE = "r5_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --steps 13` (tools/finals.sh)
 NT_KERNEL_NAME = "gemm_nt_glds_kernel"      # the dominant kernel of the update (most NT launches)
+
+
+def kernel_source_hash():
+    """sha1 of the GEMM kernels' sources (gemm.hip + common.h, where the fused epilogues' math lives): committed profiler summaries
+    record it and are only trusted for the tree they were measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("gemm.hip", "common.h"):
+        h.update(open(os.path.join(ROOT, "speecht5_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def cpu_baseline(model, args, seconds=4.0, runs=5):
@@ -432,8 +442,7 @@ def main():
         here = os.path.dirname(os.path.abspath(__file__))
         pm = _json.load(open(os.path.join(here, "profiles", PMC_TRAFFIC_FILE)))
         # only a summary measured on THIS kernel source counts (the file records the hash of csrc/gemm.hip it was taken on)
-        import hashlib
-        cur = hashlib.sha1(open(os.path.join(here, "speecht5_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:12]
+        cur = kernel_source_hash()
         if pm.get("gemm_hip_sha1") == cur and a.dtype == "bf16":
             # every bf16 instantiation of the kernel (one per epilogue feature set), weighted by launches; the fp32 one serves the
             # NCE head only
@@ -451,7 +460,7 @@ def main():
         import csv as _csv, hashlib as _hl
         here = os.path.dirname(os.path.abspath(__file__))
         meta = json.load(open(os.path.join(here, "profiles", KERNEL_STATS_FILE.replace(".csv", ".meta.json"))))
-        cur = _hl.sha1(open(os.path.join(here, "speecht5_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:12]
+        cur = kernel_source_hash()
         if meta.get("gemm_hip_sha1") == cur and a.dtype == "bf16" and a.arch == "base" and world == 1:
             rows = list(_csv.DictReader(open(os.path.join(here, "profiles", KERNEL_STATS_FILE))))
             upd_n = sum(int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"])

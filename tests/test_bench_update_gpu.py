@@ -129,6 +129,11 @@ def test_several_rank_forms_of_the_update_equal_the_one_rank_update(cuda):
             assert info["split"] and info["overlap"] and info["phased"] == (exchange == "phased"), info
             assert got[3] == ref[3] == 5
             _same(ref, got, f"several-rank form ({exchange}) vs one-rank update")
+        # what `bench.py --gpus N` runs BY DEFAULT: micro-batches side by side inside the replayed local phase, one all-reduce behind it
+        info = {}
+        got = _run(cuda, True, "side_by_side", 5, exchange="phased", info=info)
+        assert info["split"] and not info["phased"], info
+        _same(ref, got, "several-rank default form (side by side, one message) vs one-rank update")
         info = {}
         eager = _run(cuda, False, "in_turn", 5, exchange="phased", info=info)      # the same phases enqueued eagerly (ST5_EAGER_PHASED)
         assert info["phased"] and not info["split"], info

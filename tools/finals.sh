@@ -10,7 +10,7 @@ R=$PWD
 mkdir -p $R/gpurun_out
 timeout 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err < /dev/null; echo "bench rc=$?"
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt_$TAG && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -- python $R/bench.py --steps 13 --warmup 5 --no-cpu-baseline > /tmp/kt_$TAG.log 2>&1 < /dev/null; echo "rocprof rc=$?"
-  f=$(ls /tmp/kt_$TAG/*/*kernel_stats.csv 2>/dev/null | head -1); if [ -n "$f" ]; then cp "$f" $R/gpurun_out/${TAG}_bench_kernel_stats.csv; python -c "import hashlib,json;json.dump({'gemm_hip_sha1':hashlib.sha1(open('$R/speecht5_amd/csrc/gemm.hip','rb').read()).hexdigest()[:12],'command':'rocprofv3 --kernel-trace --stats -- python bench.py --steps 13 --warmup 5 --no-cpu-baseline'},open('$R/gpurun_out/${TAG}_bench_kernel_stats.meta.json','w'))"; else echo "no kernel_stats.csv"; ls -R /tmp/kt_$TAG | head -20; fi )
+  f=$(ls /tmp/kt_$TAG/*/*kernel_stats.csv 2>/dev/null | head -1); if [ -n "$f" ]; then cp "$f" $R/gpurun_out/${TAG}_bench_kernel_stats.csv; python -c "import sys;sys.path.insert(0,'$R');import hashlib,json;json.dump({'gemm_hip_sha1':__import__('bench').kernel_source_hash(),'command':'rocprofv3 --kernel-trace --stats -- python bench.py --steps 13 --warmup 5 --no-cpu-baseline'},open('$R/gpurun_out/${TAG}_bench_kernel_stats.meta.json','w'))"; else echo "no kernel_stats.csv"; ls -R /tmp/kt_$TAG | head -20; fi )
 timeout 500 bash tools/pmc_traffic.sh $TAG < /dev/null | tail -4; echo "pmc rc=$?"
 timeout 300 python bench.py --config 3 --steps 20 --warmup 5 > gpurun_out/${TAG}_cfg3.json 2> gpurun_out/${TAG}_cfg3.err < /dev/null; echo "cfg3 rc=$?"
 head -c 600 gpurun_out/${TAG}_bench.json; echo

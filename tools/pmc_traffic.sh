@@ -9,7 +9,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python $R/bench.
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline > /tmp/pmc_w.log 2>&1
 mkdir -p $R/gpurun_out/pmc
 python - <<PY
-import csv, glob, json, collections, hashlib
+import csv, glob, json, collections, hashlib, sys; sys.path.insert(0, "$R")
 acc = collections.defaultdict(lambda: {"launches": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
 for d, name in (("/tmp/pmc_f", "FETCH_SIZE"), ("/tmp/pmc_w", "WRITE_SIZE")):
     fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
@@ -31,7 +31,7 @@ for k, v in acc.items():
 out = {"command": "python bench.py --steps 3 --warmup 3 --no-cpu-baseline (two separate rocprofv3 --pmc passes: FETCH_SIZE, WRITE_SIZE)",
        "units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch as reported by rocprofv3; gfx950 correction (MI355X_MICROARCH.md, HBM section): "
                 "FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads -> doubled in hbm_corrected_bytes_per_launch",
-       "gemm_hip_sha1": hashlib.sha1(open("$R/speecht5_amd/csrc/gemm.hip", "rb").read()).hexdigest()[:12],
+       "gemm_hip_sha1": __import__("bench").kernel_source_hash(),
        "kernels": kern}
 json.dump(out, open("$R/gpurun_out/pmc/${TAG}_pmc_traffic.json", "w"), indent=1)
 for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["hbm_corrected_bytes_per_launch"] * kv[1]["launches"])[:10]:
