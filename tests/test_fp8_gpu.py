@@ -193,3 +193,88 @@ def test_large_update_in_fp8_mode_stays_close_to_bf16_mode(cuda):
     assert rest[0][0] >= 0.95, rest[:5]
     assert not post or post[0][0] >= 0.90, post[:5]
     assert num / den >= 0.99
+
+
+def test_large_fp8_mode_against_the_oracle(cuda):
+    """the fp8 compute mode was only ever compared with the bf16 mode.  Here the FULL t5_transformer_large
+    architecture (24 + 6 layers, d = 1024, FFN 4096, pre-LN, layer-norm extractor: models/speecht5.py:1402-1425) runs one
+    speech-pretraining forward + backward on 2 x 2 s with the forward / data-gradient GEMMs of its Linears on the MX-fp8 kernel, dropout
+    off and every random draw injected, against the fp32 CPU ORACLE on the same weights and draws: loss within 5e-2, norm-weighted mean
+    gradient cosine >= 0.99 (the bars VERDICT r3 item 7 / r4 item 6 state), every matrix gradient outside the mel post-net >= 0.95."""
+    from argparse import Namespace
+    from types import SimpleNamespace
+    from oracle import speecht5_oracle as O
+    from speecht5_amd import functional as Fn
+    from speecht5_amd.criterions import SpeechPretrainCriterion
+    from speecht5_amd.speecht5 import t5_transformer_large
+    from speecht5_amd.synthetic import speech_pretrain_sample
+    from speecht5_amd.task import SpeechT5Task
+    from tests.util import injected_randomness, to_dev
+    old_rows = Fn._FP8.min_rows
+    try:
+        Fn.set_compute_dtype(torch.bfloat16)
+        Fn.set_fp8(True)
+        Fn._FP8.min_rows, Fn._FP8.launches = 64, 0
+        args = Namespace(label_rates=50, sample_rate=16000, speech_odim=80, bert_init=True, use_codebook=True,
+                         share_input_output_embed=True, encoder_layerdrop=0.0, decoder_layerdrop=0.0)
+        t5_transformer_large(args)
+        for k, v in list(vars(args).items()):
+            if "dropout" in k and isinstance(v, float):
+                setattr(args, k, 0.0)
+        args.encoder_layerdrop = args.decoder_layerdrop = 0.0
+        task = SpeechT5Task.synthetic(args)
+        torch.manual_seed(4243)
+        model = task.build_model(args).to(cuda).train()
+        sample = speech_pretrain_sample(B=2, seconds=2.0, device="cpu", seed=11)
+        T = int(2.0 * 50) - 1
+        mask = torch.zeros(2, T, dtype=torch.bool)
+        mask[0, 10:70] = True
+        mask[1, 25:85] = True
+        mix_idx = torch.arange(0, T, 2)[: int(T * getattr(args, "codebook_prob", 0.5))]
+        noise = torch.zeros(1)
+        crit = SpeechPretrainCriterion(task, False, 1.0, 0.0, loss_weights=[10, 0.1], sync_logging=False)
+        with injected_randomness(model, mask, mix_idx, noise, 2.0):
+            loss, ss, _ = crit(model, to_dev(sample, cuda))
+        (loss / ss).backward()
+        torch.cuda.synchronize()
+        assert Fn._FP8.launches >= 200, Fn._FP8.launches            # the fp8 kernel really ran (8 GEMMs per layer x 30 layers)
+        got = {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+        cfg = SimpleNamespace(**vars(args))
+        ref = O.forward_speech_pretrain(sd, cfg, sample, mask_indices=mask, mix_idx=mix_idx, gumbel_noise=noise)
+        rl, rs, _ = O.speech_pretrain_loss(ref, sample, cfg, loss_weights=(10, 0.1))
+        (rl / rs).backward()
+        assert ss == rs
+        lv, rv = float(loss.detach()), float(rl.detach())
+        assert abs(lv - rv) <= 5e-2 * abs(rv), (lv, rv)
+        rnorm = sum(float(v.grad.double().pow(2).sum()) for v in sd.values() if v.requires_grad and v.grad is not None) ** 0.5
+        num = den = 0.0
+        worst = []
+        for n, g in got.items():
+            if n not in sd or sd[n].grad is None:
+                continue
+            r = sd[n].grad.double()
+            if float(r.norm()) <= 1e-5 * rnorm or n == "quantizer.vars":      # (structurally ~zero; the one discontinuous gradient)
+                continue
+            cos = float((g * r).sum() / (g.norm() * r.norm()).clamp_min(1e-30))
+            w = float(r.norm())
+            num += cos * w
+            den += w
+            if g.dim() >= 2:
+                worst.append((cos, n))
+        worst.sort()
+        print("fp8 mode vs the fp32 oracle: norm-weighted mean gradient cosine", num / den, "worst matrices", worst[:6])
+        assert num / den >= 0.99, num / den
+        # measured on MI355X: 0.9908 weighted; every matrix outside the mel post-net >= 0.97; the post-net's convolutions 0.83-0.93 --
+        # BatchNorm's backward removes the per-channel mean of a nearly constant incoming gradient, so what survives is a few % of what
+        # the rounded operands carried (tests/test_fullsize_gpu.py: 0.98 already in bf16 mode; tests/util.py BF16_POST_COS)
+        rest = [w for w in worst if "speech_decoder_postnet.postnet" not in w[1]]
+        post = [w for w in worst if "speech_decoder_postnet.postnet" in w[1]]
+        assert rest[0][0] >= 0.95, rest[:6]
+        assert not post or post[0][0] >= 0.8, post[:6]
+    finally:
+        Fn.set_fp8(False)
+        Fn._FP8.min_rows = old_rows
+        Fn.bf16_mirror.__init__()
+        Fn.weight_cache.clear()
+        Fn.set_compute_dtype(torch.float32)
