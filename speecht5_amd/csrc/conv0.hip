@@ -416,7 +416,13 @@ __device__ __forceinline__ bf16x8 c0_tr_frag(const char* tile, int off_lo, int o
   return u.v;
 }
 
-__global__ __launch_bounds__(256) void conv0_bwd_mfma_kernel(const float* __restrict__ wav, const bf16x8* __restrict__ afrag_g,
+#ifndef C0_BWD_OCC
+#define C0_BWD_OCC 2      // waves per SIMD the backward kernel is compiled for (measured: 3 = 168 registers + 17-27 spilled dwords: 164-177 us against 120)
+#endif
+#ifndef C0_BWD_PREFETCH
+#define C0_BWD_PREFETCH 4 // channel tiles whose dY loads are issued ahead (4 = the whole time step's)
+#endif
+__global__ __launch_bounds__(256, C0_BWD_OCC) void conv0_bwd_mfma_kernel(const float* __restrict__ wav, const bf16x8* __restrict__ afrag_g,
                                                              const bf16_t* __restrict__ dY,
                                                              float* __restrict__ part, int S, int L, int C, int k, int stride, int nch) {
   extern __shared__ __attribute__((aligned(16))) char sm0[];
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_mfma_kernel(const float* __rest
     // waiting for its own round trip -- two waves per SIMD do not cover that)
     uint4 dvq[4][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < C0_BWD_PREFETCH; ++q) {
       if (q < tpw) {
         dvq[q][0] = *reinterpret_cast<const uint4*>(dyrow + (wave + 4 * q) * 32);
         dvq[q][1] = *reinterpret_cast<const uint4*>(dyrow + (wave + 4 * q) * 32 + 8);
@@ -498,6 +504,13 @@ __global__ __launch_bounds__(256) void conv0_bwd_mfma_kernel(const float* __rest
     for (int q = 0; q < 4; ++q) {
       if (q >= tpw) break;
       const int mt = wave + 4 * q;
+      if (C0_BWD_PREFETCH < 4 && q + C0_BWD_PREFETCH < 4 && q + C0_BWD_PREFETCH < tpw && (q % C0_BWD_PREFETCH) == 0) {
+#pragma unroll
+        for (int u = 0; u < C0_BWD_PREFETCH; ++u) {      // (the next group of tiles, while this group is worked on)
+          dvq[q + C0_BWD_PREFETCH + u][0] = *reinterpret_cast<const uint4*>(dyrow + (wave + 4 * (q + C0_BWD_PREFETCH + u)) * 32);
+          dvq[q + C0_BWD_PREFETCH + u][1] = *reinterpret_cast<const uint4*>(dyrow + (wave + 4 * (q + C0_BWD_PREFETCH + u)) * 32 + 8);
+        }
+      }
       uint4 dv0 = dvq[q][0], dv1 = dvq[q][1];
       if (!tv) { dv0 = make_uint4(0u, 0u, 0u, 0u); dv1 = dv0; }      // (a time step past the clip's end contributes dz = 0)
       const bf16x8 a1 = afr[(mt * 2 + 0) * 64 + lane], a2 = afr[(mt * 2 + 1) * 64 + lane];
