@@ -277,19 +277,25 @@ class FlatGradDataParallel:
             self._make_flat2()
         for st in self._fwd_streams[: n - 1]:
             st.wait_stream(cur)          # every forward starts from here (what precedes: zero_grad, the previous update)
+        # Which micro-batch owns the update's own stream (`cur`)?  Default: the first.  ST5_SBS_OWNER=1 (A/B) gives it to the SECOND
+        # (host enqueue order, gradient buffers and random draws unchanged -- only the stream assignment swaps), and with a
+        # weight-gradient stream (ST5_WGRAD_STREAM=1) that micro-batch's weight-gradient GEMMs fork to it: a third concurrent chain
+        # forked from the capture's FIRST parent, the only kind ROCm 7.2 captures.
+        own = int(os.environ.get("ST5_SBS_OWNER", "0")) if (n == 2 and backward == "side_by_side") else 0
+        stream_of = (lambda i: cur if i == own else self._fwd_streams[0]) if n == 2 else (lambda i: cur)
+        if Fn.wgrad_stream() is not None and n == 2:
+            Fn.set_wgrad_owner(cur)
         losses = []
         for i, mb in enumerate(micro_batches):
-            if i == 0:
+            with torch.cuda.stream(stream_of(i)):
                 losses.append(forward_loss(mb))
-            else:
-                with torch.cuda.stream(self._fwd_streams[i - 1]):
-                    losses.append(forward_loss(mb))
         for i, loss in enumerate(losses):
-            st = cur if i == 0 else self._fwd_streams[i - 1]
+            st = stream_of(i)
             if i > 0 and backward == "in_turn":
                 st.wait_stream(cur)      # (behind micro-batch 0's backward)
             with self._grad_slot(i), torch.cuda.stream(st):
                 loss.backward()          # (root gradient on `st`: no dependence on the other micro-batch's stream)
+                Fn.join_wgrad_stream()   # (no-op unless this stream owns a weight-gradient stream: its slabs folded there, then joined)
                 # this stream's deferred reductions (split-K slabs, LayerNorm partials) are folded on this stream
                 hip.check(hip.lib().st5_layernorm_flush(hip.stream()), "st5_layernorm_flush")
                 hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")

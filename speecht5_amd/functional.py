@@ -626,7 +626,7 @@ def wgrad_stream():
 
 def join_wgrad_stream():
     """The current stream waits for every weight-gradient GEMM issued so far (and their batched split-K reduction)."""
-    if _S.side is None:
+    if not _side_here():
         return
     L = hip.lib()
     hip.check(L.st5_gemm_flush_splitk(_S.side_raw), "st5_gemm_flush_splitk")
@@ -652,12 +652,27 @@ def _side_hold(keep):
             _S.side_gens.pop(0)
 
 
+def _side_here():
+    """Does the weight-gradient stream serve the CURRENT stream?  With an owner set (set_wgrad_owner) only work issued on the owner
+    stream forks to it -- the micro-batches side by side: the one on the update's own stream; a helper stream forked from the second
+    micro-batch's stream cannot be captured on ROCm 7.2."""
+    if _S.side is None:
+        return False
+    owner = _S.__dict__.get("side_owner")
+    return owner is None or hip.stream() == owner
+
+
+def set_wgrad_owner(stream):
+    """Restrict the weight-gradient stream to work issued on `stream` (None: whoever issues weight-gradient GEMMs)."""
+    _S.__dict__["side_owner"] = stream.cuda_stream if stream is not None else None
+
+
 def _wgrad_gemm(params, A, B, C, M, N, K, dt, asum, keep):
     """C[M,N] += A^T B (fp32, both operands k-strided), bias-gradient column into `asum`.  `keep`: the tensors the GEMM
     reads -- held until the next join so that the caching allocator cannot hand their memory to a main-stream kernel
     while the side stream still reads them."""
     flags = hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32
-    if _S.side is None:
+    if not _side_here():
         hip.gemm(A, B, C, M, N, K, dt, flags=flags | hip.DEFERRABLE, beta=1.0, asum=asum)
         return
     for q in params:
@@ -677,7 +692,7 @@ def _conv_wgrad(w, opA, opB, Cout, k, Cin, Kred, dt, keep):
         tmpw = torch.empty(Cout, k * Cin, dtype=torch.float32, device=w.device)
         hip.gemm(opA, opB, hip.operand(tmpw, k * Cin), Cout, k * Cin, Kred, dt, flags=hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32)
         _gather3(tmpw, grad_buffer(w), (Cout, Cin, k), (k * Cin, 1, Cin), accumulate=True)   # grad[co, ci, j] += tmpw[co, j, ci]
-    if _S.side is not None and getattr(w, "_st5_side_ok", False):
+    if _side_here() and getattr(w, "_st5_side_ok", False):
         hip.check(hip.lib().st5_stream_fork(hip.stream(), _S.side_raw), "st5_stream_fork")
         with torch.cuda.stream(_S.side):
             run()
