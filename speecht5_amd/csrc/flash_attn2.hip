@@ -171,8 +171,13 @@ __global__ __launch_bounds__(256) void qp_table_kernel(const bf16_t* __restrict_
     qf[ks] = *reinterpret_cast<const bf16x8*>(qg + ((long long)b * T + qc) * q_ld + h * HD + ks * 16 + hi * 8);
   bf16_t* row = qp + ((long long)bh * T + qc) * nbp + QP_PAD;
   const int nbt = (nb + 31) / 32;
+  // The PE rows go into the MFMA's A operand PERMUTED (row m of the tile = bucket 16 ((m >> 2) & 1) + (m & 3) + 4 (m >> 3) of it), so
+  // that accumulator register r of lane (query, hi) is bucket 32 bt + 16 hi + r: 16 CONSECUTIVE buckets = two 16-byte stores per lane
+  // and tile (round 5; the natural order gave every lane groups of 4 buckets = 8-byte pieces 672 bytes apart, 2.4 TB/s of writes).
+  // Every table entry is the same dot product in the same k order as before: bit-identical.
+  const int prow = 16 * ((ql >> 2) & 1) + (ql & 3) + 4 * (ql >> 3);
   for (int bt = 0; bt < nbt; ++bt) {
-    int brow = bt * 32 + ql;
+    int brow = bt * 32 + prow;
     brow = brow < nb ? brow : nb - 1;
     f32x16 acc;
 #pragma unroll
@@ -183,23 +188,21 @@ __global__ __launch_bounds__(256) void qp_table_kernel(const bf16_t* __restrict_
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qf[ks], acc, 0, 0, 0);
     }
     if (qi < T) {
+      const int b0 = bt * 32 + 16 * hi;          // first bucket of this lane's 16
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int b0 = bt * 32 + 8 * g + 4 * hi;
-        if (b0 < nb) {
-          bf16x4 w;
+      for (int u = 0; u < 2; ++u) {
+        if (b0 + 8 * u < nb) {                   // (nb % 8 == 0: an 8-bucket chunk is inside the table or outside it)
+          bf16x8 w;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(acc[4 * g + e] * sc2);
-          *reinterpret_cast<bf16x4*>(row + b0) = w;
-          if (b0 == 0) {          // bucket 0 = element 0 of this group: low end replica
-            bf16x4 lo = {w[0], w[0], w[0], w[0]};
-            *reinterpret_cast<bf16x4*>(row - 8) = lo;
-            *reinterpret_cast<bf16x4*>(row - 4) = lo;
+          for (int e = 0; e < 8; ++e) w[e] = (bf16_t)(acc[8 * u + e] * sc2);
+          *reinterpret_cast<bf16x8*>(row + b0 + 8 * u) = w;
+          if (b0 + 8 * u == 0) {                 // bucket 0: low end replica
+            const bf16x8 lo = {w[0], w[0], w[0], w[0], w[0], w[0], w[0], w[0]};
+            *reinterpret_cast<bf16x8*>(row - 8) = lo;
           }
-          if (b0 + 4 == nb) {     // bucket nb-1 = element 3 of this group: high end replica
-            bf16x4 hv = {w[3], w[3], w[3], w[3]};
-            *reinterpret_cast<bf16x4*>(row + nb) = hv;
-            *reinterpret_cast<bf16x4*>(row + nb + 4) = hv;
+          if (b0 + 8 * u + 8 == nb) {            // bucket nb - 1: high end replica
+            const bf16x8 hv = {w[7], w[7], w[7], w[7], w[7], w[7], w[7], w[7]};
+            *reinterpret_cast<bf16x8*>(row + nb) = hv;
           }
         }
       }
