@@ -187,7 +187,7 @@ def box_info():
 
 
 def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, graph=True, micro="side_by_side", layerdrop=0.05,
-                wgrad_stream=None, prefetch_host=True, text_batch=16, text_len=512, seconds=10.0, exchange="phased"):
+                wgrad_stream=None, prefetch_host=True, text_batch=16, text_len=512, seconds=10.0, exchange="phased", exchange_payload="fp32"):
     """The update bench.py times, as an object (speecht5_amd/update.py): model, criterion, the two synthetic micro-batches of
     BASELINE.json cfg 2, FlatGradDataParallel + FusedAdam with the recipe's hyper-parameters.  tests/test_bench_update_gpu.py
     builds its runs from this function too."""
@@ -204,7 +204,8 @@ def make_update(device, dtype=torch.bfloat16, arch="base", batch=8, rank=0, grap
     text = text_pretrain_sample(B=text_batch, T=text_len, vocab=vocab, mask_idx=task.dicts["text"].index("<mask>"), device=device, seed=2337 + rank)
     batches = [text, speech] if os.environ.get("ST5_TEXT_FIRST") == "1" else [speech, text]    # (A/B: which micro-batch owns the first stream)
     upd = PretrainUpdate(task, model, crit, batches, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0,
-                         graph=graph, micro=micro, wgrad_stream=wgrad_stream, prefetch_host=prefetch_host, device=device, exchange=exchange)
+                         graph=graph, micro=micro, wgrad_stream=wgrad_stream, prefetch_host=prefetch_host, device=device, exchange=exchange,
+                         exchange_payload=exchange_payload)
     return args, task, model, upd
 
 
@@ -290,6 +291,9 @@ def main():
     ap.add_argument("--exchange", default="phased", choices=["phased", "one_message"],
                     help="several ranks, graph replay: phased = the local phase as 3 graphs, each completed bucket range all-reduced "
                          "under the next graph; one_message = one graph, then one all-reduce of the whole gradient buffer")
+    ap.add_argument("--exchange-payload", default="fp32", choices=["fp32", "bf16"],
+                    help="several ranks, one-message exchange: what travels -- the fp32 gradient buffer (default, exact) or its bf16 rounding "
+                         "(half the link bytes; local sums and Adam's moments stay fp32)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3],
                     help="BASELINE.json configs[]: 2 = the pre-training update (the headline metric, default); 3 = TTS fine-tuning step "
                          "(32 texts x 100 tokens -> 600 mel frames, guided attention, replayed) + full-size HiFi-GAN on the same "
@@ -354,7 +358,8 @@ def main():
     wgrad_env = os.environ.get("ST5_WGRAD_STREAM")
     args, task, model, upd = make_update(device, dtype, a.arch, a.batch, rank, graph=use_graph, micro=micro_mode, layerdrop=a.layerdrop,
                                          wgrad_stream=(wgrad_env == "1") if wgrad_env is not None else None,
-                                         prefetch_host=os.environ.get("ST5_PREFETCH_HOST", "1") == "1", exchange=a.exchange)
+                                         prefetch_host=os.environ.get("ST5_PREFETCH_HOST", "1") == "1", exchange=a.exchange,
+                                         exchange_payload=a.exchange_payload)
     split_update = upd.split
 
     def barrier():
@@ -549,9 +554,13 @@ def main():
         # the RCCL algorithm in force, and the time of the replayed local phase alone (ms_per_step minus it = exposed exchange + Adam)
         if split_update or world > 1:
             msgs = upd.ddp.exchange_plan(phased=bool(getattr(upd, "phased", False)), cuts=upd.cut_buckets() if getattr(upd, "phased", False) else None)
+            if a.exchange_payload == "bf16" and split_update and not getattr(upd, "phased", False):
+                msgs = [m // 2 for m in msgs]
             out["config"]["exchange"] = {"form": "phased" if getattr(upd, "phased", False) else ("one_message" if split_update else "bucketed, overlapped with an eager backward"),
                                          "backend": dist.get_backend() if dist.is_initialized() else None,
-                                         "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "payload": "fp32 gradients, sum; mean over ranks and micro-batches inside Adam",
+                                         "NCCL_ALGO": os.environ.get("NCCL_ALGO"),
+                                         "payload": ("bf16 rounding of the fp32 gradient sum" if (a.exchange_payload == "bf16" and split_update and not getattr(upd, "phased", False))
+                                                     else "fp32 gradients") + ", sum; mean over ranks and micro-batches inside Adam",
                                          "message_bytes": msgs, "local_phase_ms": local_ms}
         out["config"]["box"] = box_info()
         if shared:

@@ -410,7 +410,7 @@ class FlatGradDataParallel:
             w.wait()
         self._reset_round()
 
-    def all_reduce_gradients(self, average=True):
+    def all_reduce_gradients(self, average=True, payload=None):
         """The exchange step after a local_phase(): ONE all-reduce over the whole flat buffer (same call on every rank, so
         the order question of the bucketed path does not arise; 617 MB for Base: a single large message is what the xGMI
         links move fastest).  No overlap with the backward -- the price of replaying the backward as a graph, which saves more
@@ -424,7 +424,20 @@ class FlatGradDataParallel:
             # CURRENT stream and leaves its completion event there; when that stream later begins a graph capture, the group's
             # watchdog thread polls the event ("operation not permitted on an event last recorded in a capturing stream") and
             # takes the process down (measured: bench.py --exchange one_message, 1-rank RCCL group)
-            dist.all_reduce(self.flat, group=self.pg, async_op=True).wait()
+            if payload == torch.bfloat16 and self.flat.is_cuda:
+                # bf16 gradient payload: half the bytes on the links -- 309 instead of 617 MB for Base.  The local
+                # sum of the micro-batches stays fp32; it is rounded ONCE to bf16, summed over the ranks in bf16 by the collective and
+                # widened again, and Adam accumulates its moments in fp32 as before.  An option (PretrainUpdate(exchange_payload=)):
+                # the default exchange is exact fp32.
+                from . import hip
+                n = self.flat.numel()
+                if getattr(self, "_flat_bf16", None) is None:
+                    self._flat_bf16 = torch.empty(n, dtype=torch.bfloat16, device=self.flat.device)
+                hip.check(hip.lib().st5_cast_from_f32(self.flat.data_ptr(), self._flat_bf16.data_ptr(), 1, n, 0, hip.BF16, hip.stream()), "st5_cast_from_f32")
+                dist.all_reduce(self._flat_bf16, group=self.pg, async_op=True).wait()
+                hip.check(hip.lib().st5_cast_to_f32(self._flat_bf16.data_ptr(), self.flat.data_ptr(), n, hip.BF16, hip.stream()), "st5_cast_to_f32")
+            else:
+                dist.all_reduce(self.flat, group=self.pg, async_op=True).wait()
             if average and self.world > 1:
                 self.flat.mul_(1.0 / self.world)
         self._reset_round()

@@ -31,7 +31,7 @@ from . import functional as Fn
 
 class PretrainUpdate:
     def __init__(self, task, model, criterion, micro_batches, *, lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, clip_norm=5.0,
-                 graph=True, micro="side_by_side", wgrad_stream=None, prefetch_host=True, device=None, lr_fn=None, exchange="phased"):
+                 graph=True, micro="side_by_side", wgrad_stream=None, prefetch_host=True, device=None, lr_fn=None, exchange="phased", exchange_payload="fp32"):
         from .ddp import FlatGradDataParallel, FusedAdam
         assert micro in ("side_by_side", "in_turn_2buf", "in_turn")
         self.task, self.model, self.crit, self.micro = task, model, criterion, list(micro_batches)
@@ -47,6 +47,9 @@ class PretrainUpdate:
         self.opt = FusedAdam(self.ddp, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_norm=clip_norm)
         self.lr_fn = lr_fn
         self.prefetch_host = prefetch_host
+        assert exchange_payload in ("fp32", "bf16")
+        # several ranks, one-message exchange: the gradient buffer travels as bf16 (half the link bytes; local sums and Adam stay fp32)
+        self.exchange_payload = torch.bfloat16 if exchange_payload == "bf16" else None
         # several ranks + graph: graph = local phase, eager tail = all-reduce + Adam
         self.split = graph and self.ddp.collectives
         # several ranks + graph + one stream: the exchange is OVERLAPPED with the last micro-batch's backward -- the local phase
@@ -157,7 +160,7 @@ class PretrainUpdate:
 
     def exchange_and_update(self):
         """(several ranks, graph) eager tail: sum over ranks, then mean over ranks and micro-batches inside Adam."""
-        self.ddp.all_reduce_gradients(average=False)
+        self.ddp.all_reduce_gradients(average=False, payload=self.exchange_payload)
         self.opt.step(grad_scale=1.0 / (len(self.micro) * self.world))
 
     def step(self):

@@ -75,3 +75,21 @@ def test_two_ranks_with_their_own_data_exchange_exactly_the_sum_of_their_gradien
             got = torch.load(f"{out}.rank{k}.grad.pt")
             assert torch.equal(got, want), (f"{exchange}, rank {k}: exchanged buffer != g0 + g1 "
                                             f"({int((got != want).sum())} of {got.numel()} sampled elements differ)")
+
+
+def test_two_ranks_bf16_gradient_payload_stays_close_to_the_exact_exchange(cuda, tmp_path):
+    """`exchange_payload="bf16"`: the one-message exchange carries the bf16 rounding of the fp32 gradient sum.  Both
+    ranks hold the same data, so the collective's bf16 sum 2 x bf16(g) is exact and the only difference to the fp32 exchange is ONE
+    rounding of every gradient element (relative 2^-9): both ranks must agree bit for bit with each other, and after 4 updates the
+    sampled parameters must differ from the exact-exchange run's by at most 5 % of the distance the 4 updates moved them."""
+    exact = _launch(2, "one_message", str(tmp_path / "exact"), 29661, extra=["--micro", "side_by_side"])
+    half = _launch(2, "one_message", str(tmp_path / "half"), 29662, extra=["--micro", "side_by_side", "--payload", "bf16"])
+    assert half[0]["digest"] == half[1]["digest"] and all(r["finite"] and r["t"] == 4 for r in half)
+    assert half[0]["digest"] != exact[0]["digest"], "the bf16 payload changed nothing: was it used?"
+    import torch
+    e = torch.load(str(tmp_path / "exact") + ".rank0.params.pt")
+    h = torch.load(str(tmp_path / "half") + ".rank0.params.pt")
+    assert torch.equal(e["p0"], h["p0"])
+    moved = float((e["p"].double() - e["p0"].double()).norm())
+    rel = float((e["p"].double() - h["p"].double()).norm()) / moved
+    assert 0 < rel <= 0.05, rel       # 4 Adam steps by gradients that differ in their 9th bit (and what that flips downstream)

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--micro", default="in_turn")
+    ap.add_argument("--payload", default="fp32")
     ap.add_argument("--own-data", action="store_true")
     ap.add_argument("--data-rank", type=int, default=None, help="one-rank reference run over rank R's data and seeds")
     a = ap.parse_args()
@@ -41,9 +42,10 @@ def main():
     # small cfg-2-shaped update: Base, speech 2 x 4 s + text 4 x 128 (every rank: rank 0's data and seeds)
     drank = a.data_rank if a.data_rank is not None else (rank if a.own_data else 0)
     _, _, model, upd = bench.make_update(dev, torch.bfloat16, "base", 2, drank, graph=not a.no_graph, micro=a.micro, layerdrop=0.05,
-                                         text_batch=4, text_len=128, seconds=4.0, exchange=a.exchange)
+                                         text_batch=4, text_len=128, seconds=4.0, exchange=a.exchange, exchange_payload=a.payload)
     info = {"rank": rank, "world": world, "phased": bool(upd.phased), "split": bool(upd.split), "data_rank": drank}
     grads = []
+    p0 = upd.state()[0][::61].float().cpu()
     if a.own_data or a.data_rank is not None:
         upd.opt.lr = 0.0                      # parameters stay put: every update's gradient is a function of (data, seeds) only
         upd.opt.clip = 0.0
@@ -68,6 +70,7 @@ def main():
     for x in (p, m, v):
         h.update(x.cpu().numpy().tobytes())
     info.update(digest=h.hexdigest(), t=int(t), pnorm=float(p.double().norm()), finite=bool(torch.isfinite(p).all()))
+    torch.save({"p": p[::61].float().cpu(), "p0": p0}, f"{a.out}.rank{rank}.params.pt")
     if grads:
         info["grad_calls"] = len(grads)
         torch.save(grads[-1].cpu(), f"{a.out}.rank{rank}.grad.pt")
