@@ -146,6 +146,15 @@ int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
 /* Batched dgamma / dbeta reductions: while enabled, st5_layernorm_bwd leaves its block partials in an internal arena and
  * st5_layernorm_flush(stream) folds all pending LayerNorms' partials into their dgamma / dbeta with ONE launch (same stream
  * as the st5_layernorm_bwd calls; the owner of the gradient buffers flushes wherever gradients must be complete). */
+/* The LayerDrop gate folded into a post-LN layer's LAST LayerNorm (modules/encoder.py:251-257, modules/decoder.py:64-67 inside a
+ * replayed step, see st5_select): forward  y = *keep ? LN(x) * gamma + beta : skip  (skip = the layer's input, same shape and dtype);
+ * backward  as st5_layernorm_bwd with dy counted as zero when *keep == 0 (dx = 0, nothing added to dgamma / dbeta).  The gradient
+ * of the layer's OUTPUT then reaches the layer's input through st5_skip_grad.  keep = one float in device memory; cols % 4 == 0. */
+int st5_layernorm_gated_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
+                            int32_t cols, float eps, const float* keep, const void* skip, int dtype, void* stream);
+int st5_layernorm_gated_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                            float* dgamma, float* dbeta, void* ws, int64_t rows, int32_t cols, void* dx_dropped, float drop_p,
+                            uint64_t drop_seed, const float* keep, int dtype, void* stream);
 int st5_layernorm_defer(int enabled, void* stream);
 int st5_layernorm_flush(void* stream);
 int64_t st5_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols);
@@ -249,6 +258,9 @@ int st5_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, vo
  * written from the host draw before the replay; backward (ga, gb) = keep ? (0, g) : (g, 0).  Raw 16-byte chunks, any dtype. */
 int st5_select(const float* keep_dev, const void* a, const void* b, void* y, int64_t nbytes, void* stream);
 int st5_select_bwd(const float* keep_dev, const void* g, void* ga, void* gb, int64_t nbytes, void* stream);
+/* dx = *keep ? dx : g  in place (raw 16-byte chunks): the input gradient of a gated layer (st5_layernorm_gated_fwd) -- a kept layer's
+ * own input gradient stands, a dropped layer's (exact zeros) is replaced by the gradient of its output. */
+int st5_skip_grad(const float* keep_dev, const void* g, void* dx, int64_t nbytes, void* stream);
 /* y = act(x) ; dx = dy * act'(x) */
 int st5_act_fwd(const void* x, void* y, int64_t n, int32_t act, int dtype, void* stream);
 int st5_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int32_t act, int dtype, void* stream);

@@ -112,6 +112,14 @@ __global__ __launch_bounds__(256) void select_bwd_kernel(const float* __restrict
     gb[i] = k ? v : z;
   }
 }
+// The LayerDrop gate's backward at the layer input (functional.LayerDropEnterFunction): dx = keep ? dx : g, in place.  A kept layer
+// (19 of 20) costs one scalar load per wave and no traffic; a dropped layer's input gradient (exact zeros everywhere, its last
+// LayerNorm's backward was gated) is replaced by the gradient of the layer's OUTPUT.
+__global__ __launch_bounds__(256) void skip_grad_kernel(const float* __restrict__ keep, const u32x4* __restrict__ g, u32x4* __restrict__ dx,
+                                                        long long nv) {
+  if (keep[0] != 0.f) return;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) dx[i] = g[i];
+}
 
 // ---- sum of squares ----
 template <typename T>
@@ -690,6 +698,15 @@ extern "C" int st5_select_bwd(const float* keep_dev, const void* g, void* ga, vo
   if (nbytes == 0) return ST5_OK;
   hipLaunchKernelGGL(select_bwd_kernel, grid_for(nbytes / 16), dim3(256), 0, (hipStream_t)stream, keep_dev, (const u32x4*)g, (u32x4*)ga,
                      (u32x4*)gb, (long long)(nbytes / 16));
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+extern "C" int st5_skip_grad(const float* keep_dev, const void* g, void* dx, int64_t nbytes, void* stream) {
+  if (!keep_dev || !g || !dx || nbytes < 0 || nbytes % 16) return ST5_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx)) % 16) return ST5_ERR_ALIGN;
+  if (nbytes == 0) return ST5_OK;
+  hipLaunchKernelGGL(skip_grad_kernel, grid_for(nbytes / 16), dim3(256), 0, (hipStream_t)stream, keep_dev, (const u32x4*)g, (u32x4*)dx,
+                     (long long)(nbytes / 16));
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

@@ -1353,6 +1353,7 @@ int launch_nt8p(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
     case F_DROP | F_RES: return launch_nt8p_as<F_DROP | F_RES>(p, c_vec_ok, grid, s);
     case F_DACT: return launch_nt8p_as<F_DACT>(p, c_vec_ok, grid, s);
     case F_BETA: return launch_nt8p_as<F_BETA>(p, c_vec_ok, grid, s);
+    case F_RES: return launch_nt8p_as<F_RES>(p, c_vec_ok, grid, s);
     default: return launch_nt8p_as<-1>(p, c_vec_ok, grid, s);
   }
 }
@@ -1406,11 +1407,17 @@ int g_nt_slots5 = 1;   // grids of more than g_deep_blocks blocks on five operan
 //   F_DROP | F_RES   fc2 / output projection forward (bias, dropout, residual)
 //   F_DACT           data gradient through the GELU (x act'(pre))
 //   F_BETA           accumulating data gradient (dX += ...)
+//   F_RES            data gradient of a post-LN block whose input is also its residual (dX = dH W + dY: 78 of the 87 launches of an
+//                    update that still ran the run-time form in round 5, ST5_GEMM_FEAT_LOG=1)
 int nt_feat_of(const st5_gemm_params& p, int c_vec_ok) {
-  if (!c_vec_ok || p.N % 8 != 0 || (p.flags & ST5_GEMM_OUT_F32)) return -1;
+  // ST5_GEMM_FEAT_LOG=1: one stderr line per launch that falls back to the run-time form (which combinations deserve a kernel?)
+  static const bool log_rt = getenv("ST5_GEMM_FEAT_LOG") && getenv("ST5_GEMM_FEAT_LOG")[0] == '1';
   const bool dact = (p.flags & ST5_GEMM_DACT) != 0;
-  if (p.act != ACT_NONE && p.act != ACT_GELU) return -1;
-  if (dact && p.act != ACT_GELU) return -1;
+  if (!c_vec_ok || p.N % 8 != 0 || (p.flags & ST5_GEMM_OUT_F32) || (p.act != ACT_NONE && p.act != ACT_GELU) || (dact && p.act != ACT_GELU)) {
+    if (log_rt) fprintf(stderr, "st5_gemm rt-epilogue layout vec=%d f32=%d act=%d dact=%d M=%d N=%d K=%d batch=%d\n", c_vec_ok,
+                        (int)((p.flags & ST5_GEMM_OUT_F32) != 0), p.act, (int)dact, p.M, p.N, p.K, p.batch);
+    return -1;
+  }
   int f = 0;
   if (dact) f |= F_DACT;
   else if (p.act == ACT_GELU) f |= F_GELU;
@@ -1419,9 +1426,11 @@ int nt_feat_of(const st5_gemm_params& p, int c_vec_ok) {
   if (p.Cpre.ptr) f |= F_PRE;
   if (p.beta != 0.f) f |= F_BETA;
   switch (f) {
-    case 0: case F_GELU | F_PRE: case F_DROP | F_RES: case F_DACT: case F_BETA: return f;
-    default: return -1;
+    case 0: case F_GELU | F_PRE: case F_DROP | F_RES: case F_DACT: case F_BETA: case F_RES: return f;
+    default: break;
   }
+  if (log_rt) fprintf(stderr, "st5_gemm rt-epilogue feat=%d act=%d M=%d N=%d K=%d batch=%d\n", f, p.act, p.M, p.N, p.K, p.batch);
+  return -1;
 }
 
 template <typename T, int NBUF, int FEAT>
@@ -1447,6 +1456,7 @@ int launch_glds_feat(const st5_gemm_params& p, int c_vec_ok, dim3 grid, hipStrea
       case F_DROP | F_RES: return launch_glds_as<T, NBUF, F_DROP | F_RES>(p, c_vec_ok, grid, s);
       case F_DACT: return launch_glds_as<T, NBUF, F_DACT>(p, c_vec_ok, grid, s);
       case F_BETA: return launch_glds_as<T, NBUF, F_BETA>(p, c_vec_ok, grid, s);
+      case F_RES: return launch_glds_as<T, NBUF, F_RES>(p, c_vec_ok, grid, s);
       default: break;
     }
   }

@@ -159,7 +159,10 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
-                                                         long long rows, int cols, float eps) {
+                                                         long long rows, int cols, float eps,
+                                                         const float* __restrict__ keep, const T* __restrict__ skip) {
+  // keep / skip (LayerDrop gate, st5_layernorm_gated_fwd): *keep == 0 -> y = skip (the layer's input) instead of LN(x)
+  const bool dropped = keep != nullptr && *keep == 0.f;
   const int lane = threadIdx.x & 63;
   const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
   if (row0 >= rows) return;
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = fmaf(v[r][i][e] * rs, g[i][e], b[i][e]);
+          if (dropped) load4f<T>(skip + (row0 + r) * cols + c, o);
           store4f<T>(y + (row0 + r) * cols + c, o);
         }
       }
@@ -223,7 +227,10 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, T* __restrict__ dx,
                                                          float* __restrict__ part, long long rows, int cols,
-                                                         T* __restrict__ dxd, float drop_p, unsigned long long seed) {
+                                                         T* __restrict__ dxd, float drop_p, unsigned long long seed,
+                                                         const float* __restrict__ keep) {
+  // keep (LayerDrop gate, st5_layernorm_gated_bwd): *keep == 0 -> the incoming gradient counts as zero (dx = 0, no dgamma / dbeta)
+  const bool dropped = keep != nullptr && *keep == 0.f;
   const unsigned int thresh = dxd ? dropout_thresh(drop_p) : 0u;
   const float inv_keep = dxd ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ float red[];   // PG: [4 waves][2][cols]
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = in ? (Elem<T>::to_f(S.xv[r][i].v[e]) - S.mu[r]) * S.rs[r] : 0.f;
-          const float d = in ? Elem<T>::to_f(S.gv[r][i].v[e]) : 0.f;
+          const float d = (in && !dropped) ? Elem<T>::to_f(S.gv[r][i].v[e]) : 0.f;
           if (PG && live) { dg[i][e] = fmaf(d, xh, dg[i][e]); db[i][e] += d; }
           const float gg = d * g[i][e];
           xh_[i][e] = xh; gg_[i][e] = gg;
@@ -509,9 +516,10 @@ int colreduce(const void* x, const void* dy, const float* mean, const float* rst
 
 }  // namespace
 
-extern "C" int st5_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                 float* rstd, int64_t rows, int32_t cols, float eps, int dtype, void* stream) {
+static int layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                         float* rstd, int64_t rows, int32_t cols, float eps, int dtype, void* stream, const float* keep, const void* skip) {
   if (!x || !y || !gamma || !beta || rows < 0 || cols <= 0 || cols > MAXCH * 512) return ST5_ERR_ARG;
+  if (keep && (!skip || cols % 4 != 0 || cols > 2048)) return ST5_ERR_ARG;    // (the gate lives in the vector kernels only)
   if (rows == 0) return ST5_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((rows + 3) / 4));
@@ -520,7 +528,7 @@ extern "C" int st5_layernorm_fwd(const void* x, const float* gamma, const float*
     dim3 vgrid((unsigned)((rows + 4 * RPW - 1) / (4 * RPW)));
 #define LNV(TT, NV_)                                                                                                 \
   hipLaunchKernelGGL((ln_fwd_vec_kernel<TT, NV_>), vgrid, dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, \
-                     (long long)rows, cols, eps)
+                     (long long)rows, cols, eps, keep, (const TT*)skip)
 #define LNV_T(TT)                                                                                                     \
   do {                                                                                                                \
     if (cols <= 256) LNV(TT, 1); else if (cols <= 512) LNV(TT, 2); else if (cols <= 768) LNV(TT, 3);                  \
@@ -546,15 +554,26 @@ extern "C" int st5_layernorm_fwd(const void* x, const float* gamma, const float*
   return ST5_OK;
 }
 
+extern "C" int st5_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int64_t rows, int32_t cols, float eps, int dtype, void* stream) {
+  return layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, dtype, stream, nullptr, nullptr);
+}
+extern "C" int st5_layernorm_gated_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                       int64_t rows, int32_t cols, float eps, const float* keep, const void* skip, int dtype, void* stream) {
+  if (!keep || !skip) return ST5_ERR_ARG;
+  return layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, dtype, stream, keep, skip);
+}
+
 extern "C" int64_t st5_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols) {
   const int64_t a = (int64_t)nsplit_for(rows) * cols * sizeof(float);
   const int64_t b = (int64_t)ln_blocks(rows) * 2 * cols * sizeof(float);
   return a > b ? a : b;
 }
 
-extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                 const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t rows,
-                                 int32_t cols, void* dx_dropped, float drop_p, uint64_t drop_seed, int dtype, void* stream) {
+static int layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                         const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t rows,
+                         int32_t cols, void* dx_dropped, float drop_p, uint64_t drop_seed, int dtype, void* stream, const float* keep) {
+  if (keep && (!dx || cols % 4 || cols > 2048)) return ST5_ERR_ARG;
   if (dx_dropped && (!dx || cols % 4 || cols > 2048 || drop_p <= 0.f || drop_p >= 1.f)) return ST5_ERR_ARG;
   if (!dy || !x || !gamma || !mean || !rstd || rows < 0 || cols <= 0 || cols > MAXCH * 512) return ST5_ERR_ARG;
   if ((dgamma || dbeta) && !ws) return ST5_ERR_ARG;
@@ -597,10 +616,10 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
   do {                                                                                                                  \
     if (pg) hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, true>), dim3(nb), dim3(256), shm, s, (const TT*)dy, (const TT*)x, gamma, \
                                mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols, (TT*)dx_dropped, drop_p,          \
-                               (unsigned long long)drop_seed);                                                          \
+                               (unsigned long long)drop_seed, keep);                                                    \
     else hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, false>), dim3(nb), dim3(256), 0, s, (const TT*)dy, (const TT*)x, gamma, \
                             mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols, (TT*)dx_dropped, drop_p,            \
-                            (unsigned long long)drop_seed);                                                             \
+                            (unsigned long long)drop_seed, keep);                                                       \
   } while (0)
 #define LBV_T(TT)                                                                                                     \
   do {                                                                                                                \
@@ -639,6 +658,19 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
     HIP_CHECK_LAUNCH();
   }
   return ST5_OK;
+}
+
+extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t rows,
+                                 int32_t cols, void* dx_dropped, float drop_p, uint64_t drop_seed, int dtype, void* stream) {
+  return layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, dx_dropped, drop_p, drop_seed, dtype, stream, nullptr);
+}
+extern "C" int st5_layernorm_gated_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                       const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t rows,
+                                       int32_t cols, void* dx_dropped, float drop_p, uint64_t drop_seed, const float* keep, int dtype,
+                                       void* stream) {
+  if (!keep) return ST5_ERR_ARG;
+  return layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, dx_dropped, drop_p, drop_seed, dtype, stream, keep);
 }
 
 #undef g_ln_pending

@@ -1142,19 +1142,27 @@ def guided_attention_loss(att, ilens, olens, sigma, alpha):
 # -------------------------------------------------------------------------------------------------
 class LayerNormFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, gate=None):
         x2 = _rows(x)
         rows, cols = x2.shape
         y = torch.empty_like(x2)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        hip.check(hip.lib().st5_layernorm_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
-                                              rstd.data_ptr(), rows, cols, eps, _dt(x), hip.stream()), "st5_layernorm_fwd")
+        if gate is None:
+            hip.check(hip.lib().st5_layernorm_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                  rstd.data_ptr(), rows, cols, eps, _dt(x), hip.stream()), "st5_layernorm_fwd")
+        else:       # LayerDrop gate: y = keep ? LN(x) : the layer's input
+            skip = gate.skip
+            assert skip.shape == x2.shape and skip.dtype == x2.dtype and skip.is_contiguous()
+            hip.check(hip.lib().st5_layernorm_gated_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                        rstd.data_ptr(), rows, cols, eps, gate.keep.data_ptr(), skip.data_ptr(), _dt(x),
+                                                        hip.stream()), "st5_layernorm_gated_fwd")
         tag = _drop_tags.pop(x2.data_ptr(), None)
         if tag is not None and (tag[2:] != (rows, cols) or cols % 4 or cols > 2048):
             tag = None
         ctx.save_for_backward(x2, mean, rstd)
         ctx.meta = (weight, bias, x.shape, tag)
+        ctx.gate = gate
         return y.view(x.shape)
 
     @staticmethod
@@ -1174,18 +1182,30 @@ class LayerNormFunction(torch.autograd.Function):
         gw = grad_buffer(weight) if weight.requires_grad else None
         gb = grad_buffer(bias) if bias.requires_grad else None
         ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows, cols), x2.device)
-        hip.check(L.st5_layernorm_bwd(g.data_ptr(), x2.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                      hip.ptr(dx), hip.ptr(gw), hip.ptr(gb), ws.data_ptr(), rows, cols, hip.ptr(dxd),
-                                      tag[0] if dxd is not None else 0.0, tag[1] if dxd is not None else 0, _dt(x2),
-                                      hip.stream()), "st5_layernorm_bwd")
+        gate = ctx.gate
+        if gate is None:
+            hip.check(L.st5_layernorm_bwd(g.data_ptr(), x2.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                          hip.ptr(dx), hip.ptr(gw), hip.ptr(gb), ws.data_ptr(), rows, cols, hip.ptr(dxd),
+                                          tag[0] if dxd is not None else 0.0, tag[1] if dxd is not None else 0, _dt(x2),
+                                          hip.stream()), "st5_layernorm_bwd")
+        else:       # a dropped layer's output gradient counts as zero here and reaches the layer's input through the gate
+            assert dx is not None
+            gate.g_out = g
+            hip.check(L.st5_layernorm_gated_bwd(g.data_ptr(), x2.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                hip.ptr(dx), hip.ptr(gw), hip.ptr(gb), ws.data_ptr(), rows, cols, hip.ptr(dxd),
+                                                tag[0] if dxd is not None else 0.0, tag[1] if dxd is not None else 0,
+                                                gate.keep.data_ptr(), _dt(x2), hip.stream()), "st5_layernorm_gated_bwd")
         if gw is not None:
             _grad_done(weight)
         if gb is not None:
             _grad_done(bias)
-        return (dx.view(xshape) if dx is not None else None), None, None, None
+        return (dx.view(xshape) if dx is not None else None), None, None, None, None
 
 
-def layer_norm(x, weight, bias, eps=1e-5):
+def layer_norm(x, weight, bias, eps=1e-5, gate=None):
+    if gate is not None:
+        gate.used = True
+        return LayerNormFunction.apply(x.contiguous(), weight, bias, float(eps), gate)
     return LayerNormFunction.apply(x.contiguous(), weight, bias, float(eps))
 
 
@@ -1583,6 +1603,52 @@ class LayerDropSelectFunction(torch.autograd.Function):
 
 def layerdrop_select(x_in, x_out, keep):
     return LayerDropSelectFunction.apply(x_in.contiguous(), x_out.contiguous(), keep)
+
+
+class LayerDropGate:
+    """The select of a post-LN layer folded into the kernels on either side of it (one launch instead of three per layer and
+    direction): the layer's LAST LayerNorm writes  keep ? LN(z) : x_in  (st5_layernorm_gated_fwd) and, in the backward, counts its
+    incoming gradient g_out as zero when the layer is dropped -- every gradient inside the layer is then exactly zero, as with
+    layerdrop_select -- while LayerDropEnterFunction at the layer's input replaces the (zero) input gradient by g_out
+    (st5_skip_grad: a kept layer, 19 of 20, costs one early-exit launch instead of a select and an autograd accumulation).
+    Usage (modules/encoder.py, modules/decoder.py):  gate, x = layerdrop_gate(x, keep);  y = layer.forward_rows(x, ..., gate=gate)."""
+
+    def __init__(self, keep, skip):
+        self.keep, self.skip = keep, skip      # one device float; the layer's input rows (detached, contiguous)
+        self.g_out = None                      # the gradient of the gated LayerNorm's output, set by its backward
+        self.used = False
+
+
+class LayerDropEnterFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gate):
+        ctx.gate = gate
+        return x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dx):
+        gate = ctx.gate
+        g, gate.g_out = gate.g_out, None
+        assert g is not None, "LayerDropGate: the layer's input gradient arrived before its gated LayerNorm's backward ran"
+        dx = dx.contiguous()
+        assert g.numel() == dx.numel() and g.dtype == dx.dtype
+        hip.check(hip.lib().st5_skip_grad(gate.keep.data_ptr(), g.data_ptr(), dx.data_ptr(), dx.numel() * dx.element_size(), hip.stream()),
+                  "st5_skip_grad")
+        return dx, None
+
+
+LAYERDROP_GATE = os.environ.get("ST5_LAYERDROP_GATE", "1") != "0"    # A/B switch: 0 = the stand-alone select kernels everywhere
+
+
+def layerdrop_gate(x, keep):
+    """(gate, x') for a layer whose last operation is a LayerNorm that accepts `gate=`; x' aliases x."""
+    x = x.contiguous()
+    gate = LayerDropGate(keep, _rows(x.detach()))
+    y = LayerDropEnterFunction.apply(x, gate)
+    b = getattr(x, "_st5_boundary", None)
+    if b is not None:
+        y._st5_boundary = b          # (layer_boundary stays idempotent: the layer's own call must not cut the graph again)
+    return gate, y
 
 
 def layerdrop_on_device(x):

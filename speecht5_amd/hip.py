@@ -53,6 +53,10 @@ _SIGS = {
                                   c_float, c_int, c_void_p]),
     "st5_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int64, c_int32, c_void_p, c_float, c_uint64, c_int, c_void_p]),
+    "st5_layernorm_gated_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                        c_float, c_void_p, c_void_p, c_int, c_void_p]),
+    "st5_layernorm_gated_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int64, c_int32, c_void_p, c_float, c_uint64, c_void_p, c_int, c_void_p]),
     "st5_layernorm_defer": (c_int, [c_int, c_void_p]),
     "st5_layernorm_flush": (c_int, [c_void_p]),
     "st5_layernorm_bwd_ws_bytes": (c_int64, [c_int64, c_int32]),
@@ -96,6 +100,7 @@ _SIGS = {
     "st5_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
     "st5_select": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "st5_select_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "st5_skip_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "st5_act_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "st5_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "st5_channel_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),

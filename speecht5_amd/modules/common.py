@@ -17,8 +17,8 @@ class LayerNorm(nn.Module):
         self.eps = eps
         self.normalized_shape = (dim,)
 
-    def forward(self, x):
-        return Fn.layer_norm(x, self.weight, self.bias, self.eps)
+    def forward(self, x, gate=None):
+        return Fn.layer_norm(x, self.weight, self.bias, self.eps, gate=gate)
 
 
 def tbc_to_rows(x):

@@ -99,9 +99,15 @@ class TransformerDecoder(FairseqIncrementalDecoder):
             want = bool(idx == alignment_layer or alignment_layer == -1) and (self.materialise_alignment or not self.training)
             if keep_dev is not None:
                 x = Fn.layer_boundary(x, layer)      # (the select's skip operand is the tensor BEHIND the layer's boundary)
-            y, layer_attn = layer.forward_rows(x, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want,
-                                               kv_all=(kv_all, idx * 2 * C, share) if kv_all is not None else None)
-            x = y if keep_dev is None else Fn.layerdrop_select(x, y, keep_dev[idx:idx + 1])
+            kva = (kv_all, idx * 2 * C, share) if kv_all is not None else None
+            if keep_dev is not None and torch.is_grad_enabled() and Fn.LAYERDROP_GATE and layer.gate_ok():
+                # post-LN layer: the select rides on its last LayerNorm and its gradient on the layer's input (Fn.LayerDropGate)
+                gate, xg = Fn.layerdrop_gate(x, keep_dev[idx:idx + 1])
+                x, layer_attn = layer.forward_rows(xg, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want, kv_all=kva, gate=gate)
+                assert gate.used
+            else:
+                y, layer_attn = layer.forward_rows(x, B, T, enc_rows, S, enc_pad, tgt_mask, causal, want, kv_all=kva)
+                x = y if keep_dev is None else Fn.layerdrop_select(x, y, keep_dev[idx:idx + 1])
             inner_states.append(x.view(B, T, C).transpose(0, 1))
             if layer_attn is not None and want:
                 attn = layer_attn.transpose(0, 1)       # [H,B,T,S] as the reference's per-head weights

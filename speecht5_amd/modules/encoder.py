@@ -125,8 +125,15 @@ class TransformerEncoder(FairseqEncoder):
             with torch.no_grad() if frozen else contextlib.ExitStack():
                 if keep_dev is not None:
                     x = Fn.layer_boundary(x, layer)      # (the select's skip operand is the tensor BEHIND the layer's boundary)
-                    y = layer.forward_rows(x, B, T, padding_mask=encoder_padding_mask, pos_bias=self.pos_emb.for_layer(pos_k) if pos_k is not None else None)
-                    x = y if i == self.unb_enc_layer else Fn.layerdrop_select(x, y, keep_dev[i:i + 1])
+                    pb = self.pos_emb.for_layer(pos_k) if pos_k is not None else None
+                    if i != self.unb_enc_layer and not frozen and torch.is_grad_enabled() and Fn.LAYERDROP_GATE and layer.gate_ok():
+                        # post-LN layer: the select rides on its last LayerNorm and its gradient on the layer's input (Fn.LayerDropGate)
+                        gate, xg = Fn.layerdrop_gate(x, keep_dev[i:i + 1])
+                        x = layer.forward_rows(xg, B, T, padding_mask=encoder_padding_mask, pos_bias=pb, gate=gate)
+                        assert gate.used
+                    else:
+                        y = layer.forward_rows(x, B, T, padding_mask=encoder_padding_mask, pos_bias=pb)
+                        x = y if i == self.unb_enc_layer else Fn.layerdrop_select(x, y, keep_dev[i:i + 1])
                 elif not self.training or (dropout_probability > self.encoder_layerdrop) or i == self.unb_enc_layer:
                     x = Fn.layer_boundary(x, layer)
                     x = layer.forward_rows(x, B, T, padding_mask=encoder_padding_mask, pos_bias=self.pos_emb.for_layer(pos_k) if pos_k is not None else None)

@@ -30,8 +30,13 @@ class TransformerSentenceEncoderLayer(nn.Module):
         if has_relative_attention_bias:
             self.norm_k = LayerNorm(embedding_dim // num_attention_heads)
 
-    def forward_rows(self, x, B, T, padding_mask=None, pos_bias=None):
-        """x rows [B*T, C] -> rows.  Post-LN (:112-132) or pre-LN (:90-111)."""
+    def gate_ok(self):
+        """A LayerDrop gate (functional.LayerDropGate) can ride on this layer: its last operation is a LayerNorm."""
+        return not self.layer_norm_first
+
+    def forward_rows(self, x, B, T, padding_mask=None, pos_bias=None, gate=None):
+        """x rows [B*T, C] -> rows.  Post-LN (:112-132) or pre-LN (:90-111).  gate: LayerDrop select folded into the last LayerNorm."""
+        assert gate is None or self.gate_ok()
         tr = self.training
         p, pa = (self.dropout if tr else 0.0), (self.activation_dropout if tr else 0.0)
         x = Fn.layer_boundary(x, self)
@@ -48,7 +53,7 @@ class TransformerSentenceEncoderLayer(nn.Module):
                                                out_dropout=p)
             x = self.self_attn_layer_norm(x)
             x = Fn.ffn(x, x, self.fc1, self.fc2, self.act, pa, p)
-            x = self.final_layer_norm(x)
+            x = self.final_layer_norm(x, gate=gate)
         return x
 
     def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, need_weights=False, att_args=None, pos_bias=None):
@@ -91,8 +96,14 @@ class TransformerDecoderLayer(nn.Module):
         if has_relative_attention_bias:
             self.norm_k = LayerNorm(self.embed_dim // args.decoder_attention_heads)  # unused (:241), kept for checkpoints
 
-    def forward_rows(self, x, B, T, enc_rows, S, enc_padding_mask, self_padding_mask, causal, need_attn, kv_all=None):
-        """transformer_layer.py:262-404 without incremental state.  Returns (rows, cross-attn probs [B,H,T,S] or None)."""
+    def gate_ok(self):
+        """A LayerDrop gate can ride on this layer: post-LN (the last operation is final_layer_norm) and nothing frozen."""
+        return (not self.normalize_before) and self.freeze_decoder_updates <= self.num_updates
+
+    def forward_rows(self, x, B, T, enc_rows, S, enc_padding_mask, self_padding_mask, causal, need_attn, kv_all=None, gate=None):
+        """transformer_layer.py:262-404 without incremental state.  Returns (rows, cross-attn probs [B,H,T,S] or None).
+        gate: LayerDrop select folded into the last LayerNorm."""
+        assert gate is None or self.gate_ok()
         ft = self.freeze_decoder_updates <= self.num_updates
         tr = self.training
         p, pa = (self.dropout if tr else 0.0), (self.activation_dropout if tr else 0.0)
@@ -115,7 +126,7 @@ class TransformerDecoderLayer(nn.Module):
             h = self.final_layer_norm(x) if nb else x
             x = Fn.ffn(h, x, self.fc1, self.fc2, self.act, pa, p)
             if not nb:
-                x = self.final_layer_norm(x)
+                x = self.final_layer_norm(x, gate=gate)
         return x, attn
 
     @torch.no_grad()

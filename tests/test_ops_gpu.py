@@ -208,6 +208,54 @@ def test_gemm_dact_and_dropout(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("keep", [1.0, 0.0])
+def test_layernorm_gated_by_a_layerdrop_flag(cuda, dtype, keep):
+    """st5_layernorm_gated_fwd / _bwd + st5_skip_grad (the LayerDrop select folded into a post-LN layer's last LayerNorm,
+    functional.LayerDropGate): keep = 1 is bit for bit the plain LayerNorm and leaves the input gradient alone; keep = 0 hands the
+    skip rows through, produces exact zeros in dx / dgamma / dbeta and replaces the input gradient by the output gradient."""
+    rows, cols = 2100, 768
+    torch.manual_seed(5)
+    X, DY, SK = dev(torch.randn(rows, cols) * 2 + 0.5, dtype, cuda), dev(torch.randn(rows, cols), dtype, cuda), dev(torch.randn(rows, cols), dtype, cuda)
+    G, Bt = torch.randn(cols).to(cuda), torch.randn(cols).to(cuda)
+    K = torch.tensor([keep], device=cuda)
+    L = hip.lib()
+
+    def run(gated):
+        Y = torch.empty_like(X); DX = torch.empty_like(X)
+        mean = torch.empty(rows, device=cuda); rstd = torch.empty(rows, device=cuda)
+        dG = torch.ones(cols, device=cuda); dB = torch.ones(cols, device=cuda)
+        ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows, cols), cuda)
+        if gated:
+            hip.check(L.st5_layernorm_gated_fwd(X.data_ptr(), G.data_ptr(), Bt.data_ptr(), Y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                rows, cols, 1e-5, K.data_ptr(), SK.data_ptr(), hip.dt(dtype), hip.stream()), "gated fwd")
+            hip.check(L.st5_layernorm_gated_bwd(DY.data_ptr(), X.data_ptr(), G.data_ptr(), mean.data_ptr(), rstd.data_ptr(), DX.data_ptr(),
+                                                dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), rows, cols, None, 0.0, 0, K.data_ptr(),
+                                                hip.dt(dtype), hip.stream()), "gated bwd")
+        else:
+            hip.check(L.st5_layernorm_fwd(X.data_ptr(), G.data_ptr(), Bt.data_ptr(), Y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                          rows, cols, 1e-5, hip.dt(dtype), hip.stream()), "fwd")
+            hip.check(L.st5_layernorm_bwd(DY.data_ptr(), X.data_ptr(), G.data_ptr(), mean.data_ptr(), rstd.data_ptr(), DX.data_ptr(),
+                                          dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), rows, cols, None, 0.0, 0, hip.dt(dtype), hip.stream()), "bwd")
+        torch.cuda.synchronize()
+        return Y, DX, dG, dB
+
+    plain, gated = run(False), run(True)
+    din = dev(torch.randn(rows, cols), dtype, cuda)      # the layer's own input gradient
+    d0 = din.clone()
+    hip.check(L.st5_skip_grad(K.data_ptr(), DY.data_ptr(), din.data_ptr(), din.numel() * din.element_size(), hip.stream()), "skip grad")
+    torch.cuda.synchronize()
+    if keep:
+        for a, b in zip(plain, gated):
+            assert torch.equal(a, b)
+        assert torch.equal(din, d0)
+    else:
+        assert torch.equal(gated[0], SK)
+        assert float(gated[1].abs().max()) == 0.0
+        assert torch.equal(gated[2], torch.ones_like(gated[2])) and torch.equal(gated[3], torch.ones_like(gated[3]))
+        assert torch.equal(din, DY)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,cols", [(37, 768), (130, 512), (9, 64), (5, 1024), (2100, 768), (11, 30), (6, 1536)])
 def test_layernorm(cuda, dtype, rows, cols):
     torch.manual_seed(rows)
