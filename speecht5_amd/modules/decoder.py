@@ -79,7 +79,9 @@ class TransformerDecoder(FairseqIncrementalDecoder):
             bs = [b for a in cross for b in (a.k_proj.bias, a.v_proj.bias)]
             if all(b is not None for b in bs) and all(w.shape == ws[0].shape for w in ws):
                 kv_all = Fn.linear(enc_rows, ws, bs)
-                share = Fn.KVShare(len(cross), 2 * C, self.training and self.decoder_layerdrop > 0)
+                # (a layer can only be SKIPPED -- and leave its slice of the shared gradient buffer unwritten -- when LayerDrop is
+                # host control flow; in the recorded / replayed form every layer runs and writes its slice, no zero fill needed)
+                share = Fn.KVShare(len(cross), 2 * C, self.training and self.decoder_layerdrop > 0 and not Fn.layerdrop_on_device(x))
         attn_list, attn = [], None
         inner_states = [x.view(B, T, C).transpose(0, 1)]
         # LayerDrop (decoder.py:64-67 of the reference: LayerDropModuleList draws torch.empty(L).uniform_() once per pass over

@@ -41,7 +41,12 @@ class RelativePositionalEncoding(nn.Module):
         behind the gradient-exchange wrapper's "shared" boundary (ddp._boundary: one leaf per region of a phased backward)."""
         if keys is None or not self.spans_cuts:
             return keys
-        return RelPosKeys(Fn.layer_boundary(keys.table, self, "shared"), keys.maxlen)
+        t = Fn.layer_boundary(keys.table, self, "shared")
+        if t is keys.table:            # no cut in force: the same handle (and its one transposed copy) serves every layer
+            return keys
+        k = RelPosKeys(t, keys.maxlen)
+        k._t = keys.transposed()       # (a constant of the forward: the same values behind every region's leaf)
+        return k
 
 
 class TransformerEncoder(FairseqEncoder):
