@@ -130,6 +130,13 @@ int st5_gemm_mxfp8(const st5_gemm_params* p, const uint8_t* a_scale, int64_t a_s
  * values saturating at +-448.  NaN / Inf propagate: the element becomes the e4m3 NaN code 0x7f and its block's scale the e8m0 NaN 0xff,
  * so a diverged tensor still turns the GEMM output (and the loss / gradient norm behind it) non-finite. */
 int st5_quant_mxfp8(const void* x, int64_t ld, void* q, int64_t q_ld, uint8_t* s, int64_t s_ld, int64_t rows, int32_t cols, void* stream);
+/* n <= 8 weight-gradient GEMMs (each as st5_gemm would take it: A, B k-strided bf16, ST5_GEMM_OUT_F32, no epilogue but beta and asum; the
+ * four / six weight gradients of a transformer layer: autograd of F.linear at transformer_layer.py:127-131,385-389, multihead_attention.py:
+ * 213-231,397) as ONE launch in which every block runs the whole token reduction of its tile -- no split-K slabs, no reduction kernel.  The
+ * operands must stay valid until the launch has run (the caller queues the problems and keeps the tensors).  A problem's result is
+ * independent of what it is grouped with (bit for bit).  A group with a problem of another form, or with two problems writing the same
+ * output, runs through st5_gemm one by one. */
+int st5_gemm_tn_group(const st5_gemm_params* list, int32_t n, int dtype, void* stream);
 int st5_gemm_defer_splitk(int enabled, void* stream);
 int st5_gemm_flush_splitk(void* stream);
 

@@ -1519,31 +1519,31 @@ __device__ __forceinline__ bf16x8 tr_frag_asm(const unsigned lds_addr) {
   return u.v;
 }
 
+// The block program of the TN kernels: block bx of nwg (tile index before the XCD remap), split by of ny, batch z.
 template <int FEAT>   // (epilogue features, see epilogue_fast; >= 0: fp32 output in the fast layout, compile-time feature set)
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
-  ST5_PAD_TO_256_VGPRS();
+__device__ __forceinline__ void tn_glds_body(const st5_gemm_params& p, const int c_vec_ok, const int bx, const int nwg_, const int by,
+                                             const int ny, const int z) {
   typedef bf16_t T;
   constexpr int BK = 64;
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int z = blockIdx.z;
   const int tiles_n = (p.N + BN - 1) / BN;
-  int bid = blockIdx.x;
+  int bid = bx;
   {
-    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
+    const int nwg = nwg_, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
   int tm, tn;
-  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
+  tile_of(bid, tiles_n, nwg_, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
   const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
 
   // split-K range
   const int nk_all = (p.K + BK - 1) / BK;
-  const int per = (nk_all + gridDim.y - 1) / gridDim.y;
-  const int kt0 = blockIdx.y * per;
+  const int per = (nk_all + ny - 1) / ny;
+  const int kt0 = by * per;
   const int nk = (kt0 + per <= nk_all ? per : nk_all - kt0) > 0 ? (kt0 + per <= nk_all ? per : nk_all - kt0) : 0;
 
   // LDS-DMA sources: wave-instruction i of this wave covers tile rows (i*4 + wave)*4 .. +3; lane l -> row + (l>>4),
@@ -1679,7 +1679,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
   ea.atomic = 0;
   ea.fast = c_vec_ok && (p.N % 8 == 0);
-  if (gridDim.y > 1) ea.C = reinterpret_cast<float*>(ea.C) + (long long)blockIdx.y * p.M * p.N;
+  if (ny > 1) ea.C = reinterpret_cast<float*>(ea.C) + (long long)by * p.M * p.N;
   ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
   ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
   {
@@ -1694,6 +1694,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gem
   }
   float* stage = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
   run_epilogue<T, FEAT, float>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
+}
+
+template <int FEAT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  ST5_PAD_TO_256_VGPRS();
+  tn_glds_body<FEAT>(p, c_vec_ok, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y, (int)blockIdx.z);
+}
+
+// Several weight-gradient GEMMs in ONE launch, no split-K (st5_gemm_tn_group): the four (encoder) or six (decoder) weight gradients of a
+// transformer layer are 36-144 tiles of 128^2 each with a reduction over every token -- alone none of them fills the chip, which is why
+// st5_gemm splits their K range into fp32 slabs that a second kernel sums (a third of the bytes a weight-gradient launch moves).
+// Together they are 430-500 tiles, one round of two blocks per CU: every block runs its tile's whole reduction and accumulates
+// straight into the gradient buffer.  Measured on the layer's shapes (tools/r5/tn_group_probe.py): 233 -> 162 us at K = 8192 tokens,
+// 135 -> 83 us at 3992, 107 -> 58 us at 2504.  Block ranges start at multiples of 8 so that the XCD-aware tile order of the body
+// (block b runs on XCD b % 8) holds inside every problem; the padding blocks exit at once.
+constexpr int TNG_MAX = 8;
+struct TnGroupArgs { st5_gemm_params p[TNG_MAX]; int first[TNG_MAX + 1]; int tiles[TNG_MAX]; int n; };
+template <int FEAT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_group_kernel(const TnGroupArgs g) {
+  ST5_PAD_TO_256_VGPRS();
+  int j = 0;
+  while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
+  const int lb = (int)blockIdx.x - g.first[j];
+  if (lb >= g.tiles[j]) return;
+  tn_glds_body<FEAT>(g.p[j], 1, lb, g.tiles[j], 0, 1, 0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2307,6 +2332,57 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
   if (g_use_glds && tn_glds_ok(p, dtype)) return launch_tn_glds(p, c_vec_ok, nsplit, s);
   if (dtype == ST5_BF16) return launch<bf16_t>(p, c_vec_ok, nsplit, s);
   return launch<float>(p, c_vec_ok, nsplit, s);
+}
+
+/* Several weight-gradient GEMMs (C_j [M_j x N_j] (+)= A_j^T B_j: both operands k-strided bf16, fp32 output, no epilogue beyond beta and the
+ * bias-gradient column) as ONE launch without split-K (gemm_tn_group_kernel).  A problem's result does not depend on the rest of the
+ * group (every tile runs its own whole reduction).  Falls back to one st5_gemm call per problem when a problem does not have that form
+ * or two problems write the same output. */
+extern "C" int st5_gemm_tn_group(const st5_gemm_params* list, int32_t n, int dtype, void* stream) {
+  if (!list || n < 0) return ST5_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  TnGroupArgs g;
+  int m = 0;             // problems in g
+  long long padded = 0;
+  bool accum = false;
+  auto launch = [&]() {
+    if (m == 0) return (int)ST5_OK;
+    g.first[m] = (int)padded; g.n = m;
+    for (int i = m; i < TNG_MAX; ++i) { g.tiles[i] = 0; g.first[i + 1] = (int)padded; }
+    if (accum) hipLaunchKernelGGL(gemm_tn_group_kernel<F_BETA>, dim3((unsigned)padded), dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, g);
+    else hipLaunchKernelGGL(gemm_tn_group_kernel<0>, dim3((unsigned)padded), dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, g);
+    m = 0; padded = 0;
+    HIP_CHECK_LAUNCH();
+    return (int)ST5_OK;
+  };
+  // Whether a problem runs here (whole reduction per tile) or through st5_gemm (split-K) is decided by the problem ALONE, never by what it
+  // is queued with: a replayed update and an eager one, or two micro-batch schedules, form different groups and still have to agree bit
+  // for bit.  (No fall-back on the size of a group either; the under-filled ones are the leftovers at the end of a backward pass.)
+  for (int i = 0; i < n; ++i) {
+    st5_gemm_params p = list[i];
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A.ptr || !p.B.ptr || !p.C.ptr) return ST5_ERR_ARG;
+    if (p.batch <= 0) p.batch = 1;
+    if (p.zdiv <= 0) p.zdiv = 1;
+    const int want = ST5_GEMM_A_KSTRIDED | ST5_GEMM_B_KSTRIDED | ST5_GEMM_OUT_F32;
+    const bool plain = !p.bias && !p.R.ptr && !p.P.ptr && !p.Cpre.ptr && p.act == ST5_ACT_NONE && p.dropout_p == 0.f && !(p.flags & ST5_GEMM_DACT);
+    const bool c_ok = aligned(p.C.ptr, 16) && p.C.ld % 8 == 0 && !p.C.rpb && p.C.zs0 == 0 && p.C.zs1 == 0;
+    const bool ok = dtype == ST5_BF16 && g_use_glds && (p.flags & want) == want && plain && p.batch == 1 && p.N % 8 == 0 && c_ok &&
+                    tn_glds_ok(p, dtype) && (!p.asum || aligned(p.asum, 4));
+    if (!ok) {
+      const int rc = st5_gemm(&list[i], dtype, stream);
+      if (rc) return rc;
+      continue;
+    }
+    bool clash = m == TNG_MAX || (m > 0 && (p.beta != 0.f) != accum);
+    for (int j = 0; j < m && !clash; ++j) clash = g.p[j].C.ptr == p.C.ptr || (p.asum && g.p[j].asum == p.asum);
+    if (clash) { const int rc = launch(); if (rc) return rc; }      // (same output twice, or mixed beta: in order, one launch each)
+    if (m == 0) accum = p.beta != 0.f;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    g.p[m] = p; g.tiles[m] = tiles; g.first[m] = (int)padded;
+    padded += (tiles + 7) / 8 * 8;
+    ++m;
+  }
+  return launch();
 }
 
 /* MX-fp8 GEMM (see gemm_nt_mx8_kernel): p describes fp8 operands A [M x K], B [N x K] (ld in BYTES = elements, K-major, no row

@@ -128,7 +128,20 @@ class FlatGradDataParallel:
             # batched split-K reductions: this wrapper owns the points where gradients must be complete (bucket
             # all-reduce, finish()), so the per-GEMM slab reductions can be deferred and folded in one launch
             from . import hip
+            # A TIED parameter (the text embedding = the decoder's output projection) has several writers -- the embedding backward's
+            # scatter-add at once, the projection's weight-gradient GEMM through a deferred reduction -- and the order of two fp32
+            # accumulations is visible in the last bit: such a gradient is reduced where it is computed, in program order, so that the
+            # result does not depend on where the next flush point happens to be (phased or not, queue full or not).
+            owners = {}
+            for m in model.modules():
+                for p in m._parameters.values():
+                    if p is not None:
+                        owners.setdefault(id(p), []).append(p)
+            for lst in owners.values():
+                if len(lst) > 1:
+                    lst[0]._st5_multi_writer = True
             hip.check(hip.lib().st5_gemm_defer_splitk(1, hip.stream()), "st5_gemm_defer_splitk")
+            Fn.set_wgrad_grouping(True)     # (same ownership: a layer's weight gradients queued and launched as one GEMM group)
             if os.environ.get("ST5_LN_DEFER", "1") == "1":   # same idea for the LayerNorm dgamma/dbeta reductions
                 hip.check(hip.lib().st5_layernorm_defer(1, hip.stream()), "st5_layernorm_defer")
             # weight-gradient GEMMs of the transformer layers on their own stream (functional.set_wgrad_stream): their
@@ -196,6 +209,7 @@ class FlatGradDataParallel:
         """Gradients complete on the current stream: batched split-K reductions folded, weight-gradient stream joined."""
         from . import hip
         if self.flat.is_cuda:
+            Fn.flush_wgrads()
             hip.check(hip.lib().st5_layernorm_flush(hip.stream()), "st5_layernorm_flush")
             if Fn.wgrad_stream() is not None:
                 Fn.join_wgrad_stream()   # the deferred reductions belong to the side stream: folded there, then joined
@@ -295,6 +309,7 @@ class FlatGradDataParallel:
                 st.wait_stream(cur)      # (behind micro-batch 0's backward)
             with self._grad_slot(i), torch.cuda.stream(st):
                 loss.backward()          # (root gradient on `st`: no dependence on the other micro-batch's stream)
+                Fn.flush_wgrads()        # (the last layers' queued weight gradients of this micro-batch, on its stream)
                 Fn.join_wgrad_stream()   # (no-op unless this stream owns a weight-gradient stream: its slabs folded there, then joined)
                 # this stream's deferred reductions (split-K slabs, LayerNorm partials) are folded on this stream
                 hip.check(hip.lib().st5_layernorm_flush(hip.stream()), "st5_layernorm_flush")
@@ -487,6 +502,7 @@ class FlatGradDataParallel:
             Fn.set_attention_stream(None)
             if self._fwd_streams:
                 hip.check(hip.lib().st5_gemm_set_deep_ring(256, 4), "st5_gemm_set_deep_ring")   # (the library default)
+            Fn.set_wgrad_grouping(False)
             hip.check(hip.lib().st5_layernorm_defer(0, hip.stream()), "st5_layernorm_defer")
             hip.check(hip.lib().st5_gemm_defer_splitk(0, hip.stream()), "st5_gemm_defer_splitk")
         Fn.set_layer_boundary_hook(None)

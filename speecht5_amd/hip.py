@@ -47,6 +47,7 @@ _SIGS = {
     "st5_gemm_set_splitk_target": (c_int, [c_int]),
     "st5_gemm_set_deep_ring": (c_int, [c_int, c_int]),
     "st5_gemm_set_nt_slots": (c_int, [c_int]),
+    "st5_gemm_tn_group": (c_int, [c_void_p, c_int32, c_int, c_void_p]),
     "st5_gemm_defer_splitk": (c_int, [c_int, c_void_p]),
     "st5_gemm_flush_splitk": (c_int, [c_void_p]),
     "st5_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
@@ -344,6 +345,32 @@ def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_
         profiler.records.append((variant, 2.0 * M * N * K * batch, e0, e1, (M, N, K, batch)))
         return
     check(lib().st5_gemm(byref(p), dtype, stream() if on is None else on.cuda_stream), "st5_gemm")
+
+
+def gemm_tn_group(problems, dtype):
+    """problems: [(A, B, C, M, N, K, flags, beta, asum)] weight-gradient GEMMs -> ONE launch without split-K (st5_gemm_tn_group;
+    the library falls back to one st5_gemm per problem when the group does not qualify).  The caller keeps the operands alive until
+    the call returns (the launch is enqueued on the current stream by then)."""
+    n = len(problems)
+    arr = (GemmParams * n)()
+    flops = 0.0
+    for p, (A, B, C, M, N, K, flags, beta, asum) in zip(arr, problems):
+        p.A, p.B, p.C = A, B, C
+        p.R = p.P = p.Cpre = _NULL_OP
+        p.bias, p.bias_zs = None, 0
+        p.M, p.N, p.K, p.batch, p.zdiv = M, N, K, 1, 1
+        p.act, p.flags = ACT_NONE, flags
+        p.alpha, p.beta, p.dropout_p, p.seed = 1.0, beta, 0.0, 0
+        p.asum = ptr(asum)
+        flops += 2.0 * M * N * K
+    if profiler.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().st5_gemm_tn_group(arr, n, dtype, stream()), "st5_gemm_tn_group")
+        e1.record()
+        profiler.records.append((("bf16" if dtype == BF16 else "f32") + "_TN", flops, e0, e1, (problems[0][3], problems[0][4], problems[0][5], n)))
+        return
+    check(lib().st5_gemm_tn_group(arr, n, dtype, stream()), "st5_gemm_tn_group")
 
 
 def quant_mxfp8(x2):

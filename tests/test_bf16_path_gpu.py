@@ -156,6 +156,46 @@ def test_tn_glds_model_shapes_with_bias_column(cuda):
         assert (db - 2.0 - rb).abs().max().item() <= 2e-2 * max(rb.abs().max().item(), math.sqrt(K))
 
 
+@pytest.mark.parametrize("K", [3992, 2504, 8192])
+def test_weight_gradient_group_launch(cuda, K):
+    """st5_gemm_tn_group: the four weight gradients of an encoder layer (QKV 2304 x 768, out 768 x 768, fc1 3072 x 768, fc2 768 x 3072;
+    reduction over K tokens incl. a partial k-tile) as ONE launch without split-K, accumulating into non-zero gradient buffers with
+    the bias-gradient columns -- against fp32 matmul, and against the same problems through st5_gemm one by one (split-K: another
+    summation order, so a tolerance), and a problem launched alone against its result inside the group (bit-equal: replayed and eager
+    updates, or two micro-batch schedules, queue different groups and still have to agree)."""
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
+    fl = hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32
+    g = torch.Generator().manual_seed(K)
+    probs, keep = [], []
+    for (M, N) in shapes:
+        dy = torch.randn(K, M, generator=g).to(torch.bfloat16).to(cuda)
+        x = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(cuda)
+        C = torch.full((M, N), 1.0, dtype=torch.float32, device=cuda)
+        db = torch.full((M,), 2.0, dtype=torch.float32, device=cuda)
+        keep.append((dy, x, C, db))
+        probs.append((hip.operand(dy, M), hip.operand(x, N), hip.operand(C, N), M, N, K, fl, 1.0, db))
+    hip.gemm_tn_group(probs, hip.BF16)
+    torch.cuda.synchronize()
+    for (dy, x, C, db), (M, N) in zip(keep, shapes):
+        ref = dy.float().t() @ x.float()
+        _close(C - 1.0, ref, torch.bfloat16, f"tn group {M}x{N}x{K}")
+        rb = dy.float().sum(0)
+        assert (db - 2.0 - rb).abs().max().item() <= 2e-2 * max(rb.abs().max().item(), math.sqrt(K))
+        C1 = torch.full((M, N), 1.0, dtype=torch.float32, device=cuda)
+        d1 = torch.full((M,), 2.0, dtype=torch.float32, device=cuda)
+        hip.gemm(hip.operand(dy, M), hip.operand(x, N), hip.operand(C1, N), M, N, K, hip.BF16, flags=fl, beta=1.0, asum=d1)
+        torch.cuda.synchronize()
+        assert (C1 - C).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+    # a problem's result does not depend on its group: the out-projection gradient alone == the one computed inside the group of four
+    dy, x, Cg, dbg = keep[1]
+    M, N = shapes[1]
+    C1 = torch.full((M, N), 1.0, dtype=torch.float32, device=cuda)
+    d1 = torch.full((M,), 2.0, dtype=torch.float32, device=cuda)
+    hip.gemm_tn_group([(hip.operand(dy, M), hip.operand(x, N), hip.operand(C1, N), M, N, K, fl, 1.0, d1)], hip.BF16)
+    torch.cuda.synchronize()
+    assert torch.equal(C1, Cg) and torch.equal(d1, dbg)
+
+
 @pytest.mark.parametrize("mode", [3, 4])
 @pytest.mark.parametrize("kind", EPI)
 def test_nt_phased_256_tile_forced(cuda, mode, kind):
