@@ -674,7 +674,7 @@ def set_wgrad_owner(stream):
 # and hands them to st5_gemm_tn_group as soon as they amount to one round of the chip (~400-512 tiles of 128^2: the four / six weight
 # gradients of one layer): one launch, whole reductions, no slabs.  233 -> 162 us per encoder layer at 8192 tokens.
 WGRAD_GROUP = os.environ.get("ST5_WGRAD_GROUP", "1") != "0"     # A/B switch
-_WG_ROUND, _WG_FLUSH_AT, _WG_MAX = 512, 400, 8
+_WG_ROUND, _WG_FLUSH_AT, _WG_MAX = [int(v) for v in os.environ.get("ST5_WGRAD_ROUND", "512,400").split(",")] + [8]   # tiles: never above / launch at
 
 
 def set_wgrad_grouping(on):
