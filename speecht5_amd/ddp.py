@@ -124,22 +124,22 @@ class FlatGradDataParallel:
         self._next = 0
         self._works = []
         Fn.set_layer_boundary_hook(self._boundary)
+        # A TIED parameter (the text embedding = the decoder's output projection) has several writers -- the embedding backward's
+        # scatter-add at once, the projection's weight-gradient GEMM through a deferred reduction -- and the order of two fp32
+        # accumulations is visible in the last bit: such a gradient is reduced where it is computed, in program order, so that the
+        # result does not depend on where the next flush point happens to be (phased or not, queue full or not).
+        owners = {}
+        for m in model.modules():
+            for p in m._parameters.values():
+                if p is not None:
+                    owners.setdefault(id(p), []).append(p)
+        for lst in owners.values():
+            if len(lst) > 1:
+                lst[0]._st5_multi_writer = True
         if dev.type == "cuda":
             # batched split-K reductions: this wrapper owns the points where gradients must be complete (bucket
             # all-reduce, finish()), so the per-GEMM slab reductions can be deferred and folded in one launch
             from . import hip
-            # A TIED parameter (the text embedding = the decoder's output projection) has several writers -- the embedding backward's
-            # scatter-add at once, the projection's weight-gradient GEMM through a deferred reduction -- and the order of two fp32
-            # accumulations is visible in the last bit: such a gradient is reduced where it is computed, in program order, so that the
-            # result does not depend on where the next flush point happens to be (phased or not, queue full or not).
-            owners = {}
-            for m in model.modules():
-                for p in m._parameters.values():
-                    if p is not None:
-                        owners.setdefault(id(p), []).append(p)
-            for lst in owners.values():
-                if len(lst) > 1:
-                    lst[0]._st5_multi_writer = True
             hip.check(hip.lib().st5_gemm_defer_splitk(1, hip.stream()), "st5_gemm_defer_splitk")
             Fn.set_wgrad_grouping(True)     # (same ownership: a layer's weight gradients queued and launched as one GEMM group)
             if os.environ.get("ST5_LN_DEFER", "1") == "1":   # same idea for the LayerNorm dgamma/dbeta reductions
