@@ -100,8 +100,12 @@ int st5_gemm(const st5_gemm_params* p, int dtype, void* stream);
 int st5_stream_fork(void* from_stream, void* to_stream);
 int st5_gemm_set_glds(int enabled);
 /* NT block tile: 0 = chosen per problem (default), 1 = 128x128 always, 2 = first 256x256 kernel always, 3 / 4 = phased 256x256 kernel always
- * with / without the half-phase stagger (A/B measurements only). */
+ * with / without the half-phase stagger, 5 = 64x128 kernel always (A/B measurements only). */
 int st5_gemm_set_nt_tile(int mode);
+/* (mode 5 = the 64x128 kernel always.)  bf16 NT GEMMs of at most `tiles` tiles of 128x128 (x batch) run on 64x128 tiles, three blocks per CU
+ * (round 6: the transformer's Linear GEMMs at 8 utterances per GPU -- modules/transformer_layer.py:127-131, multihead_attention.py:213-231 --
+ * are 0.25-3 rounds of 128x128 tiles); 0 = never.  Results are bit-identical for every choice. */
+int st5_gemm_set_m64_max_tiles(int tiles);
 /* Block count the split-K choice of the fp32-output (weight-gradient) GEMMs aims for; default 384 (1.5 per CU). */
 int st5_gemm_set_splitk_target(int blocks);
 /* Weight-gradient (TN form, no row split / segments) GEMMs: 0 (default) = always the 128x128 LDS-DMA kernel; 1 = phased 256x256 kernel with

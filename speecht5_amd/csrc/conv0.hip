@@ -745,7 +745,9 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
 #define BWD(TT, KW)                                                                                               \
   hipLaunchKernelGGL((conv0_bwd_kernel<TT, KW>), dim3(nch, B), dim3(256), shm, s, wav, w, gamma, beta, stats,     \
                      (const TT*)dY, W.part, S, L, C, k, stride, nch)
-  const bool mfma = dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 128 == 0 && C <= 1024 && TCH % 32 == 0;
+  // (C <= 512: conv0_bwd_mfma_kernel holds at most four 128-channel tiles per wave -- G[4], dvq[4]; wider layers take the VALU kernel,
+  //  whose channel loop has no such bound.  ADVICE r5: the guard said 1024 and tiles 4.. were silently never computed.)
+  const bool mfma = dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 128 == 0 && C <= 512 && TCH % 32 == 0;
   if (mfma) {
     hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32, B), dim3(128), 0, s, w, gamma, beta, stats, W.afrag, C, k);
     const size_t seg_f = (size_t)(((TCH - 1) * stride + k + MAXK + 3) & ~3);

@@ -353,7 +353,7 @@ __device__ __forceinline__ void epilogue_rows(const EpiArgs& ea, const float* st
 // made the step's NT launches 4.5 % faster; the hot combinations of the training step therefore get kernels of their own
 // (nt_feat_of() picks, the run-time form stays the fallback).
 enum { F_GELU = 1, F_DACT = 2, F_DROP = 4, F_RES = 8, F_PRE = 16, F_BETA = 32 };
-template <typename T, typename OUT, int FEAT = -1>
+template <typename T, typename OUT, int FEAT = -1, int HALVES = 2>   // (HALVES = 1: a 32 x 64 wave tile, acc00 / acc01 only)
 __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, const f32x16& acc00, const f32x16& acc01,
                                               const f32x16& acc10, const f32x16& acc11, const int mbase, const int nbase,
                                               const int lane) {
@@ -388,7 +388,7 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
   const T* const Pb = dact ? reinterpret_cast<const T*>(ea.P) + gn : nullptr;
   T* const Qb = has_pre ? reinterpret_cast<T*>(ea.Cpre) + gn : nullptr;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < HALVES; ++h) {
     if (h == 0) stage_write(stage, acc00, acc01, lane);
     else stage_write(stage, acc10, acc11, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -449,21 +449,21 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
   }
 }
 
-template <typename T, int FEAT = -1, typename OUT = T>
+template <typename T, int FEAT = -1, typename OUT = T, int HALVES = 2>
 __device__ __forceinline__ void run_epilogue(const EpiArgs& ea, float* stage, const f32x16& acc00, const f32x16& acc01,
                                              const f32x16& acc10, const f32x16& acc11, const int mbase, const int nbase,
                                              const int lane) {
   if constexpr (FEAT >= 0) {     // (the launcher only picks a feature-specialised kernel for the fast layout with OUT outputs)
-    epilogue_fast<T, OUT, FEAT>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
+    epilogue_fast<T, OUT, FEAT, HALVES>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
     return;
   }
   if (ea.fast) {
-    if (ea.out_f32) epilogue_fast<T, float>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
-    else epilogue_fast<T, T>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
+    if (ea.out_f32) epilogue_fast<T, float, -1, HALVES>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
+    else epilogue_fast<T, T, -1, HALVES>(ea, stage, acc00, acc01, acc10, acc11, mbase, nbase, lane);
     return;
   }
 #pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < HALVES; ++h) {
     if (h == 0) stage_write(stage, acc00, acc01, lane);
     else stage_write(stage, acc10, acc11, lane);
     // the stage slab is private to this wave: order its LDS writes/reads inside the wave only.  (A block barrier here
@@ -960,6 +960,136 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
   GPROBE(4);
   if (lane == 0) { for (int i = 0; i < 5; ++i) atomicAdd(&g_gemm_timing[i], (unsigned long long)tacc[i]); atomicAdd(&g_gemm_timing[7], 1ull); }
 #endif
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// NT fast path, 64 x 128 block tile (round 6): the transformer's Linear GEMMs at B = 8 are 120-1536 tiles of 128^2 on a chip with 512
+// slots for them (two 64 KB blocks per CU), i.e. 0.25-3 rounds, and a block's k-step is bound by the LDS-DMA landing latency, not by
+// its MFMAs (~1.2 us per pair of resident blocks against 0.43 us of MFMA time): an under-filled or unevenly filled round costs a whole
+// round (8192 x 768 x 3072: 384 tiles, the CUs holding two of them set the time while the others idle after one; 3992 x 768 x K: 192
+// tiles, one per CU on 75 % of the chip, nothing covering their latency).  Half-height tiles double the number of blocks and a block
+// needs 48 KB of LDS and ~100 registers, so THREE fit on a CU (768 slots, 3 waves per SIMD): 384 tiles become 768 = exactly one round
+// on every CU, 192 become 378 = every CU busy with one or two.  Same skeleton as gemm_nt_glds_kernel<bf16, 2>: 4 waves as 2 (m) x 2
+// (n), wave tile 32 x 64 = 1 x 2 MFMA tiles of v_mfma_f32_32x32x16_bf16, k-tile 64, two-stage LDS-DMA ring (A 8 KB + B 16 KB per
+// stage), source-side XOR swizzle, register-double-buffered asm fragment reads, wave-private epilogue slab.  Every output element
+// sees the same MFMA chain (k-tiles ascending, four 16-deep groups each) as in the 128^2 and 256^2 kernels: bit-identical results.
+// Costs: 1.5x the LDS fragment bytes per flop (3 reads per 2 MFMAs instead of 4 per 4) and 1.33x the L2 -> LDS bytes per flop.
+// ------------------------------------------------------------------------------------------------------
+constexpr int M64_A_BYTES = 64 * 128, M64_STAGE = M64_A_BYTES + TILE_BYTES;
+
+template <int FEAT>
+__global__ __launch_bounds__(NTHREADS, 3) void gemm_nt_m64_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  typedef bf16_t T;
+  constexpr int VEC = 8, BK = 64;
+  typedef bf16x8 frag_t;
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int z = blockIdx.z;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
+    bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
+  const int m0 = tm * 64, n0 = tn * BN;
+  const T* Ap = reinterpret_cast<const T*>(p.A.ptr) + z_off(p.A.zs0, p.A.zs1, z, p.zdiv);
+  const T* Bp = reinterpret_cast<const T*>(p.B.ptr) + z_off(p.B.zs0, p.B.zs1, z, p.zdiv);
+  const OpAddr aa = make_addr(p.A.ld, p.A.bstride, 0, p.A.rpb, 0);
+  const OpAddr ab = make_addr(p.B.ld, p.B.bstride, 0, p.B.rpb, 0);
+
+  const T* asrc[2];
+  const T* bsrc[4];
+  const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wave) * 8 + rsub;
+    const int c = pc ^ ((row >> 1) & 7);
+    if (i < 2) {
+      int gr = m0 + row; gr = gr < p.M ? gr : p.M - 1;
+      asrc[i] = Ap + aa.outer(gr) + c * VEC;
+    }
+    int gc = n0 + row; gc = gc < p.N ? gc : p.N - 1;
+    bsrc[i] = Bp + ab.outer(gc) + c * VEC;
+  }
+  const int dst0 = wave * 1024;
+  auto issue = [&](int kt, int buf) {
+    char* base = dsm + buf * M64_STAGE + dst0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[i] + (long long)kt * BK), (lds_ptr_t)(base + M64_A_BYTES + i * 4096), 16, 0, 0);
+  };
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+  const int nk = p.K / BK;
+  issue(0, 0);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)dsm;
+  const unsigned a_addr0 = lds_off(wr * 32 + frow, fhalf), b_addr0 = M64_A_BYTES + lds_off(wc * 64 + frow, fhalf);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt has landed (this wave's pieces; the barrier publishes everybody's)
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const unsigned cb = lds_base + (kt & 1) * M64_STAGE;
+    const unsigned pa = cb + a_addr0, pb = cb + b_addr0;
+    frag_t fa[2], fb0[2], fb1[2];
+#define M64_READ(S, KG)                                                                                     \
+  fa[S] = lds_read128_asm<frag_t, 0>(pa ^ ((KG) << 5)); fb0[S] = lds_read128_asm<frag_t, 0>(pb ^ ((KG) << 5));           \
+  fb1[S] = lds_read128_asm<frag_t, 4096>(pb ^ ((KG) << 5));
+#define M64_WAIT(S, CNT)                                                                                    \
+  asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[S]), "+v"(fb0[S]), "+v"(fb1[S]) :: "memory");
+#define M64_MMA(S) mma<T>(fa[S], fb0[S], acc0); mma<T>(fa[S], fb1[S], acc1);
+    M64_READ(0, 0)
+    M64_READ(1, 1)
+    M64_WAIT(0, 3)
+    M64_MMA(0) __builtin_amdgcn_sched_barrier(0);
+    M64_READ(0, 2)
+    M64_WAIT(1, 3)
+    M64_MMA(1) __builtin_amdgcn_sched_barrier(0);
+    M64_READ(1, 3)
+    M64_WAIT(0, 3)
+    M64_MMA(0) __builtin_amdgcn_sched_barrier(0);
+    M64_WAIT(1, 0)
+    M64_MMA(1) __builtin_amdgcn_sched_barrier(0);
+#undef M64_READ
+#undef M64_WAIT
+#undef M64_MMA
+  }
+  __syncthreads();
+
+  EpiArgs ea;
+  ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
+  ea.bias = p.bias ? p.bias + (long long)z * p.bias_zs : nullptr;
+  ea.c_ld = p.C.ld; ea.c_bs = p.C.bstride; ea.r_ld = p.R.ld; ea.r_bs = p.R.bstride;
+  ea.p_ld = p.P.ld; ea.p_bs = p.P.bstride; ea.q_ld = p.Cpre.ld; ea.q_bs = p.Cpre.bstride;
+  ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
+  ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
+  ea.atomic = 0;
+  ea.fast = c_vec_ok && (p.N % 8 == 0);
+  ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
+  ea.ctr_base = (unsigned long long)z * (unsigned long long)p.M * (unsigned long long)p.N;
+  {
+    const long long zc = z_off(p.C.zs0, p.C.zs1, z, p.zdiv);
+    if (ea.out_f32) ea.C = reinterpret_cast<float*>(ea.C) + zc; else ea.C = reinterpret_cast<T*>(ea.C) + zc;
+    if (ea.R) {
+      const long long zr = z_off(p.R.zs0, p.R.zs1, z, p.zdiv);
+      if (ea.out_f32) ea.R = reinterpret_cast<const float*>(ea.R) + zr; else ea.R = reinterpret_cast<const T*>(ea.R) + zr;
+    }
+    if (ea.P) ea.P = reinterpret_cast<const T*>(ea.P) + z_off(p.P.zs0, p.P.zs1, z, p.zdiv);
+    if (ea.Cpre) ea.Cpre = reinterpret_cast<T*>(ea.Cpre) + z_off(p.Cpre.zs0, p.Cpre.zs1, z, p.zdiv);
+  }
+  float* stage = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
+  run_epilogue<T, FEAT, T, 1>(ea, stage, acc0, acc1, acc0, acc1, m0 + wr * 32, n0 + wc * 64, lane);
 }
 
 
@@ -1461,6 +1591,40 @@ int launch_glds_feat(const st5_gemm_params& p, int c_vec_ok, dim3 grid, hipStrea
     }
   }
   return launch_glds_as<T, NBUF, -1>(p, c_vec_ok, grid, s);
+}
+
+template <int FEAT>
+int launch_m64_as(const st5_gemm_params& p, int c_vec_ok, dim3 grid, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_m64_kernel<FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return ST5_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_m64_kernel<FEAT>), grid, dim3(NTHREADS), (size_t)2 * M64_STAGE, s, p, c_vec_ok);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+int launch_m64(const st5_gemm_params& p, int c_vec_ok, hipStream_t s) {
+  const int tiles = ((p.M + 63) / 64) * ((p.N + BN - 1) / BN);
+  dim3 grid(tiles, 1, p.batch);
+  switch (nt_feat_of(p, c_vec_ok)) {
+    case 0: return launch_m64_as<0>(p, c_vec_ok, grid, s);
+    case F_GELU | F_PRE: return launch_m64_as<F_GELU | F_PRE>(p, c_vec_ok, grid, s);
+    case F_DROP | F_RES: return launch_m64_as<F_DROP | F_RES>(p, c_vec_ok, grid, s);
+    case F_DACT: return launch_m64_as<F_DACT>(p, c_vec_ok, grid, s);
+    case F_BETA: return launch_m64_as<F_BETA>(p, c_vec_ok, grid, s);
+    case F_RES: return launch_m64_as<F_RES>(p, c_vec_ok, grid, s);
+    default: return launch_m64_as<-1>(p, c_vec_ok, grid, s);
+  }
+}
+// Which NT launches take the half-height tiles: bf16, and at most g_m64_max_tiles tiles of 128^2 (st5_gemm_set_m64_max_tiles; 0 = never)
+int g_m64_max_tiles = 0;      // (default: never -- every isolated gain below was a LOSS inside the update)
+bool nt_m64_pays(const st5_gemm_params& p) {
+  static const int env = getenv("ST5_M64_MAX_TILES") ? atoi(getenv("ST5_M64_MAX_TILES")) : -1;   // (A/B switch for whole-step measurements)
+  const int lim = env >= 0 ? env : g_m64_max_tiles;
+  const long long t128 = (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.batch;
+  return t128 <= lim && p.M > 64;
 }
 
 template <typename T>
@@ -2321,6 +2485,8 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
       return launch_nt8p(p, c_vec_ok, s);
     }
     if (g_nt_tile == 2) return dtype == ST5_BF16 ? launch_nt256<bf16_t>(p, c_vec_ok, s) : launch_nt256<float>(p, c_vec_ok, s);
+    if (g_nt_tile == 5 && dtype == ST5_BF16) return launch_m64(p, c_vec_ok, s);
+    if (g_nt_tile == 0 && dtype == ST5_BF16 && nt_m64_pays(p) && !nt256_pays(p.M, p.N, p.K / 64, p.batch)) return launch_m64(p, c_vec_ok, s);
     if (g_nt_tile == 0 && nt256_pays(p.M, p.N, p.K / 64, p.batch)) {
       // bf16: the phased kernel (round 4); fp32 parity mode: the first 256^2 kernel (4-stage ring)
       if (dtype == ST5_BF16 && p.K % 64 == 0) { g_p8_stagger = 1; return launch_nt8p(p, c_vec_ok, s); }
@@ -2476,4 +2642,5 @@ extern "C" int st5_gemm_set_deep_ring(int max_blocks, int nbuf) {
 /* Weight-gradient (TN) GEMMs without row split / segments: 0 (default) = always the 128^2 LDS-DMA kernel; 1 = phased 256^2 kernel,
  * 2 = the same without the stagger of the two m-halves (A/B measurements; the header documents the same default). */
 extern "C" int st5_gemm_set_tn_phased(int mode) { if (mode < 0 || mode > 2) return ST5_ERR_ARG; g_tn8p = mode; return ST5_OK; }
-extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 4) return ST5_ERR_ARG; g_nt_tile = mode; return ST5_OK; }
+extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 5) return ST5_ERR_ARG; g_nt_tile = mode; return ST5_OK; }
+extern "C" int st5_gemm_set_m64_max_tiles(int tiles) { if (tiles < 0) return ST5_ERR_ARG; g_m64_max_tiles = tiles; return ST5_OK; }

@@ -299,23 +299,43 @@ class FlatGradDataParallel:
         stream_of = (lambda i: cur if i == own else self._fwd_streams[0]) if n == 2 else (lambda i: cur)
         if Fn.wgrad_stream() is not None and n == 2:
             Fn.set_wgrad_owner(cur)
+        # ST5_WGRAD_MOVE=1 (A/B switch, OFF by default): the weight-gradient groups of the micro-batch on the SECOND stream are launched
+        # on the update's own stream, behind the first micro-batch's backward (functional.set_wgrad_target).  The idea: the second
+        # micro-batch -- text -- is the longer chain (21.1 against 17.2 ms alone, tools/r6/chains.py), its weight gradients are off its
+        # critical path and the first stream runs dry early.  Measured (round 6, same box, alternating): 35.0 ms per update against
+        # 29.8 -- every cross-stream edge inside a replayed graph costs more than the idle time it fills, like the third chain of
+        # round 5.  Same bits either way.
+        move = (n == 2 and backward == "side_by_side" and own == 0 and Fn.wgrad_stream() is None and stream_of(1) is not cur
+                and os.environ.get("ST5_WGRAD_MOVE", "0") == "1")
         losses = []
         for i, mb in enumerate(micro_batches):
             with torch.cuda.stream(stream_of(i)):
                 losses.append(forward_loss(mb))
-        for i, loss in enumerate(losses):
-            st = stream_of(i)
-            if i > 0 and backward == "in_turn":
-                st.wait_stream(cur)      # (behind micro-batch 0's backward)
-            with self._grad_slot(i), torch.cuda.stream(st):
-                loss.backward()          # (root gradient on `st`: no dependence on the other micro-batch's stream)
-                Fn.flush_wgrads()        # (the last layers' queued weight gradients of this micro-batch, on its stream)
-                Fn.join_wgrad_stream()   # (no-op unless this stream owns a weight-gradient stream: its slabs folded there, then joined)
-                # this stream's deferred reductions (split-K slabs, LayerNorm partials) are folded on this stream
-                hip.check(hip.lib().st5_layernorm_flush(hip.stream()), "st5_layernorm_flush")
-                hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")
+        try:
+            for i, loss in enumerate(losses):
+                st = stream_of(i)
+                if i > 0 and backward == "in_turn":
+                    st.wait_stream(cur)      # (behind micro-batch 0's backward)
+                if i == 1 and move:
+                    Fn.set_wgrad_target(st, cur)
+                with self._grad_slot(i), torch.cuda.stream(st):
+                    loss.backward()          # (root gradient on `st`: no dependence on the other micro-batch's stream)
+                    Fn.flush_wgrads()        # (the last layers' queued weight gradients of this micro-batch, on its stream)
+                    Fn.join_wgrad_stream()   # (no-op unless this stream owns a weight-gradient stream: its slabs folded there, then joined)
+                    # this stream's deferred reductions (split-K slabs, LayerNorm partials) are folded on this stream
+                    hip.check(hip.lib().st5_layernorm_flush(hip.stream()), "st5_layernorm_flush")
+                    hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")
+        except BaseException:
+            Fn.drop_wgrads()             # (a backward that raised leaves nothing behind for the next update)
+            raise
+        finally:
+            Fn.set_wgrad_target(None, None)
         for st in self._fwd_streams[: n - 1]:
             cur.wait_stream(st)
+        if move:
+            # (groups that fell back to single split-K launches left their slabs pending on `cur`: folded where this wrapper folds
+            #  `cur`'s own -- finish() / sum_gradient_buffers() / FusedAdam.step's callers -- before anybody reads the gradients)
+            Fn.release_wgrad_holds()     # (joined: the operands of the moved groups may go back to the allocator)
         # the update's gradient is flat + flat2: FusedAdam.step reads both (and leaves both zeroed); anyone else gets the sum
         # through sum_gradient_buffers()
         self._pair_pending = n > 1
@@ -514,6 +534,7 @@ class FlatGradDataParallel:
 
     def zero_grad(self):
         assert not self._works, "zero_grad() between backward and finish(): all-reduces are in flight"
+        Fn.drop_wgrads()     # (nothing may be queued across updates: an update that raised half way must not leak into this one)
         if self._grads_zeroed:
             self._grads_zeroed = False      # (FusedAdam's kernel zeroed them while reading)
         else:

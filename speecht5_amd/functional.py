@@ -682,17 +682,54 @@ def set_wgrad_grouping(on):
     _S.__dict__["wgroup"] = bool(on) and WGRAD_GROUP
 
 
+# Where a stream's queued weight-gradient groups are LAUNCHED (round 6; an A/B mode, ddp.accumulate_overlapped / ST5_WGRAD_MOVE=1).
+# With the two micro-batches of an update side by side the text micro-batch is the longer chain (8.1 against 4.75 TFLOP).
+# A layer's weight gradients hang off the backward's critical path -- only the optimizer reads them -- so the groups the TEXT stream
+# queues can be launched on the SPEECH stream instead: ordered behind their producers by an event (st5_stream_fork), behind everything
+# the speech stream was given before (its own backward is enqueued first), writing the text micro-batch's own gradient buffer.  No
+# third stream, same kernels, same bits.  Measured: SLOWER inside a replayed graph (35.0 against 29.8 ms per update): off by default.
+# The operands stay alive until the streams join (release_wgrad_holds): the caching allocator hands a freed block to the next
+# allocation of the stream that OWNS it, which knows nothing about a reader on another stream.
+def set_wgrad_target(src, dst):
+    """Groups queued on torch stream `src` are launched on `dst` (None, None: every stream launches its own)."""
+    _S.__dict__["wq_target"] = None if src is None else (src.cuda_stream, dst)
+
+
+def release_wgrad_holds():
+    _S.__dict__["wq_hold"] = []
+
+
+def _launch_wgrad_group(st, ent):
+    tgt = _S.__dict__.get("wq_target")
+    if tgt is None or tgt[0] != st:
+        hip.gemm_tn_group(ent[0], ent[3])
+        ent[1].clear()
+        return
+    hip.check(hip.lib().st5_stream_fork(st, tgt[1].cuda_stream), "st5_stream_fork")
+    hip.gemm_tn_group(ent[0], ent[3], on=tgt[1])
+    _S.__dict__.setdefault("wq_hold", []).append(ent[1])
+
+
 def flush_wgrads():
     """Launch what the current stream has queued.  (Every stream that issues weight gradients reaches a flush point of its own
     before anybody reads the gradients: ddp.accumulate_overlapped per micro-batch stream, ddp._flush_splitk on the update's stream.)"""
     q = _S.__dict__.get("wq")
     if not q:
         return
-    ent = q.pop(hip.stream(), None)
+    st = hip.stream()
+    ent = q.pop(st, None)
     if ent and ent[0]:
-        hip.gemm_tn_group(ent[0], ent[3])
-        ent[1].clear()
+        _launch_wgrad_group(st, ent)
     assert not any(e[0] for e in q.values()), "weight gradients still queued on another stream at a point where gradients must be complete"
+
+
+def drop_wgrads():
+    """Discard every queued weight-gradient problem and held operand (an update that failed half way: ADVICE r5 -- stale entries
+    would otherwise be launched into the NEXT update's freshly zeroed gradient buffers)."""
+    q = _S.__dict__.get("wq")
+    if q:
+        q.clear()
+    _S.__dict__["wq_hold"] = []
 
 
 def _wgrad_queue(A, B, C, M, N, K, dt, flags, asum, keep):
@@ -702,9 +739,7 @@ def _wgrad_queue(A, B, C, M, N, K, dt, flags, asum, keep):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
 
     def launch():
-        e = q.pop(st)
-        hip.gemm_tn_group(e[0], e[3])
-        e[1].clear()
+        _launch_wgrad_group(st, q.pop(st))
     if ent is not None and ent[0] and (ent[2] + tiles > _WG_ROUND or len(ent[0]) == _WG_MAX or ent[3] != dt
                                        or any(p[2].ptr == C.ptr or (asum is not None and p[8] is not None and p[8].data_ptr() == asum.data_ptr())
                                               for p in ent[0])):

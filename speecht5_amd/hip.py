@@ -44,6 +44,7 @@ _SIGS = {
     "st5_gemm_set_glds": (c_int, [c_int]),
     "st5_stream_fork": (c_int, [c_void_p, c_void_p]),
     "st5_gemm_set_nt_tile": (c_int, [c_int]),
+    "st5_gemm_set_m64_max_tiles": (c_int, [c_int]),
     "st5_gemm_set_splitk_target": (c_int, [c_int]),
     "st5_gemm_set_deep_ring": (c_int, [c_int, c_int]),
     "st5_gemm_set_nt_slots": (c_int, [c_int]),
@@ -347,10 +348,11 @@ def gemm(A, B, C, M, N, K, dtype, *, R=None, P=None, Cpre=None, bias=None, bias_
     check(lib().st5_gemm(byref(p), dtype, stream() if on is None else on.cuda_stream), "st5_gemm")
 
 
-def gemm_tn_group(problems, dtype):
+def gemm_tn_group(problems, dtype, on=None):
     """problems: [(A, B, C, M, N, K, flags, beta, asum)] weight-gradient GEMMs -> ONE launch without split-K (st5_gemm_tn_group;
     the library falls back to one st5_gemm per problem when the group does not qualify).  The caller keeps the operands alive until
-    the call returns (the launch is enqueued on the current stream by then)."""
+    the call returns (the launch is enqueued on the current stream by then).  on: torch.cuda.Stream to launch on instead of the
+    current one (the caller orders it behind the producers: st5_stream_fork, and keeps the operands alive until the streams join)."""
     n = len(problems)
     arr = (GemmParams * n)()
     flops = 0.0
@@ -363,14 +365,15 @@ def gemm_tn_group(problems, dtype):
         p.alpha, p.beta, p.dropout_p, p.seed = 1.0, beta, 0.0, 0
         p.asum = ptr(asum)
         flops += 2.0 * M * N * K
+    raw = stream() if on is None else on.cuda_stream
     if profiler.enabled:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib().st5_gemm_tn_group(arr, n, dtype, stream()), "st5_gemm_tn_group")
-        e1.record()
+        e0.record(on)
+        check(lib().st5_gemm_tn_group(arr, n, dtype, raw), "st5_gemm_tn_group")
+        e1.record(on)
         profiler.records.append((("bf16" if dtype == BF16 else "f32") + "_TN", flops, e0, e1, (problems[0][3], problems[0][4], problems[0][5], n)))
         return
-    check(lib().st5_gemm_tn_group(arr, n, dtype, stream()), "st5_gemm_tn_group")
+    check(lib().st5_gemm_tn_group(arr, n, dtype, raw), "st5_gemm_tn_group")
 
 
 def quant_mxfp8(x2):

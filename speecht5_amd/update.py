@@ -50,8 +50,11 @@ class PretrainUpdate:
         assert exchange_payload in ("fp32", "bf16")
         # several ranks, one-message exchange: the gradient buffer travels as bf16 (half the link bytes; local sums and Adam stay fp32)
         self.exchange_payload = torch.bfloat16 if exchange_payload == "bf16" else None
-        # several ranks + graph: graph = local phase, eager tail = all-reduce + Adam
-        self.split = graph and self.ddp.collectives
+        # several ranks + graph: graph = local phase, eager tail = all-reduce + Adam.  Several ranks WITHOUT a graph and two gradient
+        # buffers (micro != "in_turn"): the same split, enqueued eagerly -- the bucket triggers of the eager overlapped path need ONE
+        # buffer of summed gradients, so accumulate_overlapped() is only legal inside local_phase() (`--gpus N --no-graph`
+        # with the default micro-batch mode used to trip that assert)
+        self.split = self.ddp.collectives and (graph or micro != "in_turn")
         # several ranks + graph + one stream: the exchange is OVERLAPPED with the last micro-batch's backward -- the local phase
         # is captured as three graphs cut at bucket boundaries (ddp.cut_points), and after each of them the bucket range it
         # completed goes to the process group as one asynchronous all-reduce (RCCL's stream) while the next graph runs

@@ -216,6 +216,29 @@ def test_nt_phased_256_tile_forced(cuda, mode, kind):
 
 
 @pytest.mark.parametrize("kind", EPI)
+def test_nt_half_height_tile_bit_equal_to_128(cuda, kind):
+    """gemm_nt_m64_kernel (64 x 128 tiles, three blocks per CU; round 6) forced through st5_gemm_set_nt_tile(5) against the 128^2 kernel
+    (mode 1): M tails inside a 64-row tile (3992 = 62 * 64 + 24, 520, 72), an N tail (776), k-tile counts 1, 2, 3, 12, 48, every epilogue:
+    torch within tolerance and bit-equal (same MFMA chain per output element); and the dispatcher's own choice (mode 0) equals both."""
+    L = hip.lib()
+    for (M, N, K) in [(3992, 768, 768), (520, 776, 128), (72, 128, 64), (2504, 768, 192), (1024, 768, 3072)]:
+        outs = []
+        for mode in (5, 1, 0):
+            hip.check(L.st5_gemm_set_nt_tile(mode), "set_nt_tile")
+            try:
+                outs.append(_run_nt(cuda, torch.bfloat16, M, N, K, kind, seed=6))
+            finally:
+                hip.check(L.st5_gemm_set_nt_tile(0), "set_nt_tile")
+        (C5, ref, extra5), (C1, _, extra1), (C0, _, extra0) = outs
+        _close(C5, ref, torch.bfloat16, f"64x128 tiles {M}x{N}x{K} / {kind}")
+        assert torch.equal(C5, C1), f"64x128 and 128^2 tiles differ bitwise at {M}x{N}x{K} / {kind}"
+        assert torch.equal(C0, C1), f"the dispatcher's choice differs bitwise from 128^2 at {M}x{N}x{K} / {kind}"
+        for k in extra5:
+            _close(extra5[k][0], extra5[k][1], torch.bfloat16, f"64x128 tiles / {kind} / {k}")
+            assert torch.equal(extra5[k][0], extra1[k][0]) and torch.equal(extra0[k][0], extra1[k][0])
+
+
+@pytest.mark.parametrize("kind", EPI)
 def test_nt_five_slot_ring_bit_equal_to_two_stages(cuda, kind):
     """gemm_nt_glds_kernel<.., 5, ..> (five 16 KB operand slots, the default for grids of more than one block per CU) against the
     two-stage ring (st5_gemm_set_nt_slots(4)): same MFMA chain per element -> bit-equal; k-tile counts 2, 3, 5, 12 walk the slot ring

@@ -377,7 +377,7 @@ def test_softmax_dropout_consistency(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,S,C", [(2, 3000, 64), (1, 16000, 512)])
+@pytest.mark.parametrize("B,S,C", [(2, 3000, 64), (1, 16000, 512), (1, 4000, 1024)])
 def test_conv0_groupnorm_gelu(cuda, dtype, B, S, C):
     torch.manual_seed(S)
     k, stride = 10, 5
@@ -444,7 +444,8 @@ def test_conv0_matrix_core_apply_equals_the_valu_apply(cuda, B, S, C):
     assert float((diff > 0).float().mean()) < 0.03, float((diff > 0).float().mean())
 
 
-@pytest.mark.parametrize("B,S,C,k", [(2, 6407, 128, 10), (1, 16000, 512, 10), (2, 4000, 256, 7)])
+@pytest.mark.parametrize("B,S,C,k", [(2, 6407, 128, 10), (1, 16000, 512, 10), (2, 4000, 256, 7), (1, 4000, 1024, 10)])   # (C = 1024: beyond the
+# four channel tiles a wave of the matrix-core backward holds -- the dispatcher must take the VALU kernel there)
 def test_conv0_matrix_core_backward_equals_the_valu_backward(cuda, B, S, C, k):
     """bf16 backward of conv layer 0 on the matrix cores (recomputed convolution and the dz . x products as split-bf16 MFMAs, dz
     transposed through LDS with the gfx950 transpose read, S2 derived from A and S1) against the VALU form on the same inputs: dW,

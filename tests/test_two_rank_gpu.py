@@ -54,6 +54,16 @@ def test_two_ranks_side_by_side_micro_batches_equal_the_one_rank_update(cuda, tm
     assert ranks[0]["digest"] == ranks[1]["digest"] == one["digest"], (ranks[0]["pnorm"], ranks[1]["pnorm"], one["pnorm"])
 
 
+def test_two_ranks_side_by_side_without_a_graph_equal_the_one_rank_update(cuda, tmp_path):
+    """`bench.py --gpus N --no-graph` with the default micro-batch mode -- two gradient buffers and NO captured local
+    phase -- used to reach accumulate_overlapped() outside local_phase() and trip its assert.  The eager several-rank side-by-side
+    update now runs the same split as the replayed one (local phase, one exchange, Adam) and must produce the same bits."""
+    one = _launch(1, "phased", str(tmp_path / "one"), 0)[0]
+    ranks = _launch(2, "one_message", str(tmp_path / "sbs_eager"), 29671, extra=["--micro", "side_by_side", "--no-graph"])
+    assert all(r["split"] and not r["phased"] for r in ranks)
+    assert ranks[0]["digest"] == ranks[1]["digest"] == one["digest"], (ranks[0]["pnorm"], ranks[1]["pnorm"], one["pnorm"])
+
+
 def test_two_ranks_with_their_own_data_exchange_exactly_the_sum_of_their_gradients(cuda, tmp_path):
     """the same-data test above cannot see a reduction that mixes the ranks' buffers.  Here rank r holds its own
     data and seeds, lr = 0 (parameters fixed), and the gradient buffer the optimizer step receives in the 4th update of the two-rank

@@ -17,6 +17,8 @@ if os.environ.get("ST5_NT_SLOTS"):
     L.st5_gemm_set_nt_slots(int(os.environ["ST5_NT_SLOTS"]))
 if os.environ.get("ST5_NT_TILE"):
     L.st5_gemm_set_nt_tile(int(os.environ["ST5_NT_TILE"]))
+if os.environ.get("ST5_M64_MAX_TILES"):
+    L.st5_gemm_set_m64_max_tiles(int(os.environ["ST5_M64_MAX_TILES"]))
 
 
 def nt_cases():
