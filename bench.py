@@ -319,12 +319,12 @@ def main():
     if world > 1 or os.environ.get("ST5_DDP_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        # Only the forms that run collectives UNDERNEATH the backward (in-turn phased replay, eager bucketed exchange) pin RCCL to its ring
+        # The forms that run collectives UNDERNEATH the backward (phased replay -- the default --, eager bucketed exchange) pin RCCL to its ring
         # functions (no packed-fp32 VALU ops in them, unlike the tree / PreMulSum ones: tools/rccl_packed_ops.sh,
         # profiles/r3_rccl_packed_fp32.txt -- a round-3 precaution whose basis round 5 no longer believes to be a hardware hazard,
-        # DESIGN.md 4c, kept because it is free there).  The default form -- side by side, ONE all-reduce behind the local phase, nothing
-        # else on the chip -- leaves the algorithm to RCCL.
-        if a.no_graph or (a.micro == "in_turn" and a.exchange == "phased"):
+        # DESIGN.md 4c, kept because it is free there: 150-230 MB messages on a full mesh are ring territory anyway).  `--exchange
+        # one_message` -- ONE all-reduce behind the local phase, nothing else on the chip -- leaves the algorithm to RCCL.
+        if a.no_graph or (a.micro in ("in_turn", "side_by_side") and a.exchange == "phased"):
             os.environ.setdefault("NCCL_ALGO", "Ring")
         if shared:
             dist.init_process_group("gloo", rank=rank, world_size=world)

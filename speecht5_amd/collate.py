@@ -129,3 +129,132 @@ class SpeechPretrainCollater:
         return batch
 
     __call__ = collater
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the remaining collaters of the reference input pipeline: text-to-speech fine-tuning, speech-to-text
+# fine-tuning, text pre-training (+ its BART noise, speecht5_amd/text_noise.py).  Same design: lengths are host ints, every tensor of
+# the batch is a ragged gather over items resident in HBM, nothing passes through host memory.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _lengths(n, device):
+    return torch.tensor([int(v) for v in n], dtype=torch.long).to(device, non_blocking=True)
+
+
+def _pad_tokens(items, lens, B, T, pad, device, order=None, shift=False):
+    """fairseq.data.data_utils.collate_tokens(values, pad, left_pad=False) as one gather: out[b, t] = items[b][t] (t < len) else pad;
+    shift=True is its move_eos_to_beginning form with eos_idx=None: out[b, 0] = the item's LAST token, out[b, 1:] = items[b][:-1]."""
+    if order is not None:
+        items, lens = [items[i] for i in order], [lens[i] for i in order]
+    if not shift:
+        return _ragged(items, [0] * B, lens, B, T, 1, 1, 0, torch.int64, int(pad), device)
+    out = _ragged(items, [-1] * B, [l - 1 for l in lens], B, T, 1, 1, 1, torch.int64, int(pad), device)
+    first = _ragged(items, [l - 1 for l in lens], lens, B, 1, 1, 1, 0, torch.int64, int(pad), device)
+    out[:, 0] = first[:, 0]       # (one strided copy: glue)
+    out._st5_keep = out._st5_keep + (first,)
+    return out
+
+
+class TextToSpeechCollater:
+    """TextToSpeechDataset.collater (data/text_to_speech_dataset.py:228-281) + _collate_frames (:27-45) + collater_label (:289-298).
+    samples: [{"id", "audio_name", "source": [int64 [n] (device)], "target": fp32 [L, odim] (device), "spkembs": fp32 [D] (device)}]."""
+
+    def __init__(self, device, *, pad_idx=1, reduction_factor=2):
+        self.device, self.pad_idx, self.reduction_factor = device, pad_idx, reduction_factor
+
+    def collater(self, samples):
+        samples = [s for s in samples if s["source"] is not None]
+        if not samples:
+            return {}
+        dev, B, r = self.device, len(samples), self.reduction_factor
+        fbanks = [s["target"].contiguous() for s in samples]
+        sizes = [int(f.shape[0]) for f in fbanks]
+        odim, Lmax = int(fbanks[0].shape[1]), max(sizes)
+        dec_target = _ragged(fbanks, [0] * B, sizes, B, Lmax, odim, 1, 0, torch.float32, 0.0, dev)
+        dec_lengths = _lengths(sizes, dev)
+        # decoder input (:239-248): frames r-1, 2r-1, ... of the PADDED batch, shifted right by one behind a zero frame
+        Lin = len(range(r - 1, Lmax, r)) if r > 1 else Lmax
+        prev = _ragged(fbanks, [-1] * B, sizes, B, Lin, odim, r, 1, torch.float32, 0.0, dev)
+        tgt_lengths = _lengths([l // r for l in sizes], dev) if r > 1 else dec_lengths
+        labels = _tail([l - 1 for l in sizes], B, Lmax, True, dev)                 # (:251-253: 1.0 from the last frame on)
+        spk = [s["spkembs"].contiguous() for s in samples]
+        spkembs = _ragged(spk, [0] * B, [int(v.shape[0]) for v in spk], B, max(int(v.shape[0]) for v in spk), 1, 1, 0, torch.float32, 0.0, dev)
+        toks = [s["source"][0].contiguous() for s in samples]
+        tlen = [int(t.shape[0]) for t in toks]
+        src_tokens = _pad_tokens(toks, tlen, B, max(tlen), self.pad_idx, dev)
+        src_lengths = _lengths(tlen, dev)
+        net_input = {"src_tokens": src_tokens, "src_lengths": src_lengths, "prev_output_tokens": prev, "tgt_lengths": tgt_lengths,
+                     "spkembs": spkembs, "task_name": "t2s"}
+        return {"id": torch.LongTensor([s["id"] for s in samples]), "name": [s.get("audio_name") for s in samples], "net_input": net_input,
+                "labels": labels, "dec_target": dec_target, "dec_target_lengths": dec_lengths, "src_lengths": src_lengths, "task_name": "t2s",
+                "ntokens": int(sum(tlen)), "target": dec_target}
+
+    __call__ = collater
+
+
+class SpeechToTextCollater:
+    """SpeechToTextDataset.collater (data/speech_to_text_dataset.py:150-207) + collater_audio (:209-224) + collater_label (:232-241).
+    samples: [{"id", "source": fp32 [S] (device), "label_list": [int64 [n] (device)]}]."""
+
+    def __init__(self, device, *, pad_idx=1, eos_idx=2):
+        self.device, self.pad_idx, self.eos_idx = device, pad_idx, eos_idx
+
+    def collater(self, samples):
+        samples = [s for s in samples if s["source"] is not None]
+        if not samples:
+            return {}
+        dev, B = self.device, len(samples)
+        audios = [s["source"].contiguous() for s in samples]
+        sizes = [int(a.shape[0]) for a in audios]
+        S = max(sizes)
+        source = _ragged(audios, [0] * B, sizes, B, S, 1, 1, 0, torch.float32, 0.0, dev)
+        padding_mask = _tail(sizes, B, S, False, dev)
+        labs = [s["label_list"][0].contiguous() for s in samples]
+        n = [int(t.shape[0]) for t in labs]
+        T = max(n) + 1
+        rows = torch.arange(B, device=dev)
+        nd = _lengths(n, dev)
+        # decoder target (:167-181): label + </s>, right-padded; decoder input (:183-189): </s> moved to the front
+        target = _pad_tokens(labs, n, B, T, self.pad_idx, dev)
+        target[rows, nd] = self.eos_idx
+        prev = _ragged(labs, [-1] * B, n, B, T, 1, 1, 1, torch.int64, self.pad_idx, dev)
+        prev[:, 0] = self.eos_idx
+        net_input = {"source": source, "padding_mask": padding_mask, "prev_output_tokens": prev, "task_name": "s2t"}
+        return {"id": torch.LongTensor([s["id"] for s in samples]), "net_input": net_input, "target": target,
+                "target_lengths": _lengths([v + 1 for v in n], dev), "task_name": "s2t", "ntokens": int(sum(n))}
+
+    __call__ = collater
+
+
+class TextPretrainCollater:
+    """collate() of data/text_dataset.py:18-99 (TextPretrainDataset.collater :435-444): source / target right-padded, the batch sorted by
+    descending SOURCE length (the reference's own torch sort on the host lengths: the tie order is part of the batch), the decoder
+    input = target with its last token moved to the front.  samples: [{"id", "source": int64 [n] (device), "target": int64 [m] (device)}],
+    e.g. from text_noise.BartNoise (the noise draws are host state in the reference: torch's CPU generator)."""
+
+    def __init__(self, device, *, pad_idx=1):
+        self.device, self.pad_idx = device, pad_idx
+
+    def collater(self, samples):
+        if not samples:
+            return {}
+        dev, B = self.device, len(samples)
+        src = [s["source"].contiguous() for s in samples]
+        slen = [int(t.numel()) for t in src]
+        src_lengths, sort_order = torch.LongTensor(slen).sort(descending=True)
+        order = sort_order.tolist()
+        ids = torch.LongTensor([s["id"] for s in samples]).index_select(0, sort_order)
+        src_tokens = _pad_tokens(src, slen, B, max(slen), self.pad_idx, dev, order=order)
+        batch = {"id": ids, "net_input": {"src_tokens": src_tokens, "src_lengths": src_lengths.to(dev, non_blocking=True)},
+                 "nsentences": int(samples[0]["source"].size(0)), "sort_order": sort_order, "task_name": "text_pretrain"}
+        if samples[0].get("target") is not None:
+            tgt = [s["target"].contiguous() for s in samples]
+            tlen = [int(t.numel()) for t in tgt]
+            batch["target"] = _pad_tokens(tgt, tlen, B, max(tlen), self.pad_idx, dev, order=order)
+            batch["net_input"]["prev_output_tokens"] = _pad_tokens(tgt, tlen, B, max(tlen), self.pad_idx, dev, order=order, shift=True)
+            batch["ntokens"] = int(sum(tlen))
+        else:
+            batch["target"] = None
+            batch["ntokens"] = int(sum(slen))
+        return batch
+
+    __call__ = collater

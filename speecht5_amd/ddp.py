@@ -122,6 +122,7 @@ class FlatGradDataParallel:
         self._grads_zeroed = False   # the optimizer left both buffers zeroed: the next zero_grad() has nothing to do
         self._ready = [False] * len(self.buckets)
         self._next = 0
+        self._sum_next = 0       # sum_bucket_range(): first bucket whose two gradient buffers are not summed yet
         self._works = []
         Fn.set_layer_boundary_hook(self._boundary)
         # A TIED parameter (the text embedding = the decoder's output projection) has several writers -- the embedding backward's
@@ -190,10 +191,22 @@ class FlatGradDataParallel:
             if ent is None:
                 ent = ("shared", x, [])
                 self._cuts.append(ent)
-            region = sum(1 for c in self._cuts if c[0] != "shared")
+            region = sum(1 for c in self._cuts if c[0] not in ("shared", "bypass"))
             if not ent[2] or ent[2][-1][0] != region:
                 ent[2].append((region, x.detach().requires_grad_(True)))
             return ent[2][-1][1]
+        if tag == "bypass":
+            # A loss term that reads a tensor produced EARLY in the forward directly (the feature penalty on the convolution stack's
+            # output, speech_encoder_prenet.py:172-176): its gradient path crosses no layer boundary, so the first phase of a cut
+            # backward (loss.backward()) would run the producer's backward at once, with the penalty's gradient alone, and the phase
+            # that brings the main gradient would run it a second time.  Under cut_points() the term reads a leaf; backward_phases()
+            # hands the leaf's gradient to the producer as an extra root of the phase that runs the producer's region: one backward
+            # through the producer, the two contributions summed by autograd as in the uncut graph (two addends: order-free).
+            if not self._cut_set or not x.requires_grad:
+                return x
+            leaf = x.detach().requires_grad_(True)
+            self._cuts.append(("bypass", x, leaf, sum(1 for c in self._cuts if c[0] not in ("shared", "bypass"))))
+            return leaf
         bi = self.module_bucket.get((id(module), tag))
         if bi is not None and self._cut_set is not None and bi in self._cut_set and x.requires_grad:
             # phased backward (cut_points): everything BEHIND this point hangs off a fresh leaf, so a backward pass stops here
@@ -272,25 +285,7 @@ class FlatGradDataParallel:
         assert n <= 2, "accumulate_overlapped: at most two micro-batches per update"
         assert not self.collectives or self._local_phase, \
             "accumulate_overlapped with several ranks: inside local_phase(), followed by all_reduce_gradients()"
-        cur = torch.cuda.current_stream()
-        if not self._fwd_streams and n > 1 and os.environ.get("ST5_DEEP_RING") is None:   # (the env switch: bench.py A/B)
-            # side by side, a one-block-per-CU GEMM grid gets its latency cover from the other stream's blocks; the deep operand
-            # ring of csrc/gemm.hip (128 KB of LDS per block) would keep those off the CU: 37.7 vs 38.3 ms per update
-            hip.check(hip.lib().st5_gemm_set_deep_ring(0, 2), "st5_gemm_set_deep_ring")
-        while len(self._fwd_streams) < n - 1:
-            # ST5_SERIAL_MICRO=1 (debug): the "second stream" IS the current stream -- same program, same two gradient buffers,
-            # no concurrency at all (the reference point when hunting a race between the micro-batches' kernels)
-            # ST5_SBS_PRIORITY (A/B): HIP priority of the second micro-batch's stream (-1 = high).  The text micro-batch is the longer
-            # chain (8.1 against 4.75 TFLOP): whatever it gains while both are resident comes off the update's critical path.
-            prio = int(os.environ.get("ST5_SBS_PRIORITY", "0"))
-            self._fwd_streams.append(cur if os.environ.get("ST5_SERIAL_MICRO") == "1"
-                                     else torch.cuda.Stream(device=self.flat.device, priority=prio))
-        if n > 1 and self.flat2 is None:
-            # the second gradient buffer is created (and zero-filled) HERE, on the current stream, before the streams fork: created
-            # lazily inside the second backward it was zero-filled on this stream while the other stream already accumulated into it
-            self._make_flat2()
-        for st in self._fwd_streams[: n - 1]:
-            st.wait_stream(cur)          # every forward starts from here (what precedes: zero_grad, the previous update)
+        cur = self.pair_streams(n)
         # Which micro-batch owns the update's own stream (`cur`)?  Default: the first.  ST5_SBS_OWNER=1 (A/B) gives it to the SECOND
         # (host enqueue order, gradient buffers and random draws unchanged -- only the stream assignment swaps), and with a
         # weight-gradient stream (ST5_WGRAD_STREAM=1) that micro-batch's weight-gradient GEMMs fork to it: a third concurrent chain
@@ -320,11 +315,8 @@ class FlatGradDataParallel:
                     Fn.set_wgrad_target(st, cur)
                 with self._grad_slot(i), torch.cuda.stream(st):
                     loss.backward()          # (root gradient on `st`: no dependence on the other micro-batch's stream)
-                    Fn.flush_wgrads()        # (the last layers' queued weight gradients of this micro-batch, on its stream)
-                    Fn.join_wgrad_stream()   # (no-op unless this stream owns a weight-gradient stream: its slabs folded there, then joined)
-                    # this stream's deferred reductions (split-K slabs, LayerNorm partials) are folded on this stream
-                    hip.check(hip.lib().st5_layernorm_flush(hip.stream()), "st5_layernorm_flush")
-                    hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")
+                    # the last layers' queued weight gradients and this stream's deferred reductions are folded on this stream
+                    self.flush_stream_deferred()
         except BaseException:
             Fn.drop_wgrads()             # (a backward that raised leaves nothing behind for the next update)
             raise
@@ -340,6 +332,62 @@ class FlatGradDataParallel:
         # through sum_gradient_buffers()
         self._pair_pending = n > 1
         return [l.detach() for l in losses]
+
+    def pair_streams(self, n):
+        """Streams and buffers of n (<= 2) micro-batches side by side: the current stream for micro-batch 0, a stream of its own for
+        micro-batch 1 (created once, ordered behind the current stream here), the second gradient buffer.  Returns the current stream."""
+        from . import hip
+        cur = torch.cuda.current_stream()
+        if not self._fwd_streams and n > 1 and os.environ.get("ST5_DEEP_RING") is None:   # (the env switch: bench.py A/B)
+            # side by side, a one-block-per-CU GEMM grid gets its latency cover from the other stream's blocks; the deep operand
+            # ring of csrc/gemm.hip (128 KB of LDS per block) would keep those off the CU: 37.7 vs 38.3 ms per update
+            hip.check(hip.lib().st5_gemm_set_deep_ring(0, 2), "st5_gemm_set_deep_ring")
+        while len(self._fwd_streams) < n - 1:
+            # ST5_SERIAL_MICRO=1 (debug): the "second stream" IS the current stream -- same program, same two gradient buffers,
+            # no concurrency at all (the reference point when hunting a race between the micro-batches' kernels)
+            # ST5_SBS_PRIORITY (A/B): HIP priority of the second micro-batch's stream (-1 = high).  The text micro-batch is the longer
+            # chain (8.1 against 4.75 TFLOP): whatever it gains while both are resident comes off the update's critical path.
+            prio = int(os.environ.get("ST5_SBS_PRIORITY", "0"))
+            self._fwd_streams.append(cur if os.environ.get("ST5_SERIAL_MICRO") == "1"
+                                     else torch.cuda.Stream(device=self.flat.device, priority=prio))
+        if n > 1 and self.flat2 is None:
+            # the second gradient buffer is created (and zero-filled) HERE, on the current stream, before the streams fork: created
+            # lazily inside the second backward it was zero-filled on this stream while the other stream already accumulated into it
+            self._make_flat2()
+        for st in self._fwd_streams[: n - 1]:
+            st.wait_stream(cur)          # every forward / phase starts from here (what precedes: zero_grad, the previous phase)
+        return cur
+
+    def flush_stream_deferred(self):
+        """Fold what the CURRENT stream has deferred (queued weight-gradient groups, LayerNorm partials, split-K slabs): the end of a
+        micro-batch's backward -- or of one phase of it -- on that micro-batch's stream."""
+        from . import hip
+        Fn.flush_wgrads()
+        Fn.join_wgrad_stream()
+        hip.check(hip.lib().st5_layernorm_flush(hip.stream()), "st5_layernorm_flush")
+        hip.check(hip.lib().st5_gemm_flush_splitk(hip.stream()), "st5_gemm_flush_splitk")
+
+    def sum_bucket_range(self, upto):
+        """flat[range] += flat2[range] (and flat2[range] = 0) for the buckets [first not yet summed .. upto] (None: the rest): the
+        side-by-side phased exchange hands a bucket range to the process group as soon as BOTH micro-batches' backward passes have
+        completed it, and the group reduces ONE buffer.  x + y in fp32, like the pair kernels of FusedAdam: same bits as the one-rank
+        update.  On the current stream (the caller has joined the second micro-batch's stream)."""
+        from . import hip
+        nb = len(self.buckets)
+        hi = nb - 1 if upto is None else min(upto, nb - 1)
+        lo = self._sum_next
+        if lo > hi or self.flat2 is None:
+            self._sum_next = max(lo, hi + 1)
+            return
+        s, e = self.buckets[lo][0], self.buckets[hi][1]
+        if self.flat.is_cuda:
+            es = self.flat.element_size()
+            hip.check(hip.lib().st5_axpby(self.flat2.data_ptr() + s * es, self.flat.data_ptr() + s * es, e - s, 1.0, 1.0, hip.F32, hip.stream()),
+                      "st5_axpby")
+        else:
+            self.flat[s:e].add_(self.flat2[s:e])
+        self.flat2[s:e].zero_()
+        self._sum_next = hi + 1
 
     @contextlib.contextmanager
     def local_phase(self):
@@ -370,8 +418,9 @@ class FlatGradDataParallel:
         """The backward of a forward built under cut_points(), as a list of callables in execution order: phase 0 runs from
         the loss to the LAST cut of the forward, phase k continues behind the k-th cut from the end.  Returns [(fn, bucket)]:
         after fn() every bucket up to and including `bucket` is complete (None for the final phase: everything is)."""
-        real = [c for c in cuts if c[0] != "shared"]
+        real = [c for c in cuts if c[0] not in ("shared", "bypass")]
         shared = [c for c in cuts if c[0] == "shared"]      # (tag "shared" of _boundary: (_, producer output, [(region, leaf)]))
+        bypass = [c for c in cuts if c[0] == "bypass"]      # (tag "bypass": (_, producer output, the loss term's leaf, region))
         m = len(real)
         carry = [None] * len(shared)     # per shared tensor: the folded gradient of the regions already run
 
@@ -392,9 +441,28 @@ class FlatGradDataParallel:
                         roots.append(lf)               # a root's gradient reaches the leaf's buffer before anything this phase computes
                         grads.append(carry[i])
                         carry[i] = None
+                for _, bx, bleaf, rg in bypass:
+                    if rg == r and k > 0 and bleaf.grad is not None:
+                        roots.append(bx)               # the held-back gradient of a loss term's tap, with the region's main gradient
+                        grads.append(bleaf.grad)
+                        bleaf.grad = None
                 if k == 0:
                     assert not roots
-                    loss.backward()
+                    here = [c for c in bypass if c[3] == r]
+                    if here:
+                        # a tap in the loss's OWN region (no cut between them): first the taps' gradients alone, then one pass from the
+                        # loss and the tapped tensors together (the short loss -> tap paths are walked twice; nothing else is)
+                        leaves = [c[2] for c in here]
+                        torch.autograd.backward([loss], inputs=leaves, retain_graph=True)
+                        gs = [lf.grad for lf in leaves]
+                        for lf in leaves:
+                            lf.grad = None
+                        keep = [(c[1], g) for c, g in zip(here, gs) if g is not None]
+                        torch.autograd.backward([loss] + [x for x, _ in keep], [None] + [g for _, g in keep])
+                        for lf in leaves:
+                            lf.grad = None
+                    else:
+                        loss.backward()
                 elif roots:
                     torch.autograd.backward(roots, grads)
                 for i, (lf, ent) in enumerate(zip(mine, shared)):
@@ -530,6 +598,7 @@ class FlatGradDataParallel:
     def _reset_round(self):
         self._ready = [False] * len(self.buckets)
         self._next = 0
+        self._sum_next = 0
         self._works = []
 
     def zero_grad(self):

@@ -222,8 +222,8 @@ def layer_boundary(x, module, tag=None):
     through the skip path) applies the boundary first; the layer's own call then returns the same tensor."""
     if _S.boundary_hook is None:
         return x
-    if tag == "shared":     # (a tensor read by every layer of a stack, asked for once per layer: ddp._boundary)
-        return _S.boundary_hook(x, module, tag)
+    if tag in ("shared", "bypass"):     # (shared: a tensor read by every layer of a stack, asked for once per layer; bypass: a loss
+        return _S.boundary_hook(x, module, tag)   # term's tap on an early tensor -- ddp._boundary)
     key = (id(module), tag)
     if getattr(x, "_st5_boundary", None) == key:
         return x

@@ -146,7 +146,9 @@ class SpeechEncoderPrenet(nn.Module):
                 x = self.feature_extractor(src_tokens)
         if target_list is not None:
             x, target_list = self.forward_targets(x, target_list)
-        features_pen = Fn.mean_square(x) if require_feat_pen else None
+        # (the penalty reads the features through a "bypass" boundary: a path from the loss to the convolution stack that crosses none of
+        #  the encoder's layer boundaries -- a backward cut at those boundaries must hold its gradient back until the stack's own phase)
+        features_pen = Fn.mean_square(Fn.layer_boundary(x, self, "bypass")) if require_feat_pen else None
         x = self.layer_norm(x)
         encoder_padding_mask = self.forward_padding_mask(x, padding_mask)
         if self.post_extract_proj is not None:

@@ -16,10 +16,10 @@ arithmetic: every mode produces the SAME bits, tests/test_bench_update_gpu.py an
              "in_turn"       one stream, one gradient buffer, ddp.accumulate: the reference trainer's order
              "in_turn_2buf"  two streams / two gradient buffers, the second backward ordered behind the first
   graph      True: the update (one rank) or its local phase (several ranks) is captured once and replayed
-  several ranks, graph: the captured part is the LOCAL phase (zero_grad, both micro-batches); with micro="in_turn",
-             exchange="phased" cuts it into three graphs and all-reduces each completed bucket range under the next one;
-             otherwise ("one_message", and always with the micro-batches side by side) one graph and one all-reduce of the whole
-             buffer behind it; Adam follows eagerly
+  several ranks, graph: the captured part is the LOCAL phase (zero_grad, both micro-batches); exchange="phased" (default) cuts it
+             into three graphs and all-reduces each completed bucket range under the next one -- with micro="side_by_side" (round 6)
+             both micro-batches run inside every phase on two streams and a range is summed over the two gradient buffers before it
+             goes out; "one_message": one graph and one all-reduce of the whole buffer behind it; Adam follows eagerly
 """
 import os
 
@@ -60,8 +60,12 @@ class PretrainUpdate:
         # completed goes to the process group as one asynchronous all-reduce (RCCL's stream) while the next graph runs
         # (exchange="one_message": one graph + one all-reduce of the whole buffer afterwards, the round-2 form)
         # (ST5_EAGER_PHASED=1: the same three phases enqueued eagerly -- the tests' reference point)
+        # micro="side_by_side" (round 6, the default form): the same phases with BOTH micro-batches inside each of them, on two
+        # streams forked from and joined into the phase's graph; a bucket range goes out once both backward passes have completed it
+        # and its two gradient buffers are summed (phase_fns_side_by_side)
         self.phased = ((self.split or (self.ddp.collectives and os.environ.get("ST5_EAGER_PHASED") == "1"))
-                       and micro == "in_turn" and exchange == "phased" and len(self.micro) >= 1)
+                       and micro in ("in_turn", "side_by_side") and exchange == "phased" and len(self.micro) >= 1
+                       and (micro == "in_turn" or len(self.micro) == 2))
         if self.phased and not self.ddp.overlap_exchange:    # (decided once per group in FlatGradDataParallel, the same on every rank)
             self.phased = False      # one message behind the local phase: no collective beside the backward's kernels
         self._ph = None
@@ -95,8 +99,10 @@ class PretrainUpdate:
 
     # -- phased local part (several ranks, overlapped exchange) ------------------------------------------------------------
     def cut_buckets(self):
-        """Where the last micro-batch's backward is cut: behind the decoder (+ both heads, the shared cross-attention K/V
-        projection: ~60 M parameters complete) and in the middle of the encoder stack."""
+        """Where the backward is cut: behind the decoder (+ both heads, the shared cross-attention K/V projection: ~60 M parameters
+        complete) and inside the encoder stack -- at the input of layer L/3 (Base: layer 4), so that the LAST message, the one nothing
+        is left to hide, is the smallest: 234 / 227 / 156 MB for Base (round 5 cut at L/2: 234 / 170 / 213 MB).  ST5_ENC_CUT=<layer>
+        moves the second cut (A/B)."""
         mb = self.ddp.module_bucket
         enc = getattr(self.model, "encoder", None)
         cuts = []
@@ -104,8 +110,9 @@ class PretrainUpdate:
             if (id(enc), "out") in mb:
                 cuts.append(mb[(id(enc), "out")])
             layers = list(getattr(enc, "layers", []))
-            if len(layers) >= 4 and (id(layers[len(layers) // 2]), None) in mb:
-                cuts.append(mb[(id(layers[len(layers) // 2]), None)])
+            at = int(os.environ.get("ST5_ENC_CUT", len(layers) // 3))
+            if len(layers) >= 4 and 0 < at < len(layers) and (id(layers[at]), None) in mb:
+                cuts.append(mb[(id(layers[at]), None)])
         return sorted(set(cuts))
 
     def phase_fns(self):
@@ -156,6 +163,71 @@ class PretrainUpdate:
             return fn
         return [first] + [later(k) for k in range(1, nph)], [reduce_after(k) for k in range(nph)]
 
+    def phase_fns_side_by_side(self):
+        """phase_fns() for the two micro-batches SIDE BY SIDE: every phase forks the second micro-batch's stream from the phase's own
+        and joins it again, so each phase is one graph with two branches (the form the one-graph local phase already has); both
+        forward passes run under cut_points() and keep their own list of backward phases; nominal phase k runs each micro-batch's
+        backward, on its stream and into its gradient buffer, until bucket cuts[k] is complete in BOTH, folds each stream's deferred
+        reductions, joins, sums the two buffers over the completed bucket range (ddp.sum_bucket_range: flat += flat2, fp32, the sum the
+        pair kernels of the one-rank optimizer step form) -- and the caller hands that range of `flat` to the process group while the
+        next phase's graph runs.  Bucket ranges are static (see phase_fns)."""
+        import torch
+        ddp, cuts_b = self.ddp, self.cut_buckets()
+        nph = len(cuts_b) + 1
+        nb = len(ddp.buckets)
+        st = {}
+
+        def streams():
+            cur = ddp.pair_streams(2)           # (forks the second stream from the current one)
+            return cur, [cur, ddp._fwd_streams[0]]
+
+        def run_until(i, b):                    # micro-batch i's backward phases until bucket b (None: every bucket) is complete
+            ph = st["ph"][i]
+            while st["done"][i] < len(ph) and (b is None or st["complete"][i] < b):
+                fn, upto = ph[st["done"][i]]
+                fn()
+                st["complete"][i] = nb - 1 if upto is None else upto
+                st["done"][i] += 1
+
+        def backward_to(k, first=False, forked=None):
+            cur, ss = forked if forked is not None else streams()
+            for i in (0, 1):
+                with ddp._grad_slot(i), torch.cuda.stream(ss[i]), ddp.local_phase():
+                    if first:
+                        fn, upto = st["ph"][i][0]      # (from the loss to the last materialised cut: always runs here)
+                        fn()
+                        st["complete"][i] = nb - 1 if upto is None else upto
+                        st["done"][i] = 1
+                    run_until(i, cuts_b[k] if k < len(cuts_b) else None)
+                    ddp.flush_stream_deferred()
+            cur.wait_stream(ss[1])
+            ddp.sum_bucket_range(cuts_b[k] if k < len(cuts_b) else None)
+
+        def first():
+            ddp.zero_grad()
+            cur, ss = streams()
+            st["ph"], st["done"], st["complete"] = [None, None], [0, 0], [-1, -1]
+            with ddp.local_phase():
+                for i, mb in enumerate(self.micro):
+                    with torch.cuda.stream(ss[i]), ddp.cut_points(cuts_b) as cuts:
+                        loss = self._fwd(mb)
+                    st["ph"][i] = ddp.backward_phases(loss, cuts)
+            backward_to(0, first=True, forked=(cur, ss))     # (no join between forward and backward: each chain runs on)
+
+        def later(k):
+            def fn():
+                backward_to(k)
+                if k == nph - 1:
+                    st["ph"] = None             # (the autograd graphs of this update may go)
+            return fn
+
+        def reduce_after(k):
+            def fn():
+                ddp.reduce_bucket_range(cuts_b[k] if k < len(cuts_b) else None)
+            return fn
+        self._ph_sbs = st
+        return [first] + [later(k) for k in range(1, nph)], [reduce_after(k) for k in range(nph)]
+
     def finish_exchange_and_update(self):
         self.ddp.check_grad_views()
         self.ddp.wait_reductions()
@@ -169,7 +241,7 @@ class PretrainUpdate:
     def step(self):
         """One update enqueued on the current stream (no host synchronisation)."""
         if self.phased:
-            for fn, bt in zip(*self.phase_fns()):
+            for fn, bt in zip(*(self.phase_fns() if self.mode == "in_turn" else self.phase_fns_side_by_side())):
                 fn()
                 bt()
             self.finish_exchange_and_update()
@@ -211,7 +283,7 @@ class PretrainUpdate:
         """Two recording updates + capture (three updates' worth of host random draws; two of them executed)."""
         from .graph import StepGraph
         if self.phased:
-            phases, between = self.phase_fns()
+            phases, between = self.phase_fns() if self.mode == "in_turn" else self.phase_fns_side_by_side()
             self.sg = StepGraph(None, opt=self.opt, model=self.model, device=self.device, on_step=self.advance,
                                 prefetch_host=self.prefetch_host, after_fn=self.finish_exchange_and_update, stream=self.stream,
                                 phases=phases, between=between)
@@ -244,6 +316,7 @@ class PretrainUpdate:
             self.sg.step_fn = self.sg.after_fn = self.sg.on_step = self.sg.phases = self.sg.between = None   # not wait for the cyclic
             self.sg.graph = self.sg.graphs = None    # collector (a collection during a LATER capture destroys it mid-capture)
             self._ph = None
+            self._ph_sbs = None
             self.sg = None
 
     def state(self):

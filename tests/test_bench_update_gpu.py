@@ -129,11 +129,20 @@ def test_several_rank_forms_of_the_update_equal_the_one_rank_update(cuda):
             assert info["split"] and info["overlap"] and info["phased"] == (exchange == "phased"), info
             assert got[3] == ref[3] == 5
             _same(ref, got, f"several-rank form ({exchange}) vs one-rank update")
-        # what `bench.py --gpus N` runs BY DEFAULT: micro-batches side by side inside the replayed local phase, one all-reduce behind it
+        # what `bench.py --gpus N` runs BY DEFAULT (round 6): micro-batches side by side INSIDE every one of the three phase graphs, a
+        # bucket range summed over the two gradient buffers and all-reduced as soon as both backward passes have completed it
         info = {}
         got = _run(cuda, True, "side_by_side", 5, exchange="phased", info=info)
+        assert info["split"] and info["phased"] and info["overlap"], info
+        _same(ref, got, "several-rank default form (side by side, phased exchange) vs one-rank update")
+        info = {}
+        got = _run(cuda, True, "side_by_side", 5, exchange="one_message", info=info)
         assert info["split"] and not info["phased"], info
-        _same(ref, got, "several-rank default form (side by side, one message) vs one-rank update")
+        _same(ref, got, "several-rank form (side by side, one message) vs one-rank update")
+        info = {}
+        eager = _run(cuda, False, "side_by_side", 5, exchange="phased", info=info)   # the same side-by-side phases enqueued eagerly
+        assert info["phased"], info
+        _same(ref, eager, "eager side-by-side phased vs one-rank replay")
         info = {}
         eager = _run(cuda, False, "in_turn", 5, exchange="phased", info=info)      # the same phases enqueued eagerly (ST5_EAGER_PHASED)
         assert info["phased"] and not info["split"], info

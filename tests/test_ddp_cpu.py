@@ -313,3 +313,59 @@ def test_shared_tensor_when_no_cut_materialises_or_the_cut_is_the_first_layer():
                 assert torch.equal(p.grad, ref[n]), (cut_layers, n, float((p.grad - ref[n]).abs().max()))
     finally:
         ddp.close()
+
+
+class _TappedStack(nn.Module):
+    """A front end whose output feeds a layer stack AND, directly, a penalty term of the loss (the feature penalty on the convolution
+    stack's output, speech_encoder_prenet.py:172-176): a path from the loss to the front end that crosses no layer boundary."""
+
+    def __init__(self, d=16):
+        super().__init__()
+        self.front = nn.Linear(d, d)
+        self.layers = nn.ModuleList([Layer(d) for _ in range(4)])
+        self.head = nn.Linear(d, 1)
+        self.front_runs = 0
+
+    def forward(self, x):
+        f = torch.tanh(self.front(x))
+        f.register_hook(lambda g: setattr(self, "front_runs", self.front_runs + 1))
+        pen = Fn.layer_boundary(f, self, "bypass").pow(2).mean()
+        x = f
+        for l in self.layers:
+            x = l(x)
+        return self.head(Fn.layer_boundary(x, self, "out")).sum() + 10.0 * pen
+
+
+def test_loss_term_tapping_an_early_tensor_survives_a_cut_backward():
+    """Round 6 (the speech micro-batch inside a phased backward): without the "bypass" boundary the first phase's loss.backward() runs
+    the front end's backward with the penalty's gradient alone and the last phase runs it AGAIN ("backward through the graph a second
+    time").  With it the tap's gradient is held back and joins the main gradient as a root of the front end's own phase: one backward
+    through the front end, the uncut backward's bits -- with two cuts, one cut, and when no cut materialises (tap in the loss's region)."""
+    from speecht5_amd.ddp import BucketGroup, FlatGradDataParallel
+    torch.manual_seed(5)
+    model = _TappedStack()
+    ddp = FlatGradDataParallel(model, bucket_groups=[BucketGroup([model.head], triggers=[(model, "out")])] +
+                               [BucketGroup([l]) for l in reversed(list(model.layers))])
+    try:
+        x = torch.randn(32, 16)
+        ddp.zero_grad()
+        model(x).backward()
+        ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+        assert model.front_runs == 1
+        mb = ddp.module_bucket
+        for cut_keys, n_real in (([(id(model), "out"), (id(model.layers[2]), None)], 2), ([(id(model.layers[1]), None)], 1), ([], 0)):
+            model.front_runs = 0
+            ddp.zero_grad()
+            with ddp.local_phase():
+                with ddp.cut_points([mb[k] for k in cut_keys] or [10 ** 6]) as cuts:
+                    loss = model(x)
+                assert sum(1 for c in cuts if c[0] not in ("shared", "bypass")) == n_real and sum(1 for c in cuts if c[0] == "bypass") == 1
+                phases = ddp.backward_phases(loss, cuts)
+                assert len(phases) == n_real + 1
+                for k, (fn, _) in enumerate(phases):
+                    fn()
+                    assert model.front_runs == (1 if k == n_real else 0), (cut_keys, k, model.front_runs)
+            for n, p in model.named_parameters():
+                assert torch.equal(p.grad, ref[n]), (n_real, n, float((p.grad - ref[n]).abs().max()))
+    finally:
+        ddp.close()

@@ -54,6 +54,29 @@ def test_two_ranks_side_by_side_micro_batches_equal_the_one_rank_update(cuda, tm
     assert ranks[0]["digest"] == ranks[1]["digest"] == one["digest"], (ranks[0]["pnorm"], ranks[1]["pnorm"], one["pnorm"])
 
 
+def test_two_ranks_side_by_side_phased_exchange_equals_the_one_rank_update(cuda, tmp_path):
+    """Round 6, the default several-rank form: both micro-batches inside each of the three phase graphs, every completed bucket range
+    summed over the two gradient buffers and all-reduced (gloo here) while the next phase runs.  Same data on both ranks: bit-equal to
+    the one-rank update; each rank its OWN data and lr = 0: the buffer the optimizer receives == g_rank0 + g_rank1 of two one-rank
+    eager runs bit for bit (a range summed or sent twice, too early or from the wrong buffer would not be)."""
+    import torch
+    one = _launch(1, "phased", str(tmp_path / "one"), 0)[0]
+    ranks = _launch(2, "phased", str(tmp_path / "sbs_ph"), 29681, extra=["--micro", "side_by_side"])
+    assert all(r["split"] and r["phased"] for r in ranks)
+    assert ranks[0]["digest"] == ranks[1]["digest"] == one["digest"], (ranks[0]["pnorm"], ranks[1]["pnorm"], one["pnorm"])
+    g = []
+    for r in (0, 1):
+        info = _launch(1, "phased", str(tmp_path / f"ref{r}"), 0, extra=["--no-graph", "--data-rank", str(r)])[0]
+        g.append(torch.load(str(tmp_path / f"ref{r}") + ".rank0.grad.pt"))
+    want = g[0] + g[1]
+    out = str(tmp_path / "own_sbs_ph")
+    ranks = _launch(2, "phased", out, 29682, extra=["--own-data", "--micro", "side_by_side"])
+    assert all(r["split"] and r["phased"] and r["grad_calls"] == 4 for r in ranks)
+    for k in (0, 1):
+        got = torch.load(f"{out}.rank{k}.grad.pt")
+        assert torch.equal(got, want), f"rank {k}: exchanged buffer != g0 + g1 ({int((got != want).sum())} of {got.numel()} sampled elements differ)"
+
+
 def test_two_ranks_side_by_side_without_a_graph_equal_the_one_rank_update(cuda, tmp_path):
     """`bench.py --gpus N --no-graph` with the default micro-batch mode -- two gradient buffers and NO captured local
     phase -- used to reach accumulate_overlapped() outside local_phase() and trip its assert.  The eager several-rank side-by-side
