@@ -12,10 +12,35 @@ reference iterates: a span that starts at word-start i and covers L whole words 
 per token of the longest span.  tests/test_text_noise_cpu.py: identical items AND identical generator state afterwards, against the
 verbatim reference class (tests/golden/collate_t2s_s2t_text.pt), over every replace_length / mask_length / insert combination.
 The noised items then go to collate.TextPretrainCollater (ragged gathers on the GPU)."""
+import contextlib
 import math
 
 import numpy as np
 import torch
+
+
+@contextlib.contextmanager
+def numpy_seed(seed, *more):
+    """fairseq.data.data_utils.numpy_seed (third party, restated from its published behaviour): numpy's global stream is seeded with
+    hash((seed, *more)) % 1e6 inside the block and restored afterwards -- what __getitem__ wraps an item's noise in (:204); only the
+    rolling noise draws from numpy, everything else from torch's CPU generator, which this does NOT touch."""
+    if seed is None:
+        yield
+        return
+    if len(more) > 0:
+        seed = int(hash((seed, *more)) % 1e6)
+    state = np.random.get_state()
+    np.random.seed(seed)
+    try:
+        yield
+    finally:
+        np.random.set_state(state)
+
+
+class DegenerateItem(ValueError):
+    """strict mode: the reference cannot produce this item (its add_whole_word_mask returns ONE tensor where __getitem__ unpacks two
+    when the masking budget is zero or only 0-length spans were drawn: text_dataset.py:270, :301 against :210) -- blocks of a few tokens
+    only, never the recipe's 512-token blocks."""
 
 
 class BartNoise:
@@ -29,6 +54,7 @@ class BartNoise:
             raise ValueError("if using subwords, use replace-length=1 or 0")
         if permute_sentences > 0.0 or iid_noise_target:
             raise NotImplementedError("sentence permutation / T5-form targets are not part of the SpeechT5 pre-training recipe")
+        self.strict = False       # True: raise DegenerateItem where the reference's __getitem__ raises (tests: keeps the RNG streams in step)
         self.V, self.mask_idx, self.eos, self.bos = int(vocab_size), int(mask_idx), int(eos), int(bos)
         self.mask_ratio, self.random_ratio, self.insert_ratio, self.rotate_ratio = mask, mask_random, insert, rotate
         self.replace_length = replace_length
@@ -50,13 +76,22 @@ class BartNoise:
         assert int(tokens[-1]) == self.eos
         source, target = tokens, tokens.clone()
         if self.mask_ratio > 0:
+            self._degenerate = False
             source = self.whole_word_mask(source, self.mask_ratio)
+            if self._degenerate and self.strict:
+                raise DegenerateItem("zero masking budget / only 0-length spans: the reference raises here")
         if self.insert_ratio > 0:
             source = self.insertion(source, self.insert_ratio)
         if self.rotate_ratio > 0.0 and np.random.random() < self.rotate_ratio:
             source = self.rolling(source)
         assert int(source[0]) == self.bos and int(source[-1]) == self.eos and bool((source[1:-1] >= 1).all())
         return source, target
+
+    def item(self, index, tokens, seed, epoch=0):
+        """One dataset item (:203-226): the noise inside numpy_seed(seed, epoch, index)."""
+        with numpy_seed(seed, epoch, index):
+            source, target = self(tokens)
+        return {"id": index, "source": source, "target": target}
 
     def _random_tokens(self, count):
         return torch.randint(1, self.V, size=(count,))
@@ -68,6 +103,7 @@ class BartNoise:
         starts01[-1] = 0
         budget = int(math.ceil(starts01.float().sum() * p))       # (fp32 product, as the reference forms it)
         if budget == 0:
+            self._degenerate = True
             return source
         inserts = 0
         if self.span_lengths is not None:
@@ -84,6 +120,7 @@ class BartNoise:
             inserts = drawn - lengths.size(0)
             n_spans = lengths.size(0)
             if n_spans == 0:
+                self._degenerate = True
                 return self.insertion(source, inserts / source.size(0))
         else:
             n_spans = budget
