@@ -111,7 +111,7 @@ def cpu_baseline(model, args, seconds=4.0, runs=5):
     t = ts[len(ts) // 2]
     ref = None
     try:   # the verbatim reference stack timed beside this port on the build container's cores (oracle/time_reference_cpu.py)
-        ref = json.load(open(os.path.join(ROOT, "profiles", "r3_cpu_reference_vs_port.json")))
+        ref = json.load(open(os.path.join(ROOT, "profiles", "r6_cpu_reference_vs_port.json")))
     except Exception:
         pass
     out = {"value": round(seconds / t, 4), "unit": "audio-sec/s", "cores": best, "kind": "port",
@@ -121,7 +121,7 @@ def cpu_baseline(model, args, seconds=4.0, runs=5):
     if ref is not None:
         # the reference itself cannot travel to this box: its ratio to the port, measured where both exist, is read from the committed file
         rs, ps = ref.get("reference", {}).get("median_s"), ref.get("port", {}).get("median_s")
-        out["reference_vs_port"] = {"source": "profiles/r3_cpu_reference_vs_port.json", "reference_s_per_run": rs, "port_s_per_run": ps,
+        out["reference_vs_port"] = {"source": "profiles/r6_cpu_reference_vs_port.json", "reference_s_per_run": rs, "port_s_per_run": ps,
                                     "cores": ref.get("cores"), "port_over_reference": round(ps / rs, 3) if rs and ps else None,
                                     "reference_estimate_audio_sec_per_s": round(seconds / t * ps / rs, 4) if rs and ps else None}
     return out
@@ -219,6 +219,16 @@ def respawn(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    try:
+        import torch
+        if torch.cuda.device_count() < a.gpus:
+            # ranks SHARING a device (functional check, gloo): every process brings its update stream, the second micro-batch's stream and
+            # gloo's private copy streams.  With ROCm's default of 4 hardware queues per process the streams are multiplexed onto the same
+            # queues and the phased side-by-side form crawled (10 s per update, tools/r6/call9.sh / call10.sh; 0.3 s with 8 queues).  The
+            # runtime reads the variable when it is loaded, so it has to be in the children's environment.  Ranks with a GPU each: default.
+            env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    except Exception:
+        pass
     sys.exit(subprocess.call(cmd, env=env))
 
 
@@ -407,7 +417,7 @@ def main():
         torch.cuda.synchronize()
         hip.profiler.enabled = False
     local_ms = None
-    if use_graph and split_update and upd.sg is not None and upd.sg.graph is not None:
+    if use_graph and split_update and upd.sg is not None and (upd.sg.graphs is not None or upd.sg.graph is not None):
         # the captured local phase alone (zero_grad + both micro-batches; idempotent: it starts from cleared buffers), 5 replays
         torch.cuda.synchronize()
         with torch.cuda.stream(upd.sg.stream):
@@ -417,7 +427,15 @@ def main():
                 upd.ddp.flat2.zero_()
             e0.record()
             for _ in range(5):
-                upd.sg.graph.replay()
+                if upd.sg.graphs is not None:       # (phased form: the phase graphs back to back, no exchange between them)
+                    for g in upd.sg.graphs:
+                        g.replay()
+                    upd.ddp.flat.zero_()            # (each phase's sums start from cleared buffers, like the first)
+                    if upd.ddp.flat2 is not None:
+                        upd.ddp.flat2.zero_()
+                    upd.ddp._reset_round()
+                else:
+                    upd.sg.graph.replay()
             e1.record()
         torch.cuda.synchronize()
         local_ms = round(e0.elapsed_time(e1) / 5, 3)
@@ -540,7 +558,10 @@ def main():
                "config": {"workload": f"SpeechT5-{nm} pretrain step (speech {a.batch}x10s micro-batch + text 16x512 micro-batch, update-freq 2), "
                                       "fwd+bwd+allreduce+clip+Adam, per GPU", "arch": ("t5_transformer_large (24 enc + 6 dec, d=1024, pre-LN, layer-norm feature extractor)" if a.arch == "large"
                                    else "t5_transformer_base (12 enc + 6 dec, d=768)"),
-                          "enqueue": ("hip-graph replay of the local phase in 3 graphs cut at bucket boundaries, the bucket range each completes "
+                          "enqueue": ("hip-graph replay of the local phase in 3 graphs cut at bucket boundaries (both micro-batches inside each, "
+                                      "on two streams), the bucket range each completes summed over the two gradient buffers and all-reduced "
+                                      "(async, the group's stream) under the next graph, then Adam" if (getattr(upd, "phased", False) and micro_mode == "side_by_side") else
+                                      "hip-graph replay of the local phase in 3 graphs cut at bucket boundaries, the bucket range each completes "
                                       "all-reduced (RCCL, async) under the next graph, then Adam" if getattr(upd, "phased", False) else
                                       "hip-graph replay of the local phase + eager all-reduce (one message) + Adam" if split_update else
                                       "hip-graph replay" if use_graph else "eager"),

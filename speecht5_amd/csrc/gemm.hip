@@ -769,6 +769,13 @@ __device__ __forceinline__ F lds_read128_asm(const unsigned lds_addr) {
   return v;
 }
 
+// (cache-policy bits of the operand LDS-DMA loads, an A/B knob: 0 = default, 1 = sc0, 2 = nt, 16 = sc1; tools/r6/build_aux_lib.sh)
+#ifndef GLDS_AUX_A
+#define GLDS_AUX_A 0
+#endif
+#ifndef GLDS_AUX_B
+#define GLDS_AUX_B 0
+#endif
 template <typename T, int NBUF, int FEAT = -1>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
   ST5_PAD_TO_256_VGPRS();
@@ -816,8 +823,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
     char* base = dsm + buf * 2 * TILE_BYTES + dst0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[i] + (long long)kt * BK), (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, GLDS_AUX_A);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[i] + (long long)kt * BK), (lds_ptr_t)(base + TILE_BYTES + i * 4096), 16, 0, GLDS_AUX_B);
     }
   };
   // (NBUF == 5: five 16 KB operand slots instead of whole stages, see the k-loop)
@@ -825,13 +832,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_glds_kernel(const st5_gem
     char* base = dsm + slot * TILE_BYTES + dst0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, GLDS_AUX_A);
   };
   auto issue_b = [&](int kt, int slot) {
     char* base = dsm + slot * TILE_BYTES + dst0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[i] + (long long)kt * BK), (lds_ptr_t)(base + i * 4096), 16, 0, GLDS_AUX_B);
   };
 
   f32x16 acc00, acc01, acc10, acc11;

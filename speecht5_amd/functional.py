@@ -732,6 +732,21 @@ def drop_wgrads():
     _S.__dict__["wq_hold"] = []
 
 
+def _is_queued_wgrad_operand(t):
+    """Does a queued (not yet launched) or held weight-gradient problem read tensor t's memory?"""
+    p = t.data_ptr()
+    q = _S.__dict__.get("wq") or {}
+    for ent in q.values():
+        for keep in ent[1]:
+            if any(torch.is_tensor(k) and k.data_ptr() == p for k in keep):
+                return True
+    for keeps in _S.__dict__.get("wq_hold") or []:
+        for keep in keeps:
+            if any(torch.is_tensor(k) and k.data_ptr() == p for k in keep):
+                return True
+    return False
+
+
 def _wgrad_queue(A, B, C, M, N, K, dt, flags, asum, keep):
     q = _S.__dict__.setdefault("wq", {})
     st = hip.stream()
@@ -1726,6 +1741,10 @@ class LayerDropEnterFunction(torch.autograd.Function):
         assert g is not None, "LayerDropGate: the layer's input gradient arrived before its gated LayerNorm's backward ran"
         dx = dx.contiguous()
         assert g.numel() == dx.numel() and g.dtype == dx.dtype
+        if _is_queued_wgrad_operand(dx):
+            # (the kernel below overwrites dx IN PLACE for a dropped layer.  Today dx is a fresh data-gradient GEMM output;
+            #  should it ever alias an operand a queued weight-gradient GEMM has yet to read, that GEMM must keep seeing the zeros)
+            dx = dx.clone()
         hip.check(hip.lib().st5_skip_grad(gate.keep.data_ptr(), g.data_ptr(), dx.data_ptr(), dx.numel() * dx.element_size(), hip.stream()),
                   "st5_skip_grad")
         return dx, None

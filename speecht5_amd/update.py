@@ -50,6 +50,7 @@ class PretrainUpdate:
         assert exchange_payload in ("fp32", "bf16")
         # several ranks, one-message exchange: the gradient buffer travels as bf16 (half the link bytes; local sums and Adam stay fp32)
         self.exchange_payload = torch.bfloat16 if exchange_payload == "bf16" else None
+        self._payload_asked = exchange_payload
         # several ranks + graph: graph = local phase, eager tail = all-reduce + Adam.  Several ranks WITHOUT a graph and two gradient
         # buffers (micro != "in_turn"): the same split, enqueued eagerly -- the bucket triggers of the eager overlapped path need ONE
         # buffer of summed gradients, so accumulate_overlapped() is only legal inside local_phase() (`--gpus N --no-graph`
@@ -68,6 +69,13 @@ class PretrainUpdate:
                        and (micro == "in_turn" or len(self.micro) == 2))
         if self.phased and not self.ddp.overlap_exchange:    # (decided once per group in FlatGradDataParallel, the same on every rank)
             self.phased = False      # one message behind the local phase: no collective beside the backward's kernels
+        if self.exchange_payload is not None and (self.phased or not self.split):
+            # (the bf16 payload exists for the one-message exchange only; silently exchanging fp32 is not what was asked)
+            import warnings
+            warnings.warn("speecht5_amd: exchange_payload='bf16' applies to the one-message exchange only (exchange='one_message' with a "
+                          "replayed or split update); this update exchanges fp32 gradients "
+                          f"({'phased' if self.phased else 'bucketed, eager'} form)")
+            self.exchange_payload = None
         self._ph = None
         self.n = 0            # update counter (fairseq's num_updates)
         self.sg = None
@@ -221,9 +229,13 @@ class PretrainUpdate:
                     st["ph"] = None             # (the autograd graphs of this update may go)
             return fn
 
+        defer = os.environ.get("ST5_PHASED_DEFER_EXCHANGE") == "1"    # (diagnostic: the same three graphs, ONE message behind the last)
+
         def reduce_after(k):
             def fn():
-                ddp.reduce_bucket_range(cuts_b[k] if k < len(cuts_b) else None)
+                if defer and k < nph - 1:
+                    return
+                ddp.reduce_bucket_range(cuts_b[k] if (k < len(cuts_b) and not defer) else None)
             return fn
         self._ph_sbs = st
         return [first] + [later(k) for k in range(1, nph)], [reduce_after(k) for k in range(nph)]

@@ -21,6 +21,7 @@ def _launch(nproc, exchange, out, port, extra=()):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["OMP_NUM_THREADS"] = "8"
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")     # (two processes on ONE device: see bench.respawn)
     worker = os.path.join(ROOT, "tests", "two_rank_worker.py")
     if nproc == 1:
         cmd = [sys.executable, worker, "--exchange", exchange, "--out", out] + list(extra)
