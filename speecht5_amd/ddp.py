@@ -876,4 +876,10 @@ class FusedAdam:
         if self.mirror is not None:
             for p in self.ddp.params:
                 p._st5_mver = p._version
-            self.mirror.refresh_transposes()
+            if os.environ.get("ST5_LAZY_TRANSPOSES") == "1":
+                # (A/B, round 6: leave the refresh to the first data-gradient GEMM of the next update -- off the serial tail, onto the
+                #  shorter micro-batch chain.  Measured: 30.5 against 30.15 ms per update, same box, alternating: the one extra
+                #  cross-stream event inside the replayed graph costs more than the 0.24 ms it moves.  Off.)
+                self.mirror.mark_stale()
+            else:
+                self.mirror.refresh_transposes()

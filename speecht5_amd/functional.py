@@ -307,6 +307,13 @@ class _Bf16Mirror:
         self.jobs_dev = None
         self.ntiles = 0
         self.dirty = False      # job table changed since it was last uploaded
+        # Round 6, an A/B mode (ddp.FusedAdam, ST5_LAZY_TRANSPOSES=1; measured slower, off): the batched refresh can be LAZY.  Only the
+        # data-gradient GEMMs read the transposed copies, i.e. nothing before the first backward of the NEXT update -- the optimizer step
+        # then only marks them stale (mark_stale) and the first reader refreshes them, on its stream, at the head of that update's
+        # backward.  A reader on another stream waits for that refresh's event once.
+        self.stale = False
+        self.refreshed = None   # (event, raw stream) of the last lazy refresh
+        self.waited = set()     # raw streams already ordered behind it
 
     def attach(self, flat_bf16, params, offsets):
         self.__init__()
@@ -334,7 +341,23 @@ class _Bf16Mirror:
             return None
         return off, self.flat[off:nxt].view(-1, K)
 
+    def mark_stale(self):
+        """The parameters (and their bf16 image) changed: every transposed copy is out of date until the next reader refreshes them."""
+        self.stale = True
+
+    def _sync_transposes(self):
+        if self.stale:
+            self.stale = False
+            self.refresh_transposes()
+            ev = torch.cuda.Event()
+            ev.record()
+            self.refreshed, self.waited = (ev, hip.stream()), {hip.stream()}
+        elif self.refreshed is not None and hip.stream() not in self.waited:
+            torch.cuda.current_stream().wait_event(self.refreshed[0])
+            self.waited.add(hip.stream())
+
     def transposed(self, off, rows, cols):
+        self._sync_transposes()
         key = (off, rows, cols)
         hit = self.jobs.get(key)
         if hit is not None:
