@@ -57,8 +57,8 @@ def build(device, compute_dtype, arch="base", layerdrop=0.05):
     return args, task, model, crit
 
 
-PMC_TRAFFIC_FILE = "r5_pmc_traffic.json"   # written by tools/pmc_traffic.sh
-KERNEL_STATS_FILE = "r5_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --steps 13` (tools/finals.sh)
+PMC_TRAFFIC_FILE = "r6_pmc_traffic.json"   # written by tools/pmc_traffic.sh
+KERNEL_STATS_FILE = "r6_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --steps 13` (tools/finals.sh)
 NT_KERNEL_NAME = "gemm_nt_glds_kernel"      # the dominant kernel of the update (most NT launches)
 
 

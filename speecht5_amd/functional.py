@@ -722,7 +722,35 @@ def release_wgrad_holds():
     _S.__dict__["wq_hold"] = []
 
 
+def hold_wgrads(stream):
+    """Weight-gradient groups queued on torch stream `stream` are not launched but HELD (with their operands) until
+    launch_held_wgrads() -- on whatever stream is current then, e.g. inside another graph (tools/r6/multi_graph.py: a micro-batch's weight
+    gradients as graphs of their own on a third stream, ordered behind the backward phase that produced their operands by a plain stream
+    event).  None: off."""
+    _S.__dict__["wq_holding"] = None if stream is None else (stream.cuda_stream, [])
+
+
+def launch_held_wgrads(keep_alive):
+    """Launch every held group on the current stream; their operand tensors are appended to `keep_alive` (the caller decides how long the
+    allocator must not reuse them)."""
+    h = _S.__dict__.get("wq_holding")
+    if h is None:
+        return 0
+    n = 0
+    for problems, dt, keeps in h[1]:
+        hip.gemm_tn_group(problems, dt)
+        keep_alive.append(keeps)
+        n += 1
+    del h[1][:]
+    return n
+
+
 def _launch_wgrad_group(st, ent):
+    h = _S.__dict__.get("wq_holding")
+    if h is not None and h[0] == st:
+        h[1].append((ent[0], ent[3], list(ent[1])))
+        ent[1].clear()
+        return
     tgt = _S.__dict__.get("wq_target")
     if tgt is None or tgt[0] != st:
         hip.gemm_tn_group(ent[0], ent[3])
