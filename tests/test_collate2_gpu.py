@@ -80,3 +80,42 @@ def test_text_pretrain_pipeline_equals_the_reference(cuda, name):
     batch = TextPretrainCollater(cuda, pad_idx=cc.PAD).collater(_dev(items, cuda))
     torch.cuda.synchronize()
     _same(batch, gold["batch"], f"text {name}")
+
+
+def test_reference_datasets_wrapped_with_gpu_collaters(cuda):
+    """speecht5_amd.data.GpuCollated / wrap_datasets: objects shaped like the reference's dataset classes (the attributes their collaters
+    read) get the matching GPU collater, configured from those attributes; items go to the device in __getitem__; everything else is the
+    wrapped dataset's.  The batches equal the verbatim collaters' fixtures."""
+    from speecht5_amd.data import GpuCollated, wrap_datasets
+    gold = torch.load(GOLD)
+
+    class Dict:
+        def pad(self): return cc.PAD
+        def eos(self): return cc.EOS
+
+    class TextToSpeechDataset:
+        def __init__(self, items, r):
+            self.items, self.reduction_factor, self.src_dict, self.sizes = items, r, Dict(), [len(i["target"]) for i in items]
+        def __getitem__(self, i): return self.items[i]
+        def __len__(self): return len(self.items)
+        def ordered_indices(self): return list(range(len(self.items)))
+
+    class SpeechToTextDataset(TextToSpeechDataset):
+        def __init__(self, items):
+            self.items, self.tgt_dict = items, Dict()
+
+    t2s = GpuCollated(TextToSpeechDataset(cc.t2s_items("r2"), 2), cuda)
+    assert len(t2s) == 4 and t2s.ordered_indices() == [0, 1, 2, 3] and t2s[0]["target"].is_cuda and t2s[0]["source"][0].is_cuda
+    _same(t2s.collater([t2s[i] for i in range(4)]), gold["t2s"]["r2"], "wrapped t2s")
+
+    class MultitaskDataset:
+        def __init__(self, ds):
+            self.datasets, self.sample_ratios = list(ds), 1
+        def collater(self, samples, idx):
+            return self.datasets[idx].collater(samples)
+
+    multi = wrap_datasets(MultitaskDataset([TextToSpeechDataset(cc.t2s_items("r1"), 1), SpeechToTextDataset(cc.s2t_items("ragged"))]), cuda)
+    assert all(isinstance(m, GpuCollated) for m in multi.datasets)
+    _same(multi.collater([multi.datasets[0][i] for i in range(2)], 0), gold["t2s"]["r1"], "wrapped multitask member 0")
+    _same(multi.collater([multi.datasets[1][i] for i in range(4)], 1), gold["s2t"]["ragged"], "wrapped multitask member 1")
+    torch.cuda.synchronize()
