@@ -129,11 +129,20 @@ int st5_gemm_set_nt_slots(int slots);
  * Replaces the same F.linear call sites as st5_gemm when the fp8 compute mode is on (speecht5_amd.functional.set_fp8). */
 int st5_gemm_mxfp8(const st5_gemm_params* p, const uint8_t* a_scale, int64_t a_scale_ld, const uint8_t* b_scale, int64_t b_scale_ld,
                    void* stream);
+/* Block tile of st5_gemm_mxfp8: 0 (default) = per problem -- the phased 256x256 kernel (gemm_nt8p_mx8_kernel: st5_gemm's phased bf16
+ * schedule on fp8 bytes, twice the reduction depth per LDS byte and matrix-pipe cycle) for problems of several rounds of 256x256 tiles
+ * or one nearly full round, else 128x128; 1 = 128x128 always, 2 = phased 256x256 always.  Results are bit-identical for every choice. */
+int st5_gemm_set_mx8_tile(int mode);
 /* MX quantisation along rows of a bf16 matrix x [rows x cols] (ld elements, cols % 32 == 0): q = e4m3(x * 2^(127 - s)) bytes
  * (pitch q_ld), s[r][c / 32] = floor(log2(max|finite block elements|)) - 8 + 127 as e8m0 (pitch s_ld); round to nearest even, finite
  * values saturating at +-448.  NaN / Inf propagate: the element becomes the e4m3 NaN code 0x7f and its block's scale the e8m0 NaN 0xff,
  * so a diverged tensor still turns the GEMM output (and the loss / gradient norm behind it) non-finite. */
 int st5_quant_mxfp8(const void* x, int64_t ld, void* q, int64_t q_ld, uint8_t* s, int64_t s_ld, int64_t rows, int32_t cols, void* stream);
+/* The same for njobs CONTIGUOUS bf16 matrices in one launch -- the fp8 images of every eligible Linear weight and of its transposed copy
+ * (forward / data-gradient operand of F.linear, transformer_layer.py:127-131,385-389), refreshed once per optimizer step.  jobs: DEVICE array
+ * of njobs records { const void* x; void* q; uint8_t* s; int64_t elems (rows * cols, cols % 32 == 0); int32_t cols; int32_t blk0 }, blk0 = the
+ * job's first block at 2048 elements per block (ascending, job 0 at 0); nblocks = the total. */
+int st5_multi_quant_mxfp8(const void* jobs, int32_t njobs, int32_t nblocks, void* stream);
 /* n <= 8 weight-gradient GEMMs (each as st5_gemm would take it: A, B k-strided bf16, ST5_GEMM_OUT_F32, no epilogue but beta and asum; the
  * four / six weight gradients of a transformer layer: autograd of F.linear at transformer_layer.py:127-131,385-389, multihead_attention.py:
  * 213-231,397) as ONE launch in which every block runs the whole token reduction of its tile -- no split-K slabs, no reduction kernel.  The

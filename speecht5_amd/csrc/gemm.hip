@@ -14,6 +14,7 @@
 // bf16 uses v_mfma_f32_32x32x16_bf16; f32 uses v_mfma_f32_32x32x2_f32 (exact f32, parity mode).
 // The epilogue goes through LDS so that bias/activation/residual/dropout are applied on 8
 // consecutive columns per lane and stored as 16-byte vectors.
+#include <type_traits>
 #include "common.h"
 #include "../../include/speecht5_hip.h"
 
@@ -2323,11 +2324,289 @@ int launch_mx8_as(const st5_gemm_params& p, int c_vec_ok, const unsigned char* s
   return ST5_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// MX-fp8 NT path, 256 x 256 block tile, PHASED schedule (round 6): gemm_nt8p_kernel's program on fp8 bytes.  An LDS row is still 128
+// bytes, now 128 k-elements, so staging, swizzle, the four fragment offsets and the phase structure are the bf16 kernel's byte for
+// byte; a phase's eight v_mfma_f32_32x32x16_bf16 (32 cycles each) become four v_mfma_scale_f32_32x32x64_f8f6f4 (64 cycles each): the
+// same matrix-pipe time and the same LDS / LDS-DMA traffic per k-tile for TWICE the reduction depth.  That is what makes the fp8 mode
+// pay: the 128^2 fp8 kernel ran at 0.85-0.97 PFLOP/s against the phased bf16 kernel's 0.9-1.2 on the Large shapes (a tie).
+// Scale bytes: as in gemm_nt_mx8_kernel one aligned dword per row and k-tile, loaded straight into registers one k-tile ahead -- in
+// phase 1, IN FRONT of that phase's LDS-DMA pieces, so the one counted vmcnt(4) of phase 4 (which leaves only the two youngest
+// half-tiles in flight) retires them too; six dwords per wave and k-tile (4 A row blocks, 2 B row blocks of the 128 x 64 wave tile).
+// Every output element sees the MFMA chain of the 128^2 kernel (k-tiles ascending, two 64-deep groups each): bit-identical results.
+// ------------------------------------------------------------------------------------------------------
+template <int FEAT, bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_nt8p_mx8_kernel(const st5_gemm_params p, const int c_vec_ok,
+                                                            const unsigned char* __restrict__ sa, const long long sa_ld,
+                                                            const unsigned char* __restrict__ sb, const long long sb_ld) {
+  typedef bf16_t T;                             // type of the C-class operands
+  constexpr int BK = 128;                       // k-elements (= bytes) per tile row
+  constexpr int HALF = TILE_BYTES;              // 16 KB: 128 rows x 128 B
+  constexpr int BUF = 4 * HALF;                 // A0 A1 B0 B1
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (p.N + 255) / 256;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
+    bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+  }
+  int tm, tn;
+  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  // Operands and scales through buffer resources (32-bit per-lane offsets + a scalar k offset instead of 64-bit pointers: this kernel
+  // has 208 registers of accumulators and fragments, two waves per SIMD, and six scale dwords more to hold than its bf16 twin).  The
+  // launcher guarantees that every image is < 2 GB.
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A.ptr), 0, (int)((long long)p.M * p.A.ld), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B.ptr), 0, (int)((long long)p.N * p.B.ld), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(sa), 0, (int)((long long)p.M * sa_ld), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(sb), 0, (int)((long long)p.N * sb_ld), 0x00020000);
+  int voff[4][2];     // half-tile h (0, 1: A rows 0-127 / 128-255; 2, 3: B), instruction i of this wave: rows (i * 8 + wave) * 8 .. +7
+  {
+    const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (i * 8 + wave) * 8 + rsub;
+      const int c = pc ^ ((row >> 1) & 7);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int gr = m0 + h * 128 + row; gr = gr < p.M ? gr : p.M - 1;
+        voff[h][i] = gr * (int)p.A.ld + c * 16;
+        int gc = n0 + h * 128 + row; gc = gc < p.N ? gc : p.N - 1;
+        voff[2 + h][i] = gc * (int)p.B.ld + c * 16;
+      }
+    }
+  }
+  auto stage = [&](const int h, const int kt) {        // half-tile h of k-tile kt -> buffer kt & 1
+    char* base = dsm + (kt & 1) * BUF + h * HALF + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(h < 2 ? ra : rb, (lds_ptr_t)(base + i * 8192), 16, voff[h][i], kt * BK, 0, 0);
+  };
+
+  const int nk = p.K / BK;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  int foff[4];      // chunk 2 kg + fhalf of the lane's fragment row: k-group g of the k-tile reads kg = 2g (first MX block) and 2g + 1
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) foff[kg] = lds_off(frow, 2 * kg + fhalf);
+  const int a_half = wr * HALF;
+  const int b_base = (2 + (wc >> 1)) * HALF + (wc & 1) * 64 * 128;
+  // scale dwords of this lane's fragment rows: 4 A row blocks (32 rows each), 2 B row blocks; dword kt = the 4 block scales of k-tile kt
+  int svoff[6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = m0 + wr * 128 + i * 32 + frow; r = r < p.M ? r : p.M - 1;
+    svoff[i] = r * (int)sa_ld;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int c = n0 + wc * 64 + j * 32 + frow; c = c < p.N ? c : p.N - 1;
+    svoff[4 + j] = c * (int)sb_ld;
+  }
+  auto load_scales = [&](unsigned int (&dst)[6], const int kt) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dst[j] = __builtin_amdgcn_raw_buffer_load_b32(j < 4 ? rsa : rsb, svoff[j], 4 * kt, 0);
+  };
+  const int sh = 8 * fhalf;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: the scales and all of k-tile 0, the A halves of k-tile 1
+  unsigned int scn[6];
+  load_scales(scn, 0);
+  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  if (nk > 1) { stage(0, 1); stage(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  // fragments: a[i][g] / b[g] = the two MX blocks of k-group g for row block i (registers 0-3: first block, 4-7: second; layout
+  // measured on the part, see gemm_nt_mx8_kernel)
+  auto frag = [&](const char* tile, const int g) {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(tile + foff[2 * g]);
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(tile + foff[2 * g + 1]);
+    i32x8 r;
+    r[0] = (int)lo[0]; r[1] = (int)lo[1]; r[2] = (int)lo[2]; r[3] = (int)lo[3];
+    r[4] = (int)hi[0]; r[5] = (int)hi[1]; r[6] = (int)hi[2]; r[7] = (int)hi[3];
+    return r;
+  };
+  // A phase's four MFMAs (two accumulators x two k-groups; the dependent pair of an accumulator is separated by the other one's).  The
+  // empty asm statements pin them INSIDE the phase: hipcc sinks the (side-effect-free) mfma_scale builtins of all four phases to the
+  // end of the loop body otherwise -- behind the barriers, the counted vmcnt wait and every LDS-DMA issue, i.e. no overlap at all.
+#define MX8P_PIN(I0, I1, J) asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I1][J]));
+#define MX8P_MMA2(I0, I1, J)                                                                                                                  \
+  MX8P_PIN(I0, I1, J)                                                                                                                         \
+  acc[I0][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[I0][0], bfr[0], acc[I0][J], 0, 0, 0, (int)sc[I0], 0, (int)sc[4 + (J)]);      \
+  acc[I1][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[I1][0], bfr[0], acc[I1][J], 0, 0, 0, (int)sc[I1], 0, (int)sc[4 + (J)]);      \
+  acc[I0][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[I0][1], bfr[1], acc[I0][J], 0, 0, 0, (int)sc2[I0], 0, (int)sc2[4 + (J)]);    \
+  acc[I1][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[I1][1], bfr[1], acc[I1][J], 0, 0, 0, (int)sc2[I1], 0, (int)sc2[4 + (J)]);    \
+  MX8P_PIN(I0, I1, J)
+  i32x8 af[4][2], bfr[2];
+  unsigned int sc[6], sc2[6];
+  // One k-tile; HAS1 / HAS2: k-tiles t + 1 / t + 2 exist.  The steady-state loop runs the <true, true> copy and the last two k-tiles
+  // their own, so that no staging sits behind a branch: hipcc's vmcnt bookkeeping for the scale dwords (ordinary loads it must wait
+  // for itself) only counts the LDS-DMA pieces it can PROVE younger; with conditional staging it waited vmcnt(2) at the bottom of every
+  // k-tile -- i.e. for the half-tile issued one phase earlier -- instead of nothing (the counted vmcnt(4) of phase 4 covers them).
+  auto ktile = [&](const int t, auto has1, auto has2) {
+    constexpr bool HAS1 = decltype(has1)::value, HAS2 = decltype(has2)::value;
+    const char* cur = dsm + (t & 1) * BUF;
+    // the scale operand is read from byte 0 of its register (op_sel is ignored on this part): block 2g + (lane >> 5) of the row's dword
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { sc[j] = scn[j] >> sh; sc2[j] = sc[j] >> 16; }
+    // ---- phase 1 ----
+#pragma unroll
+    for (int g = 0; g < 2; ++g) bfr[g] = frag(cur + b_base, g);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) af[i][g] = frag(cur + a_half + i * 4096, g);
+    if constexpr (HAS1) {
+      load_scales(scn, t + 1);
+      stage(2, t + 1);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    MX8P_MMA2(0, 1, 0)
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2 ----
+    if constexpr (HAS1) stage(3, t + 1);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    MX8P_MMA2(2, 3, 0)
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3 ----
+#pragma unroll
+    for (int g = 0; g < 2; ++g) bfr[g] = frag(cur + b_base + 4096, g);
+    if constexpr (HAS2) stage(0, t + 2);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    MX8P_MMA2(2, 3, 1)
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4 ----
+    if constexpr (HAS2) { stage(1, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    MX8P_MMA2(0, 1, 1)
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  {
+    typedef std::integral_constant<bool, true> yes_t;
+    typedef std::integral_constant<bool, false> no_t;
+    int t = 0;
+    for (; t + 2 < nk; ++t) ktile(t, yes_t(), yes_t());
+    if (t + 1 < nk) { ktile(t, yes_t(), no_t()); ++t; }
+    ktile(t, no_t(), no_t());
+  }
+#undef MX8P_MMA2
+#undef MX8P_PIN
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();     // (every wave executes the same number of barriers)
+  __syncthreads();
+
+  EpiArgs ea;
+  ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
+  ea.bias = p.bias;
+  ea.c_ld = p.C.ld; ea.c_bs = p.C.bstride; ea.r_ld = p.R.ld; ea.r_bs = p.R.bstride;
+  ea.p_ld = p.P.ld; ea.p_bs = p.P.bstride; ea.q_ld = p.Cpre.ld; ea.q_bs = p.Cpre.bstride;
+  ea.rpb = p.C.rpb; ea.M = p.M; ea.N = p.N; ea.act = p.act;
+  ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
+  ea.atomic = 0;
+  ea.fast = c_vec_ok && (p.N % 8 == 0);
+  ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
+  ea.ctr_base = 0ull;
+  float* stg = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
+  run_epilogue<T, FEAT>(ea, stg, acc[0][0], acc[0][1], acc[1][0], acc[1][1], m0 + wr * 128, n0 + wc * 64, lane);
+  run_epilogue<T, FEAT>(ea, stg, acc[2][0], acc[2][1], acc[3][0], acc[3][1], m0 + wr * 128 + 64, n0 + wc * 64, lane);
+}
+
+// (one block per CU: its prologue and 128 KB store epilogue are exposed, so it wants whole rounds -- see nt256_pays)
+bool mx8_256_pays(int M, int N) {
+  const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  return t256 >= 448 || (t256 >= 176 && t256 <= 256);
+}
+int g_mx8_tile = 0;   // 0 = choose per problem, 1 = always 128^2, 2 = always the phased 256^2 kernel (st5_gemm_set_mx8_tile)
+template <int FEAT>
+int launch_mx8p_as(const st5_gemm_params& p, int c_vec_ok, const unsigned char* sa, long long sa_ld, const unsigned char* sb, long long sb_ld,
+                   hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_nt8p_mx8_kernel<FEAT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return ST5_ERR_LAUNCH;
+    attr = true;
+  }
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  hipLaunchKernelGGL((gemm_nt8p_mx8_kernel<FEAT, true>), dim3(tiles, 1, 1), dim3(512), (size_t)8 * TILE_BYTES, s, p, c_vec_ok, sa, sa_ld, sb, sb_ld);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
 // MX quantisation of a row-major bf16 matrix along its rows: per 32 consecutive elements one e8m0 scale byte
 // E = floor(log2(amax)) - 8 + 127 (the OCP MX rule for e4m3, whose largest binade is 2^8) and 32 e4m3 bytes of x * 2^(127 - E),
 // round-to-nearest-even, saturating FINITE values at +-448 (NaN / Inf propagate: see the kernel).  Four lanes per block, 8 elements each: coalesced 16-byte loads and 8-byte stores
 // (the first version gave a lane a whole block: 64-byte stride between the lanes of every load instruction), the block maximum by
 // two quad shuffles.
+// One lane's share of an MX block: 8 consecutive bf16 of a row (4 lanes = one 32-element block, aligned in the wave) -> 8 e4m3 bytes
+// and, from the block's first lane, the e8m0 scale byte.
+__device__ __forceinline__ void mx8_quant8(const float (&v)[8], unsigned char* __restrict__ q8, unsigned char* __restrict__ sbyte, const bool leader) {
+  // Non-finite inputs PROPAGATE: fmaxf ignores a NaN and the clamp below would turn NaN / Inf into +-448, so a diverged
+  // activation or gradient would never reach the loss / the gradient norm in fp8 mode.  The block maximum is taken over the FINITE
+  // elements (an Inf must not push the scale to 2^120 and zero its 31 neighbours); a non-finite element gets the e4m3 NaN code
+  // 0x7f, and the block's scale byte becomes the e8m0 NaN 0xff (OCP MX: the whole block then dequantises to NaN).
+  float amax = 0.f;
+  unsigned int nf = 0u;          // bit e: element e is NaN or Inf
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool bad = (__float_as_uint(v[e]) & 0x7f800000u) == 0x7f800000u;
+    nf |= bad ? (1u << e) : 0u;
+    amax = fmaxf(amax, bad ? 0.f : fabsf(v[e]));
+  }
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  unsigned int nf_blk = nf != 0u ? 1u : 0u;
+  nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 1, 64);
+  nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 2, 64);
+  int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;      // biased exponent of amax, minus emax(e4m3)
+  E = E < 0 ? 0 : (E > 254 ? 254 : E);
+  const float inv = __uint_as_float((unsigned int)(254 - E) << 23);    // 2^(127 - E)
+  u32x2 o;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    float f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = ((nf >> (4 * w + e)) & 1u) ? 0.f : v[4 * w + e] * inv;
+      f[e] = fminf(fmaxf(t, -448.f), 448.f);
+    }
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+    unsigned int u = (unsigned int)pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((nf >> (4 * w + e)) & 1u) u = (u & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
+    o[w] = u;
+  }
+  *reinterpret_cast<u32x2*>(q8) = o;
+  if (leader) *sbyte = nf_blk ? (unsigned char)0xff : (unsigned char)E;
+}
+
 __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict__ x, long long ld, unsigned char* __restrict__ q, long long q_ld,
                                                         unsigned char* __restrict__ s, long long s_ld, long long rows, int cols) {
   const int ng = cols >> 3;                 // 8-element groups per row (a multiple of 4: cols % 32 == 0)
@@ -2337,47 +2616,27 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict
     const int g = (int)(i - row * ng);
     float v[8];
     load8f<bf16_t>(x + row * ld + g * 8, v);
-    // Non-finite inputs PROPAGATE: fmaxf ignores a NaN and the clamp below would turn NaN / Inf into +-448, so a diverged
-    // activation or gradient would never reach the loss / the gradient norm in fp8 mode.  The block maximum is taken over the FINITE
-    // elements (an Inf must not push the scale to 2^120 and zero its 31 neighbours); a non-finite element gets the e4m3 NaN code
-    // 0x7f, and the block's scale byte becomes the e8m0 NaN 0xff (OCP MX: the whole block then dequantises to NaN).
-    float amax = 0.f;
-    unsigned int nf = 0u;          // bit e: element e is NaN or Inf
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool bad = (__float_as_uint(v[e]) & 0x7f800000u) == 0x7f800000u;
-      nf |= bad ? (1u << e) : 0u;
-      amax = fmaxf(amax, bad ? 0.f : fabsf(v[e]));
-    }
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    unsigned int nf_blk = nf != 0u ? 1u : 0u;
-    nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 1, 64);
-    nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 2, 64);
-    int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;      // biased exponent of amax, minus emax(e4m3)
-    E = E < 0 ? 0 : (E > 254 ? 254 : E);
-    const float inv = __uint_as_float((unsigned int)(254 - E) << 23);    // 2^(127 - E)
-    u32x2 o;
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-      float f[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float t = ((nf >> (4 * w + e)) & 1u) ? 0.f : v[4 * w + e] * inv;
-        f[e] = fminf(fmaxf(t, -448.f), 448.f);
-      }
-      int pk = 0;
-      pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
-      pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
-      unsigned int u = (unsigned int)pk;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if ((nf >> (4 * w + e)) & 1u) u = (u & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
-      o[w] = u;
-    }
-    *reinterpret_cast<u32x2*>(q + row * q_ld + g * 8) = o;
-    if ((g & 3) == 0) s[row * s_ld + (g >> 2)] = nf_blk ? (unsigned char)0xff : (unsigned char)E;
+    mx8_quant8(v, q + row * q_ld + g * 8, s + row * s_ld + (g >> 2), (g & 3) == 0);
   }
+}
+
+// Many matrices in ONE launch (round 6): the fp8 images of every eligible weight and of its transposed copy, refreshed once per
+// optimizer step behind the batched transpose (functional._Fp8Mirror) -- ~280 launches of 2-5 us per update before, each produced by
+// whichever micro-batch stream reached the Linear first, with the other stream waiting on an event (a cross-stream edge inside the
+// replayed graph per weight).  Contiguous matrices (ld = cols); a block quantises 2048 consecutive elements of one job.
+struct QuantJob { const bf16_t* x; unsigned char* q; unsigned char* s; long long elems; int cols; int blk0; };
+__global__ __launch_bounds__(256) void multi_quant_mx8_kernel(const QuantJob* __restrict__ jobs, const int njobs) {
+  int lo = 0, hi = njobs - 1;      // last job with blk0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const QuantJob j = jobs[lo];
+  const long long i = ((long long)((int)blockIdx.x - j.blk0) * 256 + threadIdx.x) * 8;     // first element of this lane's group
+  if (i >= j.elems) return;                 // (elems % 32 == 0: the four lanes of a block leave together)
+  float v[8];
+  load8f<bf16_t>(j.x + i, v);
+  mx8_quant8(v, j.q + i, j.s + (i >> 5), (i & 31) == 0);
 }
 
 }  // namespace
@@ -2585,9 +2844,24 @@ extern "C" int st5_gemm_mxfp8(const st5_gemm_params* pp, const uint8_t* a_scale,
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
     attr = true;
   }
+  const long long al = a_scale_ld, bl = b_scale_ld;
+  // Block tile, the bf16 rule (nt256_pays): the phased 256^2 kernel for several rounds of the chip or one nearly full round
+  // (the phased kernel addresses operands and scales through buffer resources: 32-bit byte offsets)
+  const long long lim = 1ll << 31;
+  const bool small_images = (long long)p.M * p.A.ld < lim && (long long)p.N * p.B.ld < lim && (long long)p.M * al < lim && (long long)p.N * bl < lim;
+  if (small_images && (g_mx8_tile == 2 || (g_mx8_tile == 0 && mx8_256_pays(p.M, p.N)))) {
+    switch (nt_feat_of(p, c_vec_ok)) {
+      case 0: return launch_mx8p_as<0>(p, c_vec_ok, a_scale, al, b_scale, bl, s);
+      case F_GELU | F_PRE: return launch_mx8p_as<F_GELU | F_PRE>(p, c_vec_ok, a_scale, al, b_scale, bl, s);
+      case F_DROP | F_RES: return launch_mx8p_as<F_DROP | F_RES>(p, c_vec_ok, a_scale, al, b_scale, bl, s);
+      case F_DACT: return launch_mx8p_as<F_DACT>(p, c_vec_ok, a_scale, al, b_scale, bl, s);
+      case F_BETA: return launch_mx8p_as<F_BETA>(p, c_vec_ok, a_scale, al, b_scale, bl, s);
+      case F_RES: return launch_mx8p_as<F_RES>(p, c_vec_ok, a_scale, al, b_scale, bl, s);
+      default: return launch_mx8p_as<-1>(p, c_vec_ok, a_scale, al, b_scale, bl, s);
+    }
+  }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, 1, 1);
-  const long long al = a_scale_ld, bl = b_scale_ld;
   switch (nt_feat_of(p, c_vec_ok)) {
     case 0: return launch_mx8_as<0>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
     case F_GELU | F_PRE: return launch_mx8_as<F_GELU | F_PRE>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
@@ -2609,6 +2883,18 @@ extern "C" int st5_quant_mxfp8(const void* x, int64_t ld, void* q, int64_t q_ld,
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(quant_mx8_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16_t*)x, (long long)ld,
                      (unsigned char*)q, (long long)q_ld, (unsigned char*)s, (long long)s_ld, (long long)rows, (int)cols);
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+
+/* njobs contiguous bf16 matrices quantised as st5_quant_mxfp8 would, in one launch.  jobs: device array of njobs records
+ * { const void* x; void* q; uint8_t* s; int64 elems (= rows * cols, cols % 32 == 0); int32 cols; int32 blk0 } with blk0 = the job's first
+ * block (2048 elements per block, jobs in ascending blk0 order, blk0 of job 0 == 0); nblocks = total block count. */
+extern "C" int st5_multi_quant_mxfp8(const void* jobs, int32_t njobs, int32_t nblocks, void* stream) {
+  if (!jobs || njobs < 0 || nblocks < 0) return ST5_ERR_ARG;
+  if (njobs == 0 || nblocks == 0) return ST5_OK;
+  hipLaunchKernelGGL(multi_quant_mx8_kernel, dim3((unsigned)nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const QuantJob*>(jobs), (int)njobs);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -2650,4 +2936,6 @@ extern "C" int st5_gemm_set_deep_ring(int max_blocks, int nbuf) {
  * 2 = the same without the stagger of the two m-halves (A/B measurements; the header documents the same default). */
 extern "C" int st5_gemm_set_tn_phased(int mode) { if (mode < 0 || mode > 2) return ST5_ERR_ARG; g_tn8p = mode; return ST5_OK; }
 extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 5) return ST5_ERR_ARG; g_nt_tile = mode; return ST5_OK; }
+/* MX-fp8 NT block tile: 0 = per-problem choice (default), 1 = 128x128 always, 2 = phased 256x256 always (A/B measurements, tests). */
+extern "C" int st5_gemm_set_mx8_tile(int mode) { if (mode < 0 || mode > 2) return ST5_ERR_ARG; g_mx8_tile = mode; return ST5_OK; }
 extern "C" int st5_gemm_set_m64_max_tiles(int tiles) { if (tiles < 0) return ST5_ERR_ARG; g_m64_max_tiles = tiles; return ST5_OK; }

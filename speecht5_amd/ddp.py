@@ -881,5 +881,7 @@ class FusedAdam:
                 #  shorter micro-batch chain.  Measured: 30.5 against 30.15 ms per update, same box, alternating: the one extra
                 #  cross-stream event inside the replayed graph costs more than the 0.24 ms it moves.  Off.)
                 self.mirror.mark_stale()
+                Fn.fp8_mirror.off = True
             else:
                 self.mirror.refresh_transposes()
+                Fn.fp8_mirror.refresh()     # (fp8 mode: every weight's e4m3 image + block scales in one launch; no-op otherwise)

@@ -317,6 +317,7 @@ class _Bf16Mirror:
 
     def attach(self, flat_bf16, params, offsets):
         self.__init__()
+        fp8_mirror.reset()
         self.flat = flat_bf16
         for p, off in zip(params, offsets):
             p._st5_moff = off
@@ -484,7 +485,79 @@ def _fp8_ok(M, N, K, dtype):
 
 def _quant_cached(kind, weights, mat):
     """(q, scales) of a cached compute-dtype weight matrix, themselves cached until the parameters change."""
+    hit = fp8_mirror.quantised(mat)
+    if hit is not None:
+        return hit
     return weight_cache.get((kind,) + tuple(id(w) for w in weights), weights, lambda: hip.quant_mxfp8(mat))
+
+
+class _Fp8Mirror:
+    """fp8 images (e4m3 bytes + e8m0 block scales) of the weight matrices the fp8 GEMMs read, kept current by ONE batched
+    quantisation launch per optimizer step (st5_multi_quant_mxfp8, behind the batched transpose of _Bf16Mirror whose copies are the
+    data-gradient sources) -- round 6.  Before, every weight and every transposed weight was quantised by a launch of its own, once per
+    update, on whichever micro-batch stream reached the Linear first (~280 launches of 2-5 us and as many cross-stream event waits
+    inside the replayed graph).  Only matrices that live in the bf16 mirror's two pools (stable addresses, refreshed by the optimizer
+    step) are registered; everything else keeps the per-step cache."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.jobs = {}          # (address, rows, cols) -> (source view, q, scales)
+        self.first = {}         # key -> (event, raw stream) of an image produced by a first-use launch since the last batched refresh
+        self.jobs_dev = None
+        self.nblocks = 0
+        self.dirty = False
+        self.off = False        # (set when the optimizer step does not refresh: lazy-transpose A/B mode)
+
+    def quantised(self, W):
+        m = bf16_mirror
+        if self.off or m.flat is None or m.stale or not W.is_cuda or W.dtype != torch.bfloat16:
+            return None
+        st = W.untyped_storage().data_ptr()
+        if st != m.flat.untyped_storage().data_ptr() and (m.tflat is None or st != m.tflat.untyped_storage().data_ptr()):
+            return None
+        if W.dim() != 2 or not W.is_contiguous() or W.shape[1] % 32:
+            return None
+        key = (W.data_ptr(), W.shape[0], W.shape[1])
+        hit = self.jobs.get(key)
+        if hit is not None:
+            ev = self.first.get(key)
+            if ev is not None and ev[1] != hip.stream():
+                # produced on ANOTHER stream earlier in this very update (first use, before any batched refresh has covered it)
+                torch.cuda.current_stream().wait_event(ev[0])
+            return hit[1], hit[2]
+        q, sc = hip.quant_mxfp8(W)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.first[key] = (ev, hip.stream())
+        self.jobs[key] = (W, q, sc)
+        self.dirty = True
+        return q, sc
+
+    def refresh(self):
+        """Re-quantise every registered matrix from its (just refreshed) bf16 source: one launch, on the optimizer's stream."""
+        self.first = {}
+        if self.off or not self.jobs or not _FP8.enabled:
+            if self.jobs and not _FP8.enabled:
+                self.reset()    # (mode switched off: the images would go stale)
+            return
+        if self.dirty or self.jobs_dev is None:
+            import struct
+            recs, blk0 = [], 0
+            for (W, q, sc) in self.jobs.values():
+                n = W.numel()
+                recs.append(struct.pack("<QQQqii", W.data_ptr(), q.data_ptr(), sc.data_ptr(), n, W.shape[1], blk0))
+                blk0 += (n + 2047) // 2048
+            self.nblocks = blk0
+            dev = next(iter(self.jobs.values()))[0].device
+            self.jobs_dev = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+            self.dirty = False
+        hip.check(hip.lib().st5_multi_quant_mxfp8(self.jobs_dev.data_ptr(), len(self.jobs), self.nblocks, hip.stream()),
+                  "st5_multi_quant_mxfp8")
+
+
+fp8_mirror = _Fp8Mirror()
 
 
 def _nt_gemm(a2, weights, transposed, C, M, N, K, dtype, **epi):

@@ -45,6 +45,7 @@ _SIGS = {
     "st5_stream_fork": (c_int, [c_void_p, c_void_p]),
     "st5_gemm_set_nt_tile": (c_int, [c_int]),
     "st5_gemm_set_m64_max_tiles": (c_int, [c_int]),
+    "st5_gemm_set_mx8_tile": (c_int, [c_int]),
     "st5_gemm_set_splitk_target": (c_int, [c_int]),
     "st5_gemm_set_deep_ring": (c_int, [c_int, c_int]),
     "st5_gemm_set_nt_slots": (c_int, [c_int]),
@@ -84,6 +85,7 @@ _SIGS = {
     "st5_gemm_set_tn_phased": (c_int, [c_int]),
     "st5_gemm_mxfp8": (c_int, [POINTER(GemmParams), c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "st5_quant_mxfp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    "st5_multi_quant_mxfp8": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "st5_flash_attn_qp_row": (c_int32, [c_int32]),
     "st5_flash_attn_qp_table": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_int, c_void_p]),
     "st5_conv0_gn_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,

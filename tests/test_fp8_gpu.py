@@ -110,6 +110,58 @@ def test_mx_gemm_matches_fp32_matmul_of_the_dequantised_operands(cuda, M, N, K):
         assert float((y2.float() - (want_pre + R.float())).abs().max()) <= 1e-2 * float(want_pre.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 256), (300, 520, 384), (1000, 1024, 1024), (257, 264, 640), (4096, 1024, 4096)])
+def test_phased_256_tile_mx_kernel_is_bit_identical_to_the_128_tile_kernel(cuda, M, N, K):
+    """Round 6: gemm_nt8p_mx8_kernel (st5_gemm_set_mx8_tile(2): phased 256 x 256 schedule on fp8 bytes, scales through buffer loads one
+    k-tile ahead, last two k-tiles peeled) runs every output element through the MFMA chain of the 128 x 128 kernel: equal bits, for
+    1 / 2 / 3 / many k-tiles, M / N tails inside a tile, and every fused epilogue class of the training step."""
+    torch.manual_seed(M * 7 + N)
+    L = hip.lib()
+    A = torch.randn(M, K, device=cuda).to(torch.bfloat16)
+    B = (torch.randn(N, K, device=cuda) * 0.05).to(torch.bfloat16)
+    A[5] *= 300.0; B[3] *= 40.0; A[M - 1] *= 1e-3                         # rows with very different scale bytes
+    Aq, As = hip.quant_mxfp8(A)
+    Bq, Bs = hip.quant_mxfp8(B)
+    bias = torch.randn(N, device=cuda)
+    R = torch.randn(M, N, device=cuda).to(torch.bfloat16)
+    P = torch.randn(M, N, device=cuda).to(torch.bfloat16)
+
+    def run(mode):
+        hip.check(L.st5_gemm_set_mx8_tile(mode), "st5_gemm_set_mx8_tile")
+        outs = []
+        try:
+            C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=cuda)
+            hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(C, N), M, N, K)
+            outs.append(C)
+            y, pre = torch.empty_like(C), torch.empty_like(C)
+            hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(y, N), M, N, K, bias=bias, act=hip.ACT_GELU, Cpre=hip.operand(pre, N))
+            outs += [y, pre]
+            y2 = torch.empty_like(C)
+            hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(y2, N), M, N, K, bias=bias, R=hip.operand(R, N), dropout_p=0.1, seed=11)
+            outs.append(y2)
+            y3 = torch.empty_like(C)
+            hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(y3, N), M, N, K, P=hip.operand(P, N), act=hip.ACT_GELU, flags=hip.DACT)
+            outs.append(y3)
+            y4 = R.clone()
+            hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(y4, N), M, N, K, beta=1.0)
+            outs.append(y4)
+            y5 = torch.empty_like(C)
+            hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(y5, N), M, N, K, R=hip.operand(R, N))
+            outs.append(y5)
+            torch.cuda.synchronize()
+        finally:
+            hip.check(L.st5_gemm_set_mx8_tile(0), "st5_gemm_set_mx8_tile")
+        return outs
+
+    small, big = run(1), run(2)
+    for i, (a, b) in enumerate(zip(small, big)):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), \
+            f"output {i}: {int((a.view(torch.int16) != b.view(torch.int16)).sum())} of {a.numel()} elements differ"
+    ref = _deq(Aq, As) @ _deq(Bq, Bs).t()
+    assert float((big[0].float() - ref).abs().max()) <= 6e-3 * float(ref.abs().max())
+
+
 def test_fp8_linear_against_bf16_linear(cuda):
     """The quantisation error of one Linear at Large's shapes: cosine with the bf16 result."""
     torch.manual_seed(0)
