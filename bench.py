@@ -355,6 +355,12 @@ def main():
         hip.lib().st5_gemm_set_nt_tile(int(os.environ["ST5_NT_TILE"]))
     if os.environ.get("ST5_DEEP_RING"):   # A/B: "max_blocks,nbuf" of the 128x128 NT kernel's deep operand ring (nbuf 2 = off)
         hip.lib().st5_gemm_set_deep_ring(*[int(v) for v in os.environ["ST5_DEEP_RING"].split(",")])
+    if os.environ.get("ST5_MX8_HEAVY_NK"):   # A/B (fp8 mode): k-tiles an epilogue-heavy fp8 GEMM needs before it takes the phased 256x256 kernel
+        hip.lib().st5_gemm_set_mx8_heavy_nk(int(os.environ["ST5_MX8_HEAVY_NK"]))
+    if os.environ.get("ST5_MX8_TILE"):       # A/B (fp8 mode): 1 = 128x128 always, 2 = phased 256x256 always
+        hip.lib().st5_gemm_set_mx8_tile(int(os.environ["ST5_MX8_TILE"]))
+    if os.environ.get("ST5_TN_GROUP_TILE"):  # A/B: 1 = grouped weight gradients on 128x128 tiles always (default: phased 256x256 where the shapes allow)
+        hip.lib().st5_gemm_set_tn_group_tile(int(os.environ["ST5_TN_GROUP_TILE"]))
     if os.environ.get("ST5_SPLITK_TARGET"):   # A/B: block count the weight-gradient split-K aims for
         hip.lib().st5_gemm_set_splitk_target(int(os.environ["ST5_SPLITK_TARGET"]))
     if os.environ.get("ST5_CONV0_MFMA"):  # A/B: 0 = VALU form of conv layer 0's forward apply pass (default 1: matrix cores)

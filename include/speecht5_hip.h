@@ -129,10 +129,19 @@ int st5_gemm_set_nt_slots(int slots);
  * Replaces the same F.linear call sites as st5_gemm when the fp8 compute mode is on (speecht5_amd.functional.set_fp8). */
 int st5_gemm_mxfp8(const st5_gemm_params* p, const uint8_t* a_scale, int64_t a_scale_ld, const uint8_t* b_scale, int64_t b_scale_ld,
                    void* stream);
+/* st5_gemm_mxfp8 whose bf16 output C [M x N] (N % 32 == 0, plain layout) is ALSO written as its MX-fp8 image -- out_q [M x N] e4m3 bytes,
+ * out_s [M x N/32] e8m0 scale bytes: the bytes st5_quant_mxfp8 would produce from C -- by the epilogue, for the two producers whose output is
+ * the next fp8 GEMM's A operand: bias + GELU with the pre-activation copy (fc1 forward, transformer_layer.py:127-131) and x act'(P) (the data
+ * gradient of fc2).  Any other epilogue combination: ST5_ERR_ARG. */
+int st5_gemm_mxfp8_q(const st5_gemm_params* p, const uint8_t* a_scale, int64_t a_scale_ld, const uint8_t* b_scale, int64_t b_scale_ld,
+                     void* out_q, int64_t out_q_ld, uint8_t* out_s, int64_t out_s_ld, void* stream);
 /* Block tile of st5_gemm_mxfp8: 0 (default) = per problem -- the phased 256x256 kernel (gemm_nt8p_mx8_kernel: st5_gemm's phased bf16
  * schedule on fp8 bytes, twice the reduction depth per LDS byte and matrix-pipe cycle) for problems of several rounds of 256x256 tiles
  * or one nearly full round, else 128x128; 1 = 128x128 always, 2 = phased 256x256 always.  Results are bit-identical for every choice. */
 int st5_gemm_set_mx8_tile(int mode);
+/* The per-problem choice keeps launches with a heavy epilogue (GELU / its derivative, pre-activation copy, dropout, fp8 image) on 128x128
+ * tiles, two blocks per CU, unless the reduction has at least `nk` k-tiles of 128 (default 16; 0 = no such rule).  A/B knob. */
+int st5_gemm_set_mx8_heavy_nk(int nk);
 /* MX quantisation along rows of a bf16 matrix x [rows x cols] (ld elements, cols % 32 == 0): q = e4m3(x * 2^(127 - s)) bytes
  * (pitch q_ld), s[r][c / 32] = floor(log2(max|finite block elements|)) - 8 + 127 as e8m0 (pitch s_ld); round to nearest even, finite
  * values saturating at +-448.  NaN / Inf propagate: the element becomes the e4m3 NaN code 0x7f and its block's scale the e8m0 NaN 0xff,
@@ -150,6 +159,12 @@ int st5_multi_quant_mxfp8(const void* jobs, int32_t njobs, int32_t nblocks, void
  * independent of what it is grouped with (bit for bit).  A group with a problem of another form, or with two problems writing the same
  * output, runs through st5_gemm one by one. */
 int st5_gemm_tn_group(const st5_gemm_params* list, int32_t n, int dtype, void* stream);
+/* Block tile of st5_gemm_tn_group: 0 (default) = per problem -- the phased 256x256 grouped kernel (gemm_tn8p_group_kernel: whole token
+ * reductions on st5_gemm's phased schedule; weight gradients bit-identical to the 128x128 group, bias-gradient column summed on the VALU in
+ * its own fixed order) when M and N are multiples of 256 and K >= 512, i.e. every Linear of the transformer; 1 = 128x128 always. */
+int st5_gemm_set_tn_group_tile(int mode);
+/* 1 when st5_gemm_tn_group would run a weight gradient of this shape on the phased kernel (host-side accounting of 256x256 tiles). */
+int st5_gemm_tn_group_is_phased(int32_t M, int32_t N, int32_t K);
 int st5_gemm_defer_splitk(int enabled, void* stream);
 int st5_gemm_flush_splitk(void* stream);
 
@@ -166,6 +181,11 @@ int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
 /* Batched dgamma / dbeta reductions: while enabled, st5_layernorm_bwd leaves its block partials in an internal arena and
  * st5_layernorm_flush(stream) folds all pending LayerNorms' partials into their dgamma / dbeta with ONE launch (same stream
  * as the st5_layernorm_bwd calls; the owner of the gradient buffers flushes wherever gradients must be complete). */
+/* st5_layernorm_fwd for bf16 rows with cols % 32 == 0 (cols <= 2048) that also writes y's MX-fp8 image (q [rows x cols] e4m3 bytes,
+ * sc [rows x cols / 32] e8m0 scale bytes: the bytes st5_quant_mxfp8 produces from y): the LayerNorm in front of the QKV projection / fc1 of
+ * a pre-LN layer in fp8 compute mode (transformer_layer.py:103-110,124-126 with `encoder_normalize_before`). */
+int st5_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* q, uint8_t* sc,
+                         int64_t rows, int32_t cols, float eps, void* stream);
 /* The LayerDrop gate folded into a post-LN layer's LAST LayerNorm (modules/encoder.py:251-257, modules/decoder.py:64-67 inside a
  * replayed step, see st5_select): forward  y = *keep ? LN(x) * gamma + beta : skip  (skip = the layer's input, same shape and dtype);
  * backward  as st5_layernorm_bwd with dy counted as zero when *keep == 0 (dx = 0, nothing added to dgamma / dbeta).  The gradient

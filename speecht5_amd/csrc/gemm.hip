@@ -252,12 +252,59 @@ __device__ __forceinline__ void store_vec(U* p, bool full, int ne, const float (
   }
 }
 
+// One lane's share of an MX block: 8 consecutive bf16 of a row (4 lanes = one 32-element block, aligned in the wave) -> 8 e4m3 bytes
+// and, from the block's first lane, the e8m0 scale byte.
+__device__ __forceinline__ void mx8_quant8(const float (&v)[8], unsigned char* __restrict__ q8, unsigned char* __restrict__ sbyte, const bool leader) {
+  // Non-finite inputs PROPAGATE (ADVICE r4): fmaxf ignores a NaN and the clamp below would turn NaN / Inf into +-448, so a diverged
+  // activation or gradient would never reach the loss / the gradient norm in fp8 mode.  The block maximum is taken over the FINITE
+  // elements (an Inf must not push the scale to 2^120 and zero its 31 neighbours); a non-finite element gets the e4m3 NaN code
+  // 0x7f, and the block's scale byte becomes the e8m0 NaN 0xff (OCP MX: the whole block then dequantises to NaN).
+  float amax = 0.f;
+  unsigned int nf = 0u;          // bit e: element e is NaN or Inf
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool bad = (__float_as_uint(v[e]) & 0x7f800000u) == 0x7f800000u;
+    nf |= bad ? (1u << e) : 0u;
+    amax = fmaxf(amax, bad ? 0.f : fabsf(v[e]));
+  }
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  unsigned int nf_blk = nf != 0u ? 1u : 0u;
+  nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 1, 64);
+  nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 2, 64);
+  int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;      // biased exponent of amax, minus emax(e4m3)
+  E = E < 0 ? 0 : (E > 254 ? 254 : E);
+  const float inv = __uint_as_float((unsigned int)(254 - E) << 23);    // 2^(127 - E)
+  u32x2 o;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    float f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = ((nf >> (4 * w + e)) & 1u) ? 0.f : v[4 * w + e] * inv;
+      f[e] = fminf(fmaxf(t, -448.f), 448.f);
+    }
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+    unsigned int u = (unsigned int)pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((nf >> (4 * w + e)) & 1u) u = (u & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
+    o[w] = u;
+  }
+  *reinterpret_cast<u32x2*>(q8) = o;
+  if (leader) *sbyte = nf_blk ? (unsigned char)0xff : (unsigned char)E;
+}
+
 struct EpiArgs {  // everything the epilogue needs, by value
   void* C; const void* R; const void* P; void* Cpre; const float* bias;
   long long c_ld, c_bs, r_ld, r_bs, p_ld, p_bs, q_ld, q_bs;
   int rpb, M, N, act, out_f32, dact, c_vec_ok, atomic, fast;
   float alpha, beta, dropout_p;
   unsigned long long seed, ctr_base;
+  // F_Q8 instantiations only (fp8 mode): the MX-fp8 image of the bf16 output for the NEXT fp8 GEMM's A operand, written beside it
+  unsigned char* q8; unsigned char* s8; long long q8_ld, s8_ld;
 };
 
 __device__ __forceinline__ void stage_write(float* stage, const f32x16& acc0, const f32x16& acc1, const int lane) {
@@ -353,7 +400,11 @@ __device__ __forceinline__ void epilogue_rows(const EpiArgs& ea, const float* st
 // while the other resident block is in its k-loop.  Measured: removing only the tanh / LeakyReLU cases from the activation switch
 // made the step's NT launches 4.5 % faster; the hot combinations of the training step therefore get kernels of their own
 // (nt_feat_of() picks, the run-time form stays the fallback).
-enum { F_GELU = 1, F_DACT = 2, F_DROP = 4, F_RES = 8, F_PRE = 16, F_BETA = 32 };
+enum { F_GELU = 1, F_DACT = 2, F_DROP = 4, F_RES = 8, F_PRE = 16, F_BETA = 32, F_Q8 = 64 };
+// F_Q8 (round 6, fp8 mode; compile-time only): the output tile is also MX-quantised in the epilogue -- a lane holds 8 consecutive
+// columns of a row, 4 lanes one 32-element MX block (tile columns start at multiples of 64) -- exactly as st5_quant_mxfp8 would
+// quantise the bf16 output (the ROUNDED values are quantised: same bytes), so the consumer GEMM needs no quantisation pass: the
+// K = 4096 passes over the FFN's hidden activations and their gradients were the largest of them (38-76 us per GEMM at Large B = 32).
 template <typename T, typename OUT, int FEAT = -1, int HALVES = 2>   // (HALVES = 1: a 32 x 64 wave tile, acc00 / acc01 only)
 __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, const f32x16& acc00, const f32x16& acc01,
                                               const f32x16& acc10, const f32x16& acc11, const int mbase, const int nbase,
@@ -443,6 +494,12 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
             for (int e = 0; e < 8; ++e) x[e] = fmaf(ea.beta, ov[e], x[e]);
           }
           store8f<OUT>(Cb + c_off, x);
+          if constexpr (FEAT >= 0 && (FEAT & F_Q8) != 0) {
+            float xr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xr[e] = Elem<OUT>::to_f(Elem<OUT>::from_f(x[e]));
+            mx8_quant8(xr, ea.q8 + (long long)gm * ea.q8_ld + gn, ea.s8 + (long long)gm * ea.s8_ld + (gn >> 5), (lane & 3) == 0);
+          }
         }
       }
     }
@@ -1904,8 +1961,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_group_kernel(const TnGrou
 // (four floats per lane; the 128^2 kernel spends an extra MFMA column on it), in a fixed order: deterministic, no atomics.
 // Not here: row-split / segmented operands (conv weight gradients) -- those stay on gemm_tn_glds_kernel.
 // ------------------------------------------------------------------------------------------------------
+// (bx of nwg: this block's tile among the problem's 256 x 256 tiles; by of ny: its split of the reduction -- the launch grid's own numbers
+//  for the single-problem kernel, problem-local ones inside a grouped launch)
 template <int FEAT, bool STAGGER>
-__global__ __launch_bounds__(512) void gemm_tn8p_kernel(const st5_gemm_params p, const int c_vec_ok) {
+__device__ __forceinline__ void tn8p_body(const st5_gemm_params& p, const int c_vec_ok, const int bx, const int nwg_, const int by, const int ny) {
   typedef bf16_t T;
   constexpr int BK = 64;
   constexpr int HALF = TILE_BYTES;
@@ -1915,20 +1974,20 @@ __global__ __launch_bounds__(512) void gemm_tn8p_kernel(const st5_gemm_params p,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_n = (p.N + 255) / 256;
-  int bid = blockIdx.x;
+  int bid = bx;
   {
-    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
+    const int nwg = nwg_, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
   int tm, tn;
-  tile_of(bid, tiles_n, (int)gridDim.x, tm, tn);
+  tile_of(bid, tiles_n, nwg_, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
   const T* Ap = reinterpret_cast<const T*>(p.A.ptr);
   const T* Bp = reinterpret_cast<const T*>(p.B.ptr);
 
   const int nk_all = (p.K + BK - 1) / BK;
-  const int per = (nk_all + gridDim.y - 1) / gridDim.y;
-  const int kt0 = blockIdx.y * per;
+  const int per = (nk_all + ny - 1) / ny;
+  const int kt0 = by * per;
   int nk = nk_all - kt0; nk = nk < per ? nk : per; nk = nk > 0 ? nk : 0;
 
   // LDS-DMA sources.  Instruction i of this wave covers half-tile rows (k) (i * 8 + wave) * 4 .. +3: lane l -> row + (l >> 4), physical
@@ -2063,7 +2122,9 @@ __global__ __launch_bounds__(512) void gemm_tn8p_kernel(const st5_gemm_params p,
   __syncthreads();
 
   if (do_asum) {
-    bool accumulate; float* dst = asum_target(p, accumulate);
+    // (as asum_target: in place without split-K, else this split's column behind the slabs)
+    const bool accumulate = ny == 1;
+    float* dst = accumulate ? p.asum : reinterpret_cast<float*>(const_cast<void*>(p.C.ptr)) + (long long)ny * p.M * p.N + (long long)by * p.M;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float v = rsum[i] + __shfl_xor(rsum[i], 32, 64);
@@ -2081,12 +2142,34 @@ __global__ __launch_bounds__(512) void gemm_tn8p_kernel(const st5_gemm_params p,
   ea.out_f32 = (p.flags & ST5_GEMM_OUT_F32) != 0; ea.dact = (p.flags & ST5_GEMM_DACT) != 0; ea.c_vec_ok = c_vec_ok;
   ea.atomic = 0;
   ea.fast = c_vec_ok && (p.N % 8 == 0);
-  if (gridDim.y > 1) ea.C = reinterpret_cast<float*>(ea.C) + (long long)blockIdx.y * p.M * p.N;
+  if (ny > 1) ea.C = reinterpret_cast<float*>(ea.C) + (long long)by * p.M * p.N;
   ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
   ea.ctr_base = 0ull;
   float* stg = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
   run_epilogue<T, FEAT, float>(ea, stg, acc[0][0], acc[0][1], acc[1][0], acc[1][1], m0 + wr * 128, n0 + wc * 64, lane);
   run_epilogue<T, FEAT, float>(ea, stg, acc[2][0], acc[2][1], acc[3][0], acc[3][1], m0 + wr * 128 + 64, n0 + wc * 64, lane);
+}
+
+template <int FEAT, bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_tn8p_kernel(const st5_gemm_params p, const int c_vec_ok) {
+  tn8p_body<FEAT, STAGGER>(p, c_vec_ok, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// The grouped weight-gradient launch (gemm_tn_group_kernel) on the PHASED 256 x 256 schedule (round 6).  A layer's weight gradients are
+// 108 (Base) / 192 (Large) tiles of 256 x 256 with whole token reductions; two layers' worth (or a layer and a bit) is one block on nearly
+// every CU, and a whole-token reduction is 60-250 k-tiles: the regime where the phased schedule is 1.3-1.5x the 128^2 kernel per flop (its
+// exposed prologue / 128 KB store epilogue amortised) and the fabric sees every operand stripe N / 256 instead of N / 128 times.  As in the
+// 128^2 group: every tile runs its own whole reduction and accumulates into the gradient buffer (no slabs, no reduction kernel), block
+// ranges start at multiples of 8 (XCD-aware tile order inside every problem), a problem's result does not depend on its group.  Every
+// output element sees the MFMA chain of the 128^2 kernels (k-tiles ascending, four 16-deep groups each): the WEIGHT gradients are
+// bit-identical to gemm_tn_group_kernel's; the bias-gradient column is summed on the VALU here (tn8p_body), in another -- fixed -- order.
+template <int FEAT>
+__global__ __launch_bounds__(512) void gemm_tn8p_group_kernel(const TnGroupArgs g) {
+  int j = 0;
+  while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
+  const int lb = (int)blockIdx.x - g.first[j];
+  if (lb >= g.tiles[j]) return;
+  tn8p_body<FEAT, true>(g.p[j], 1, lb, g.tiles[j], 0, 1);
 }
 
 int g_tn8p = 0;   // st5_gemm_set_tn_phased: 0 (default) = always the 128^2 kernel; 1 / 2 = eligible weight-gradient GEMMs on the phased 256^2 kernel (staggered / not).
@@ -2187,6 +2270,8 @@ bool nt256_pays(int M, int N, int nk64, int batch) {
 // tile get pre-shifted copies of the dword.
 // ------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) int i32x8;
+// (F_Q8 instantiations: where the epilogue writes the MX-fp8 image of the output; null otherwise)
+struct MxOut { unsigned char* q; long long q_ld; unsigned char* s; long long s_ld; };
 
 __device__ __forceinline__ i32x8 mx_frag2(const char* tile, int row, int c0, int c1) {
   const u32x4 lo = *reinterpret_cast<const u32x4*>(tile + lds_off(row, c0));
@@ -2199,7 +2284,7 @@ __device__ __forceinline__ i32x8 mx_frag2(const char* tile, int row, int c0, int
 template <int FEAT>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_mx8_kernel(const st5_gemm_params p, const int c_vec_ok,
                                                                   const unsigned char* __restrict__ sa, const long long sa_ld,
-                                                                  const unsigned char* __restrict__ sb, const long long sb_ld) {
+                                                                  const unsigned char* __restrict__ sb, const long long sb_ld, const MxOut mo) {
   ST5_PAD_TO_256_VGPRS();
   typedef bf16_t T;                 // type of the C-class operands
   constexpr int BK = 128;           // k-elements (= bytes) per tile row
@@ -2312,14 +2397,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_mx8_kernel(const st5_gemm
   ea.fast = c_vec_ok && (p.N % 8 == 0);
   ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
   ea.ctr_base = 0ull;
+  ea.q8 = mo.q; ea.s8 = mo.s; ea.q8_ld = mo.q_ld; ea.s8_ld = mo.s_ld;
   float* stage = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
   run_epilogue<T, FEAT>(ea, stage, acc00, acc01, acc10, acc11, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 template <int FEAT>
 int launch_mx8_as(const st5_gemm_params& p, int c_vec_ok, const unsigned char* sa, long long sa_ld, const unsigned char* sb, long long sb_ld,
-                  dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_nt_mx8_kernel<FEAT>), grid, dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, p, c_vec_ok, sa, sa_ld, sb, sb_ld);
+                  dim3 grid, hipStream_t s, const MxOut mo = MxOut{nullptr, 0, nullptr, 0}) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_mx8_kernel<FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_mx8_kernel<FEAT>), grid, dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, p, c_vec_ok, sa, sa_ld, sb, sb_ld, mo);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -2338,7 +2429,7 @@ int launch_mx8_as(const st5_gemm_params& p, int c_vec_ok, const unsigned char* s
 template <int FEAT, bool STAGGER>
 __global__ __launch_bounds__(512) void gemm_nt8p_mx8_kernel(const st5_gemm_params p, const int c_vec_ok,
                                                             const unsigned char* __restrict__ sa, const long long sa_ld,
-                                                            const unsigned char* __restrict__ sb, const long long sb_ld) {
+                                                            const unsigned char* __restrict__ sb, const long long sb_ld, const MxOut mo) {
   typedef bf16_t T;                             // type of the C-class operands
   constexpr int BK = 128;                       // k-elements (= bytes) per tile row
   constexpr int HALF = TILE_BYTES;              // 16 KB: 128 rows x 128 B
@@ -2531,20 +2622,28 @@ __global__ __launch_bounds__(512) void gemm_nt8p_mx8_kernel(const st5_gemm_param
   ea.fast = c_vec_ok && (p.N % 8 == 0);
   ea.alpha = p.alpha; ea.beta = p.beta; ea.dropout_p = p.dropout_p; ea.seed = p.seed;
   ea.ctr_base = 0ull;
+  ea.q8 = mo.q; ea.s8 = mo.s; ea.q8_ld = mo.q_ld; ea.s8_ld = mo.s_ld;
   float* stg = reinterpret_cast<float*>(dsm) + wave * (32 * EP_LD);
   run_epilogue<T, FEAT>(ea, stg, acc[0][0], acc[0][1], acc[1][0], acc[1][1], m0 + wr * 128, n0 + wc * 64, lane);
   run_epilogue<T, FEAT>(ea, stg, acc[2][0], acc[2][1], acc[3][0], acc[3][1], m0 + wr * 128 + 64, n0 + wc * 64, lane);
 }
 
 // (one block per CU: its prologue and 128 KB store epilogue are exposed, so it wants whole rounds -- see nt256_pays)
-bool mx8_256_pays(int M, int N) {
+// A heavy epilogue (GELU + pre-activation copy, the GELU derivative, dropout, the fp8 image: two or three output tensors or a dozen
+// VALU slots per element) is NOT hidden in a one-block-per-CU kernel; behind a short reduction it costs more than the phased schedule
+// gains (measured inside the Large update, B = 32: fc1 forward N = 4096, K = 1024 with GELU + copy + fp8 image 147 us phased against
+// 113 us + quantiser on 128^2 tiles, while the plain N = 3072 / 4096 launches gain 20-25 %): such launches need >= g_mx8_heavy_nk k-tiles.
+int g_mx8_heavy_nk = 16;
+bool mx8_256_pays(int M, int N, int nk, int feat) {
   const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
-  return t256 >= 448 || (t256 >= 176 && t256 <= 256);
+  if (!(t256 >= 448 || (t256 >= 176 && t256 <= 256))) return false;
+  const bool heavy = feat < 0 || (feat & (F_GELU | F_DACT | F_PRE | F_DROP | F_Q8)) != 0;
+  return !heavy || nk >= g_mx8_heavy_nk;
 }
 int g_mx8_tile = 0;   // 0 = choose per problem, 1 = always 128^2, 2 = always the phased 256^2 kernel (st5_gemm_set_mx8_tile)
 template <int FEAT>
 int launch_mx8p_as(const st5_gemm_params& p, int c_vec_ok, const unsigned char* sa, long long sa_ld, const unsigned char* sb, long long sb_ld,
-                   hipStream_t s) {
+                   hipStream_t s, const MxOut mo = MxOut{nullptr, 0, nullptr, 0}) {
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)gemm_nt8p_mx8_kernel<FEAT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -2552,7 +2651,7 @@ int launch_mx8p_as(const st5_gemm_params& p, int c_vec_ok, const unsigned char* 
     attr = true;
   }
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  hipLaunchKernelGGL((gemm_nt8p_mx8_kernel<FEAT, true>), dim3(tiles, 1, 1), dim3(512), (size_t)8 * TILE_BYTES, s, p, c_vec_ok, sa, sa_ld, sb, sb_ld);
+  hipLaunchKernelGGL((gemm_nt8p_mx8_kernel<FEAT, true>), dim3(tiles, 1, 1), dim3(512), (size_t)8 * TILE_BYTES, s, p, c_vec_ok, sa, sa_ld, sb, sb_ld, mo);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }
@@ -2562,51 +2661,6 @@ int launch_mx8p_as(const st5_gemm_params& p, int c_vec_ok, const unsigned char* 
 // round-to-nearest-even, saturating FINITE values at +-448 (NaN / Inf propagate: see the kernel).  Four lanes per block, 8 elements each: coalesced 16-byte loads and 8-byte stores
 // (the first version gave a lane a whole block: 64-byte stride between the lanes of every load instruction), the block maximum by
 // two quad shuffles.
-// One lane's share of an MX block: 8 consecutive bf16 of a row (4 lanes = one 32-element block, aligned in the wave) -> 8 e4m3 bytes
-// and, from the block's first lane, the e8m0 scale byte.
-__device__ __forceinline__ void mx8_quant8(const float (&v)[8], unsigned char* __restrict__ q8, unsigned char* __restrict__ sbyte, const bool leader) {
-  // Non-finite inputs PROPAGATE (ADVICE r4): fmaxf ignores a NaN and the clamp below would turn NaN / Inf into +-448, so a diverged
-  // activation or gradient would never reach the loss / the gradient norm in fp8 mode.  The block maximum is taken over the FINITE
-  // elements (an Inf must not push the scale to 2^120 and zero its 31 neighbours); a non-finite element gets the e4m3 NaN code
-  // 0x7f, and the block's scale byte becomes the e8m0 NaN 0xff (OCP MX: the whole block then dequantises to NaN).
-  float amax = 0.f;
-  unsigned int nf = 0u;          // bit e: element e is NaN or Inf
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const bool bad = (__float_as_uint(v[e]) & 0x7f800000u) == 0x7f800000u;
-    nf |= bad ? (1u << e) : 0u;
-    amax = fmaxf(amax, bad ? 0.f : fabsf(v[e]));
-  }
-  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-  unsigned int nf_blk = nf != 0u ? 1u : 0u;
-  nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 1, 64);
-  nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 2, 64);
-  int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;      // biased exponent of amax, minus emax(e4m3)
-  E = E < 0 ? 0 : (E > 254 ? 254 : E);
-  const float inv = __uint_as_float((unsigned int)(254 - E) << 23);    // 2^(127 - E)
-  u32x2 o;
-#pragma unroll
-  for (int w = 0; w < 2; ++w) {
-    float f[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float t = ((nf >> (4 * w + e)) & 1u) ? 0.f : v[4 * w + e] * inv;
-      f[e] = fminf(fmaxf(t, -448.f), 448.f);
-    }
-    int pk = 0;
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
-    unsigned int u = (unsigned int)pk;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if ((nf >> (4 * w + e)) & 1u) u = (u & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
-    o[w] = u;
-  }
-  *reinterpret_cast<u32x2*>(q8) = o;
-  if (leader) *sbyte = nf_blk ? (unsigned char)0xff : (unsigned char)E;
-}
-
 __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict__ x, long long ld, unsigned char* __restrict__ q, long long q_ld,
                                                         unsigned char* __restrict__ s, long long s_ld, long long rows, int cols) {
   const int ng = cols >> 3;                 // 8-element groups per row (a multiple of 4: cols % 32 == 0)
@@ -2770,26 +2824,44 @@ extern "C" int st5_gemm(const st5_gemm_params* pp, int dtype, void* stream) {
  * bias-gradient column) as ONE launch without split-K (gemm_tn_group_kernel).  A problem's result does not depend on the rest of the
  * group (every tile runs its own whole reduction).  Falls back to one st5_gemm call per problem when a problem does not have that form
  * or two problems write the same output. */
+int g_tn_group_tile = 0;   // st5_gemm_set_tn_group_tile: 0 = per problem (phased 256^2 when M, N are multiples of 256 and K >= 512), 1 = 128^2 always
+// Does this (group-eligible) problem run on the phased 256 x 256 grouped kernel?  A function of the problem alone.
+bool tn_group_phased(const st5_gemm_params& p) {
+  return g_tn_group_tile == 0 && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 512 && p.C.ld % 4 == 0 && !p.A.rpb && !p.B.rpb && !p.A.seg && !p.B.seg;
+}
 extern "C" int st5_gemm_tn_group(const st5_gemm_params* list, int32_t n, int dtype, void* stream) {
   if (!list || n < 0) return ST5_ERR_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_tn8p_group_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_tn8p_group_kernel<F_BETA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return ST5_ERR_LAUNCH;
+    attr = true;
+  }
   TnGroupArgs g;
   int m = 0;             // problems in g
   long long padded = 0;
-  bool accum = false;
+  bool accum = false, phased = false;
   auto launch = [&]() {
     if (m == 0) return (int)ST5_OK;
     g.first[m] = (int)padded; g.n = m;
     for (int i = m; i < TNG_MAX; ++i) { g.tiles[i] = 0; g.first[i + 1] = (int)padded; }
-    if (accum) hipLaunchKernelGGL(gemm_tn_group_kernel<F_BETA>, dim3((unsigned)padded), dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, g);
-    else hipLaunchKernelGGL(gemm_tn_group_kernel<0>, dim3((unsigned)padded), dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, g);
+    if (phased) {
+      if (accum) hipLaunchKernelGGL(gemm_tn8p_group_kernel<F_BETA>, dim3((unsigned)padded), dim3(512), (size_t)8 * TILE_BYTES, s, g);
+      else hipLaunchKernelGGL(gemm_tn8p_group_kernel<0>, dim3((unsigned)padded), dim3(512), (size_t)8 * TILE_BYTES, s, g);
+    } else {
+      if (accum) hipLaunchKernelGGL(gemm_tn_group_kernel<F_BETA>, dim3((unsigned)padded), dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, g);
+      else hipLaunchKernelGGL(gemm_tn_group_kernel<0>, dim3((unsigned)padded), dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, g);
+    }
     m = 0; padded = 0;
     HIP_CHECK_LAUNCH();
     return (int)ST5_OK;
   };
-  // Whether a problem runs here (whole reduction per tile) or through st5_gemm (split-K) is decided by the problem ALONE, never by what it
-  // is queued with: a replayed update and an eager one, or two micro-batch schedules, form different groups and still have to agree bit
-  // for bit.  (No fall-back on the size of a group either; the under-filled ones are the leftovers at the end of a backward pass.)
+  // Whether a problem runs here (whole reduction per tile) or through st5_gemm (split-K), and on which block tile, is decided by the
+  // problem ALONE, never by what it is queued with: a replayed update and an eager one, or two micro-batch schedules, form different
+  // groups and still have to agree bit for bit.  (No fall-back on the size of a group either; the under-filled ones are the leftovers at
+  // the end of a backward pass.)
   for (int i = 0; i < n; ++i) {
     st5_gemm_params p = list[i];
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A.ptr || !p.B.ptr || !p.C.ptr) return ST5_ERR_ARG;
@@ -2805,22 +2877,31 @@ extern "C" int st5_gemm_tn_group(const st5_gemm_params* list, int32_t n, int dty
       if (rc) return rc;
       continue;
     }
-    bool clash = m == TNG_MAX || (m > 0 && (p.beta != 0.f) != accum);
+    const bool ph = tn_group_phased(p);
+    bool clash = m == TNG_MAX || (m > 0 && ((p.beta != 0.f) != accum || ph != phased));
     for (int j = 0; j < m && !clash; ++j) clash = g.p[j].C.ptr == p.C.ptr || (p.asum && g.p[j].asum == p.asum);
-    if (clash) { const int rc = launch(); if (rc) return rc; }      // (same output twice, or mixed beta: in order, one launch each)
-    if (m == 0) accum = p.beta != 0.f;
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (clash) { const int rc = launch(); if (rc) return rc; }      // (same output twice, mixed beta or block tile: in order, one launch each)
+    if (m == 0) { accum = p.beta != 0.f; phased = ph; }
+    const int tiles = ph ? (p.M / 256) * (p.N / 256) : ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     g.p[m] = p; g.tiles[m] = tiles; g.first[m] = (int)padded;
     padded += (tiles + 7) / 8 * 8;
     ++m;
   }
   return launch();
 }
+/* Block tile of the grouped weight-gradient launch: 0 (default) = per problem -- the phased 256x256 kernel when M and N are multiples of
+ * 256 and K >= 512 (every Linear of the transformer), else 128x128; 1 = 128x128 always (A/B measurements, tests). */
+extern "C" int st5_gemm_set_tn_group_tile(int mode) { if (mode < 0 || mode > 1) return ST5_ERR_ARG; g_tn_group_tile = mode; return ST5_OK; }
+/* 1 when st5_gemm_tn_group would run a weight gradient of this shape on the phased 256x256 kernel (host-side tile accounting). */
+extern "C" int st5_gemm_tn_group_is_phased(int32_t M, int32_t N, int32_t K) {
+  return g_tn_group_tile == 0 && M % 256 == 0 && N % 256 == 0 && K >= 512;
+}
 
 /* MX-fp8 GEMM (see gemm_nt_mx8_kernel): p describes fp8 operands A [M x K], B [N x K] (ld in BYTES = elements, K-major, no row
  * split / segments / batch) and bf16 C-class operands; a_scale / b_scale hold one e8m0 byte per 32 k-elements of a row. */
-extern "C" int st5_gemm_mxfp8(const st5_gemm_params* pp, const uint8_t* a_scale, int64_t a_scale_ld, const uint8_t* b_scale,
-                              int64_t b_scale_ld, void* stream) {
+namespace {
+int gemm_mxfp8_impl(const st5_gemm_params* pp, const uint8_t* a_scale, int64_t a_scale_ld, const uint8_t* b_scale, int64_t b_scale_ld,
+                    const MxOut mo, void* stream) {
   if (!pp || !a_scale || !b_scale) return ST5_ERR_ARG;
   st5_gemm_params p = *pp;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A.ptr || !p.B.ptr || !p.C.ptr) return ST5_ERR_ARG;
@@ -2836,21 +2917,23 @@ extern "C" int st5_gemm_mxfp8(const st5_gemm_params* pp, const uint8_t* a_scale,
   };
   const int c_vec_ok = c_ok(p.C) && c_ok(p.R) && c_ok(p.P) && c_ok(p.Cpre);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  static bool attr = false;
-  if (!attr) {
-    const void* fns[] = {(const void*)gemm_nt_mx8_kernel<0>, (const void*)gemm_nt_mx8_kernel<F_GELU | F_PRE>, (const void*)gemm_nt_mx8_kernel<F_DROP | F_RES>,
-                         (const void*)gemm_nt_mx8_kernel<F_DACT>, (const void*)gemm_nt_mx8_kernel<F_BETA>, (const void*)gemm_nt_mx8_kernel<-1>};
-    for (const void* f : fns)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
-    attr = true;
-  }
   const long long al = a_scale_ld, bl = b_scale_ld;
+  int feat = nt_feat_of(p, c_vec_ok);
+  if (mo.q) {
+    // output also MX-quantised in the epilogue: the two producers the training step has (fc1 forward: bias + GELU + pre-activation copy;
+    // the data gradient through the GELU), plain layout only
+    if (!mo.s || p.N % 32 || p.C.rpb || mo.q_ld % 8 || !aligned(mo.q, 8)) return ST5_ERR_ARG;
+    if (feat != (F_GELU | F_PRE) && feat != F_DACT) return ST5_ERR_ARG;
+    feat |= F_Q8;
+  }
   // Block tile, the bf16 rule (nt256_pays): the phased 256^2 kernel for several rounds of the chip or one nearly full round
   // (the phased kernel addresses operands and scales through buffer resources: 32-bit byte offsets)
   const long long lim = 1ll << 31;
   const bool small_images = (long long)p.M * p.A.ld < lim && (long long)p.N * p.B.ld < lim && (long long)p.M * al < lim && (long long)p.N * bl < lim;
-  if (small_images && (g_mx8_tile == 2 || (g_mx8_tile == 0 && mx8_256_pays(p.M, p.N)))) {
-    switch (nt_feat_of(p, c_vec_ok)) {
+  if (small_images && (g_mx8_tile == 2 || (g_mx8_tile == 0 && mx8_256_pays(p.M, p.N, p.K / 128, feat)))) {
+    switch (feat) {
+      case F_GELU | F_PRE | F_Q8: return launch_mx8p_as<F_GELU | F_PRE | F_Q8>(p, c_vec_ok, a_scale, al, b_scale, bl, s, mo);
+      case F_DACT | F_Q8: return launch_mx8p_as<F_DACT | F_Q8>(p, c_vec_ok, a_scale, al, b_scale, bl, s, mo);
       case 0: return launch_mx8p_as<0>(p, c_vec_ok, a_scale, al, b_scale, bl, s);
       case F_GELU | F_PRE: return launch_mx8p_as<F_GELU | F_PRE>(p, c_vec_ok, a_scale, al, b_scale, bl, s);
       case F_DROP | F_RES: return launch_mx8p_as<F_DROP | F_RES>(p, c_vec_ok, a_scale, al, b_scale, bl, s);
@@ -2862,7 +2945,9 @@ extern "C" int st5_gemm_mxfp8(const st5_gemm_params* pp, const uint8_t* a_scale,
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, 1, 1);
-  switch (nt_feat_of(p, c_vec_ok)) {
+  switch (feat) {
+    case F_GELU | F_PRE | F_Q8: return launch_mx8_as<F_GELU | F_PRE | F_Q8>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s, mo);
+    case F_DACT | F_Q8: return launch_mx8_as<F_DACT | F_Q8>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s, mo);
     case 0: return launch_mx8_as<0>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
     case F_GELU | F_PRE: return launch_mx8_as<F_GELU | F_PRE>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
     case F_DROP | F_RES: return launch_mx8_as<F_DROP | F_RES>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
@@ -2870,6 +2955,20 @@ extern "C" int st5_gemm_mxfp8(const st5_gemm_params* pp, const uint8_t* a_scale,
     case F_BETA: return launch_mx8_as<F_BETA>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
     default: return launch_mx8_as<-1>(p, c_vec_ok, a_scale, al, b_scale, bl, grid, s);
   }
+}
+}  // namespace
+extern "C" int st5_gemm_mxfp8(const st5_gemm_params* pp, const uint8_t* a_scale, int64_t a_scale_ld, const uint8_t* b_scale,
+                              int64_t b_scale_ld, void* stream) {
+  return gemm_mxfp8_impl(pp, a_scale, a_scale_ld, b_scale, b_scale_ld, MxOut{nullptr, 0, nullptr, 0}, stream);
+}
+/* st5_gemm_mxfp8 whose bf16 output C [M x N] (N % 32 == 0) is ALSO written as its MX-fp8 image: out_q [M x N] e4m3 bytes (pitch out_q_ld),
+ * out_s [M x N/32] e8m0 scale bytes (pitch out_s_ld) -- the bytes st5_quant_mxfp8 would produce from C.  For the two epilogues whose output
+ * feeds the next fp8 GEMM as its A operand: bias + GELU with the pre-activation copy (fc1 forward), and x act'(P) (data gradient of fc2). */
+extern "C" int st5_gemm_mxfp8_q(const st5_gemm_params* pp, const uint8_t* a_scale, int64_t a_scale_ld, const uint8_t* b_scale,
+                                int64_t b_scale_ld, void* out_q, int64_t out_q_ld, uint8_t* out_s, int64_t out_s_ld, void* stream) {
+  if (!out_q || !out_s) return ST5_ERR_ARG;
+  return gemm_mxfp8_impl(pp, a_scale, a_scale_ld, b_scale, b_scale_ld,
+                         MxOut{reinterpret_cast<unsigned char*>(out_q), (long long)out_q_ld, out_s, (long long)out_s_ld}, stream);
 }
 
 /* q[r, c] (e4m3 bytes) and s[r, c / 32] (e8m0 bytes) of the bf16 matrix x [rows x cols] (cols % 32 == 0), MX blocks along a row. */
@@ -2938,4 +3037,6 @@ extern "C" int st5_gemm_set_tn_phased(int mode) { if (mode < 0 || mode > 2) retu
 extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 5) return ST5_ERR_ARG; g_nt_tile = mode; return ST5_OK; }
 /* MX-fp8 NT block tile: 0 = per-problem choice (default), 1 = 128x128 always, 2 = phased 256x256 always (A/B measurements, tests). */
 extern "C" int st5_gemm_set_mx8_tile(int mode) { if (mode < 0 || mode > 2) return ST5_ERR_ARG; g_mx8_tile = mode; return ST5_OK; }
+/* (A/B) k-tiles of 128 an epilogue-heavy fp8 GEMM needs before the per-problem choice takes the phased 256x256 kernel; default 16, 0 = always. */
+extern "C" int st5_gemm_set_mx8_heavy_nk(int nk) { if (nk < 0) return ST5_ERR_ARG; g_mx8_heavy_nk = nk; return ST5_OK; }
 extern "C" int st5_gemm_set_m64_max_tiles(int tiles) { if (tiles < 0) return ST5_ERR_ARG; g_m64_max_tiles = tiles; return ST5_OK; }

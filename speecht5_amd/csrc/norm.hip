@@ -155,12 +155,17 @@ template <> __device__ __forceinline__ void store4f<bf16_t>(bf16_t* p, const flo
   *reinterpret_cast<bf16x4*>(p) = o;
 }
 
-template <typename T, int NV>
+// Q8 (round 6, fp8 compute mode): the output row is ALSO written as its MX-fp8 image (q8: e4m3 bytes [rows x cols], s8: one e8m0 scale
+// byte per 32 columns) -- the bytes st5_quant_mxfp8 produces from y, so the fp8 GEMMs that read a pre-LN layer's LayerNorm output (QKV,
+// fc1: models/speecht5.py:1402-1425 `encoder_normalize_before`) need no quantisation pass.  A lane holds 4 consecutive columns, 8
+// lanes one MX block (blocks start at multiples of 32 columns = 8 lanes).
+template <typename T, int NV, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
                                                          long long rows, int cols, float eps,
-                                                         const float* __restrict__ keep, const T* __restrict__ skip) {
+                                                         const float* __restrict__ keep, const T* __restrict__ skip,
+                                                         unsigned char* __restrict__ q8 = nullptr, unsigned char* __restrict__ s8 = nullptr) {
   // keep / skip (LayerDrop gate, st5_layernorm_gated_fwd): *keep == 0 -> y = skip (the layer's input) instead of LN(x)
   const bool dropped = keep != nullptr && *keep == 0.f;
   const int lane = threadIdx.x & 63;
@@ -211,6 +216,42 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
           for (int e = 0; e < 4; ++e) o[e] = fmaf(v[r][i][e] * rs, g[i][e], b[i][e]);
           if (dropped) load4f<T>(skip + (row0 + r) * cols + c, o);
           store4f<T>(y + (row0 + r) * cols + c, o);
+          if constexpr (Q8) {
+            // (cols % 32 == 0: the 8 lanes of a block are all inside the row or all outside)
+            float amax = 0.f;
+            unsigned int nf = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o[e] = Elem<T>::to_f(Elem<T>::from_f(o[e]));        // the value the bf16 output holds
+              const bool bad = (__float_as_uint(o[e]) & 0x7f800000u) == 0x7f800000u;
+              nf |= bad ? (1u << e) : 0u;
+              amax = fmaxf(amax, bad ? 0.f : fabsf(o[e]));
+            }
+            unsigned int nf_blk = nf != 0u ? 1u : 0u;
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {
+              amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+              nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, m, 64);
+            }
+            int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;
+            E = E < 0 ? 0 : (E > 254 ? 254 : E);
+            const float inv = __uint_as_float((unsigned int)(254 - E) << 23);
+            float f4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = ((nf >> e) & 1u) ? 0.f : o[e] * inv;
+              f4[e] = fminf(fmaxf(t, -448.f), 448.f);
+            }
+            int pk = 0;
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(f4[0], f4[1], pk, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(f4[2], f4[3], pk, true);
+            unsigned int u = (unsigned int)pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if ((nf >> e) & 1u) u = (u & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
+            *reinterpret_cast<unsigned int*>(q8 + (row0 + r) * cols + c) = u;
+            if ((lane & 7) == 0) s8[(row0 + r) * (cols >> 5) + (c >> 5)] = nf_blk ? (unsigned char)0xff : (unsigned char)E;
+          }
         }
       }
       if (lane == 0) { if (mean) mean[row0 + r] = mu; if (rstd) rstd[row0 + r] = rs; }
@@ -557,6 +598,23 @@ static int layernorm_fwd(const void* x, const float* gamma, const float* beta, v
 extern "C" int st5_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                  float* rstd, int64_t rows, int32_t cols, float eps, int dtype, void* stream) {
   return layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, dtype, stream, nullptr, nullptr);
+}
+/* st5_layernorm_fwd (bf16, cols % 32 == 0, cols <= 2048) that also writes y's MX-fp8 image: q [rows x cols] e4m3 bytes, s [rows x cols/32]
+ * e8m0 scale bytes -- what st5_quant_mxfp8 would produce from y.  fp8 compute mode, pre-LN layers (t5_transformer_large). */
+extern "C" int st5_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* q, uint8_t* sc,
+                                    int64_t rows, int32_t cols, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta || !q || !sc || rows < 0 || cols <= 0 || cols % 32 || cols > 2048) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 vgrid((unsigned)((rows + 4 * RPW - 1) / (4 * RPW)));
+#define LNQ(NV_)                                                                                                                       \
+  hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, NV_, true>), vgrid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, \
+                     (long long)rows, cols, eps, (const float*)nullptr, (const bf16_t*)nullptr, (unsigned char*)q, (unsigned char*)sc)
+  if (cols <= 256) LNQ(1); else if (cols <= 512) LNQ(2); else if (cols <= 768) LNQ(3);
+  else if (cols <= 1024) LNQ(4); else if (cols <= 1536) LNQ(6); else LNQ(8);
+#undef LNQ
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
 }
 extern "C" int st5_layernorm_gated_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                        int64_t rows, int32_t cols, float eps, const float* keep, const void* skip, int dtype, void* stream) {

@@ -298,6 +298,8 @@ class _Bf16Mirror:
     A parameter's image is used only while `p._version` still equals the version recorded at the last refresh."""
 
     def __init__(self):
+        if globals().get("fp8_mirror") is not None:
+            fp8_mirror.reset()  # (its jobs point into this mirror's pools)
         self.flat = None        # bf16 [total], same element layout as the optimizer's flat fp32 buffer
         self.tflat = None       # bf16 pool of transposed copies
         self.tcap = 0
@@ -317,7 +319,6 @@ class _Bf16Mirror:
 
     def attach(self, flat_bf16, params, offsets):
         self.__init__()
-        fp8_mirror.reset()
         self.flat = flat_bf16
         for p, off in zip(params, offsets):
             p._st5_moff = off
@@ -466,7 +467,7 @@ def fused_weight_t(weights, dtype):
 # Activations / gradients are quantised per call (st5_quant_mxfp8: 32-element blocks along the reduction index), weights once
 # per optimizer step (cached with the other compute-dtype copies, dropped by weight_cache.clear()).
 # -------------------------------------------------------------------------------------------------
-_FP8 = SimpleNamespace(enabled=False, min_rows=512, min_n=512, launches=0)
+_FP8 = SimpleNamespace(enabled=False, min_rows=512, min_n=512, launches=0, fuse=int(os.environ.get("ST5_FP8_FUSE_QUANT", "7")))   # fuse: bit mask of the producers that write fp8 images -- 1 LayerNorm forward, 2 GELU epilogue (fc1), 4 GELU-derivative epilogue
 
 
 def set_fp8(enabled):
@@ -560,14 +561,49 @@ class _Fp8Mirror:
 fp8_mirror = _Fp8Mirror()
 
 
-def _nt_gemm(a2, weights, transposed, C, M, N, K, dtype, **epi):
+# fp8 images made by a PRODUCER (round 6): the LayerNorm forward of a pre-LN layer, the fc1 GEMM's GELU epilogue and the data gradient
+# through the GELU write the MX-fp8 image of their bf16 output beside it (st5_layernorm_fwd_q8, st5_gemm_mxfp8_q), so the fp8 GEMM that
+# consumes the tensor launches no quantisation pass.  Keyed by the output's address; an entry HOLDS the output tensor, so the address
+# cannot be handed to another tensor while the entry exists, and is dropped when its consumer takes it (or by the small FIFO bound).
+_q8_tags = {}      # y.data_ptr() -> (y, q, scales, rows, cols)
+_Q8_MAX = 8
+
+
+def _q8_tag(y, q, sc, rows, cols):
+    while len(_q8_tags) >= _Q8_MAX:
+        _q8_tags.pop(next(iter(_q8_tags)), None)
+    _q8_tags[y.data_ptr()] = (y, q, sc, rows, cols)
+
+
+def _q8_take(a2, rows, cols):
+    hit = _q8_tags.pop(a2.data_ptr(), None)
+    if hit is not None and hit[3:] == (rows, cols) and a2.is_contiguous():
+        return hit[1], hit[2]
+    return None
+
+
+def _q8_buffers(rows, cols, device):
+    return (torch.empty(rows, cols, dtype=torch.uint8, device=device), torch.empty(rows, cols // 32, dtype=torch.uint8, device=device))
+
+
+def _nt_gemm(a2, weights, transposed, C, M, N, K, dtype, quant_out=None, **epi):
     """C = epilogue(a2 . W^T) with W = stacked weights [N, K] (transposed: W = stack^T, the data-gradient form) -- on the MX-fp8
-    kernel when the mode is on and the shapes allow, else st5_gemm in the compute dtype."""
+    kernel when the mode is on and the shapes allow, else st5_gemm in the compute dtype.  quant_out = the output TENSOR when its
+    consumer is another fp8 GEMM over all N columns (the FFN's hidden activations and their gradients): the epilogue then writes the
+    output's fp8 image too."""
     W = fused_weight_t(weights, dtype) if transposed else fused_weight(weights, dtype)
     if _fp8_ok(M, N, K, dtype) and W.is_contiguous() and a2.is_contiguous():
         Wq, Ws = _quant_cached("qt" if transposed else "q", weights, W)
-        aq, as_ = hip.quant_mxfp8(a2)
-        hip.gemm_mxfp8(aq, as_, Wq, Ws, C, M, N, K, **epi)
+        pre = _q8_take(a2, M, K)
+        aq, as_ = pre if pre is not None else hip.quant_mxfp8(a2)
+        out_q = None
+        if quant_out is not None and (_FP8.fuse & (4 if (epi.get("flags", 0) & hip.DACT) else 2)) and N % 128 == 0 and epi.get("dropout_p", 0.0) == 0 and epi.get("R") is None and \
+                epi.get("beta", 0.0) == 0 and quant_out.is_contiguous() and quant_out.shape == (M, N) and \
+                ((epi.get("flags", 0) & hip.DACT) or (epi.get("act", ACT_NONE) == ACT_GELU and epi.get("Cpre") is not None)):
+            out_q = _q8_buffers(M, N, a2.device)
+        hip.gemm_mxfp8(aq, as_, Wq, Ws, C, M, N, K, out_q=out_q, **epi)
+        if out_q is not None:
+            _q8_tag(quant_out, out_q[0], out_q[1], M, N)
         _FP8.launches += 1
         return
     hip.gemm(hip.operand(a2, a2.stride(0)), hip.operand(W, W.shape[1]), C, M, N, K, _dt(dtype), **epi)
@@ -771,6 +807,9 @@ def set_wgrad_owner(stream):
 # gradients of one layer): one launch, whole reductions, no slabs.  233 -> 162 us per encoder layer at 8192 tokens.
 WGRAD_GROUP = os.environ.get("ST5_WGRAD_GROUP", "1") != "0"     # A/B switch
 _WG_ROUND, _WG_FLUSH_AT, _WG_MAX = [int(v) for v in os.environ.get("ST5_WGRAD_ROUND", "512,400").split(",")] + [8]   # tiles: never above / launch at
+# (round 6) problems whose M, N are multiples of 256 -- every Linear of the transformer -- run on the phased 256 x 256 grouped kernel, one
+# block per CU: a round is 256 tiles of 256^2 (two Base layers are 216, a Large layer and the next one's first problems 208-240)
+_WG_ROUND_P, _WG_FLUSH_AT_P = [int(v) for v in os.environ.get("ST5_WGRAD_ROUND_P", "256,200").split(",")]
 
 
 def set_wgrad_grouping(on):
@@ -875,21 +914,23 @@ def _wgrad_queue(A, B, C, M, N, K, dt, flags, asum, keep):
     q = _S.__dict__.setdefault("wq", {})
     st = hip.stream()
     ent = q.get(st)
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    phased = bool(hip.lib().st5_gemm_tn_group_is_phased(M, N, K))       # (the library's own per-problem rule)
+    tiles = (M // 256) * (N // 256) if phased else ((M + 127) // 128) * ((N + 127) // 128)
+    round_, flush_at = (_WG_ROUND_P, _WG_FLUSH_AT_P) if phased else (_WG_ROUND, _WG_FLUSH_AT)
 
     def launch():
         _launch_wgrad_group(st, q.pop(st))
-    if ent is not None and ent[0] and (ent[2] + tiles > _WG_ROUND or len(ent[0]) == _WG_MAX or ent[3] != dt
+    if ent is not None and ent[0] and (ent[2] + tiles > round_ or len(ent[0]) == _WG_MAX or ent[3] != dt or ent[4] != phased
                                        or any(p[2].ptr == C.ptr or (asum is not None and p[8] is not None and p[8].data_ptr() == asum.data_ptr())
                                               for p in ent[0])):
-        launch()            # (the round is full, or the same gradient twice -- tied weights -- would race inside one launch)
+        launch()            # (the round is full, another block tile, or the same gradient twice -- tied weights -- would race inside one launch)
         ent = None
     if ent is None:
-        ent = q[st] = [[], [], 0, dt]
+        ent = q[st] = [[], [], 0, dt, phased]
     ent[0].append((A, B, C, M, N, K, flags, 1.0, asum))
     ent[1].append(keep)
     ent[2] += tiles
-    if ent[2] >= _WG_FLUSH_AT:
+    if ent[2] >= flush_at:
         launch()
 
 
@@ -1140,7 +1181,7 @@ class FFNFunction(torch.autograd.Function):
         # epilogue of the dX GEMM instead of by a separate autograd accumulation kernel.
         res_is_x = isinstance(residual, str)
         res2 = x2 if res_is_x else (_rows(residual) if residual is not None else None)
-        _nt_gemm(x2, [w1], False, hip.operand(h, Fd), M, Fd, d, dtype, Cpre=hip.operand(hpre, Fd),
+        _nt_gemm(x2, [w1], False, hip.operand(h, Fd), M, Fd, d, dtype, quant_out=h, Cpre=hip.operand(hpre, Fd),
                  bias=b1.detach(), act=act, dropout_p=p_act, seed=s1)
         _nt_gemm(h, [w2], False, hip.operand(y, w2.shape[0]), M, w2.shape[0], Fd, dtype,
                  R=hip.operand(res2, w2.shape[0]) if res2 is not None else None, bias=b2.detach(), dropout_p=p_out, seed=s2)
@@ -1165,6 +1206,7 @@ class FFNFunction(torch.autograd.Function):
         # dHpre = (G . W2) * act'(Hpre) [* activation-dropout mask]   (fused epilogue)
         dh = torch.empty(M, Fd, dtype=dtype, device=x2.device)
         _nt_gemm(g, [w2], True, hip.operand(dh, Fd), M, Fd, dout, dtype,     # (B operand: W2^T [Fd, dout])
+                 quant_out=dh if ctx.needs_input_grad[0] else None,
                  P=hip.operand(hpre, Fd), act=act, flags=hip.DACT, dropout_p=p_act, seed=s1)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -1381,7 +1423,15 @@ class LayerNormFunction(torch.autograd.Function):
         y = torch.empty_like(x2)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        if gate is None:
+        if gate is None and _FP8.enabled and (_FP8.fuse & 1) and x2.dtype == torch.bfloat16 and cols % 128 == 0 and cols <= 2048 and \
+                rows >= _FP8.min_rows:
+            # fp8 mode: the consumer of a pre-LN layer's LayerNorm is an fp8 GEMM (QKV / fc1) -- its operand image comes out of this pass
+            q, sc = _q8_buffers(rows, cols, x.device)
+            hip.check(hip.lib().st5_layernorm_fwd_q8(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                     rstd.data_ptr(), q.data_ptr(), sc.data_ptr(), rows, cols, eps, hip.stream()),
+                      "st5_layernorm_fwd_q8")
+            _q8_tag(y, q, sc, rows, cols)
+        elif gate is None:
             hip.check(hip.lib().st5_layernorm_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
                                                   rstd.data_ptr(), rows, cols, eps, _dt(x), hip.stream()), "st5_layernorm_fwd")
         else:       # LayerDrop gate: y = keep ? LN(x) : the layer's input

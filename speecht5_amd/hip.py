@@ -46,6 +46,9 @@ _SIGS = {
     "st5_gemm_set_nt_tile": (c_int, [c_int]),
     "st5_gemm_set_m64_max_tiles": (c_int, [c_int]),
     "st5_gemm_set_mx8_tile": (c_int, [c_int]),
+    "st5_gemm_set_mx8_heavy_nk": (c_int, [c_int]),
+    "st5_gemm_set_tn_group_tile": (c_int, [c_int]),
+    "st5_gemm_tn_group_is_phased": (c_int, [c_int32, c_int32, c_int32]),
     "st5_gemm_set_splitk_target": (c_int, [c_int]),
     "st5_gemm_set_deep_ring": (c_int, [c_int, c_int]),
     "st5_gemm_set_nt_slots": (c_int, [c_int]),
@@ -86,6 +89,9 @@ _SIGS = {
     "st5_gemm_mxfp8": (c_int, [POINTER(GemmParams), c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "st5_quant_mxfp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     "st5_multi_quant_mxfp8": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    "st5_gemm_mxfp8_q": (c_int, [POINTER(GemmParams), c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "st5_layernorm_fwd_q8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
+                                     c_void_p]),
     "st5_flash_attn_qp_row": (c_int32, [c_int32]),
     "st5_flash_attn_qp_table": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_int, c_void_p]),
     "st5_conv0_gn_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
@@ -389,8 +395,9 @@ def quant_mxfp8(x2):
 
 
 def gemm_mxfp8(Aq, As, Bq, Bs, C, M, N, K, *, R=None, P=None, Cpre=None, bias=None, act=ACT_NONE, flags=0, alpha=1.0, beta=0.0,
-               dropout_p=0.0, seed=0):
-    """C (bf16 operand) = epilogue(Aq . Bq^T) on the block-scaled fp8 MFMA; Aq / Bq uint8 [rows, K] with scales As / Bs [rows, K/32]."""
+               dropout_p=0.0, seed=0, out_q=None):
+    """C (bf16 operand) = epilogue(Aq . Bq^T) on the block-scaled fp8 MFMA; Aq / Bq uint8 [rows, K] with scales As / Bs [rows, K/32].
+    out_q = (q uint8 [M, N], s uint8 [M, N/32]): the epilogue also writes C's MX-fp8 image (st5_gemm_mxfp8_q)."""
     p = GemmParams()
     p.A, p.B, p.C = operand(Aq, Aq.stride(0)), operand(Bq, Bq.stride(0)), C
     p.R = R if R is not None else _NULL_OP
@@ -402,14 +409,21 @@ def gemm_mxfp8(Aq, As, Bq, Bs, C, M, N, K, *, R=None, P=None, Cpre=None, bias=No
     p.act, p.flags = act, flags
     p.alpha, p.beta, p.dropout_p, p.seed = alpha, beta, dropout_p, seed
     p.asum = 0
+    def launch():
+        if out_q is not None:
+            oq, os_ = out_q
+            check(lib().st5_gemm_mxfp8_q(byref(p), As.data_ptr(), As.stride(0), Bs.data_ptr(), Bs.stride(0), oq.data_ptr(), oq.stride(0),
+                                         os_.data_ptr(), os_.stride(0), stream()), "st5_gemm_mxfp8_q")
+        else:
+            check(lib().st5_gemm_mxfp8(byref(p), As.data_ptr(), As.stride(0), Bs.data_ptr(), Bs.stride(0), stream()), "st5_gemm_mxfp8")
     if profiler.enabled:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib().st5_gemm_mxfp8(byref(p), As.data_ptr(), As.stride(0), Bs.data_ptr(), Bs.stride(0), stream()), "st5_gemm_mxfp8")
+        launch()
         e1.record()
         profiler.records.append(("fp8_NT", 2.0 * M * N * K, e0, e1, (M, N, K, 1)))
         return
-    check(lib().st5_gemm_mxfp8(byref(p), As.data_ptr(), As.stride(0), Bs.data_ptr(), Bs.stride(0), stream()), "st5_gemm_mxfp8")
+    launch()
 
 
 # ---------------------------------------------------------------------------------------------

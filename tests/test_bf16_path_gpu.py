@@ -196,6 +196,51 @@ def test_weight_gradient_group_launch(cuda, K):
     assert torch.equal(C1, Cg) and torch.equal(d1, dbg)
 
 
+@pytest.mark.parametrize("K", [3992, 8192, 640])
+def test_phased_weight_gradient_group_equals_the_128_tile_group_bit_for_bit(cuda, K):
+    """Round 6 (gemm_tn8p_group_kernel): the grouped launch on the phased 256 x 256 schedule -- the default for problems whose M, N are
+    multiples of 256 -- gives every WEIGHT-gradient element the MFMA chain of the 128 x 128 group: equal bits (a partial last k-tile
+    included); the bias-gradient column (summed on the VALU in its own fixed order) within rounding of it; two layers' problems in one
+    launch; a problem alone == inside the group."""
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (1024, 1024), (256, 512)]
+    fl = hip.A_KSTRIDED | hip.B_KSTRIDED | hip.OUT_F32
+    L = hip.lib()
+    g = torch.Generator().manual_seed(K + 1)
+    ops = []
+    for (M, N) in shapes:
+        dy = torch.randn(K, M, generator=g).to(torch.bfloat16).to(cuda)
+        x = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(cuda)
+        ops.append((dy, x))
+    assert all(L.st5_gemm_tn_group_is_phased(M, N, K) == 1 for (M, N) in shapes)
+
+    def run(mode, which):
+        hip.check(L.st5_gemm_set_tn_group_tile(mode), "st5_gemm_set_tn_group_tile")
+        try:
+            outs, probs = [], []
+            for i in which:
+                (M, N), (dy, x) = shapes[i], ops[i]
+                C = torch.full((M, N), 1.0, dtype=torch.float32, device=cuda)
+                db = torch.full((M,), 2.0, dtype=torch.float32, device=cuda)
+                outs.append((C, db))
+                probs.append((hip.operand(dy, M), hip.operand(x, N), hip.operand(C, N), M, N, K, fl, 1.0, db))
+            hip.gemm_tn_group(probs, hip.BF16)
+            torch.cuda.synchronize()
+            return outs
+        finally:
+            hip.check(L.st5_gemm_set_tn_group_tile(0), "st5_gemm_set_tn_group_tile")
+
+    small, big = run(1, range(6)), run(0, range(6))
+    for i, ((C0, d0), (C1, d1)) in enumerate(zip(small, big)):
+        dy, x = ops[i]
+        _close(C1 - 1.0, dy.float().t() @ x.float(), torch.bfloat16, f"phased tn group {shapes[i]} K={K}")
+        assert torch.equal(C0, C1), f"{shapes[i]}: {int((C0 != C1).sum())} weight-gradient elements differ from the 128^2 group"
+        rb = dy.float().sum(0)
+        assert (d1 - 2.0 - rb).abs().max().item() <= 2e-2 * max(rb.abs().max().item(), math.sqrt(K))
+        assert (d1 - d0).abs().max().item() <= 1e-3 * max(rb.abs().max().item(), math.sqrt(K))
+    alone = run(0, [1])[0]
+    assert torch.equal(alone[0], big[1][0]) and torch.equal(alone[1], big[1][1])
+
+
 @pytest.mark.parametrize("mode", [3, 4])
 @pytest.mark.parametrize("kind", EPI)
 def test_nt_phased_256_tile_forced(cuda, mode, kind):

@@ -162,6 +162,103 @@ def test_phased_256_tile_mx_kernel_is_bit_identical_to_the_128_tile_kernel(cuda,
     assert float((big[0].float() - ref).abs().max()) <= 6e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(512, 1024, 256), (1000, 4096, 1024), (300, 256, 128)])
+def test_epilogue_written_fp8_image_is_the_quantiser_applied_to_the_output(cuda, tile, M, N, K):
+    """Round 6 (st5_gemm_mxfp8_q): the fc1 forward (bias + GELU + pre-activation copy) and the data gradient through the GELU write the
+    MX-fp8 image of their bf16 output from the epilogue; it must be byte for byte what st5_quant_mxfp8 makes of that output, and the bf16
+    outputs must not change -- on both block tiles, with an M tail."""
+    torch.manual_seed(M + N + tile)
+    L = hip.lib()
+    A = torch.randn(M, K, device=cuda).to(torch.bfloat16)
+    B = (torch.randn(N, K, device=cuda) * 0.08).to(torch.bfloat16)
+    Aq, As = hip.quant_mxfp8(A)
+    Bq, Bs = hip.quant_mxfp8(B)
+    bias = torch.randn(N, device=cuda)
+    P = torch.randn(M, N, device=cuda).to(torch.bfloat16)
+    hip.check(L.st5_gemm_set_mx8_tile(tile), "st5_gemm_set_mx8_tile")
+    try:
+        for kind in ("gelu", "dact"):
+            kw = dict(bias=bias, act=hip.ACT_GELU) if kind == "gelu" else dict(P=hip.operand(P, N), act=hip.ACT_GELU, flags=hip.DACT)
+            y0, pre0 = torch.empty(M, N, dtype=torch.bfloat16, device=cuda), torch.empty(M, N, dtype=torch.bfloat16, device=cuda)
+            y1, pre1 = torch.empty_like(y0), torch.empty_like(pre0)
+            if kind == "gelu":
+                hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(y0, N), M, N, K, Cpre=hip.operand(pre0, N), **kw)
+            else:
+                hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(y0, N), M, N, K, **kw)
+            q = torch.full((M, N), 0xAA, dtype=torch.uint8, device=cuda)
+            sc = torch.full((M, N // 32), 0xAA, dtype=torch.uint8, device=cuda)
+            if kind == "gelu":
+                hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(y1, N), M, N, K, Cpre=hip.operand(pre1, N), out_q=(q, sc), **kw)
+            else:
+                hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(y1, N), M, N, K, out_q=(q, sc), **kw)
+            wq, ws = hip.quant_mxfp8(y0)
+            torch.cuda.synchronize()
+            assert torch.equal(y0.view(torch.int16), y1.view(torch.int16)), kind
+            if kind == "gelu":
+                assert torch.equal(pre0.view(torch.int16), pre1.view(torch.int16))
+            assert torch.equal(sc, ws), f"{kind}: {int((sc != ws).sum())} scale bytes differ"
+            assert torch.equal(q, wq), f"{kind}: {int((q != wq).sum())} of {q.numel()} fp8 bytes differ"
+        # any other epilogue combination is refused, not silently left unquantised
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=cuda)
+        with pytest.raises(hip.HipKernelError):
+            hip.gemm_mxfp8(Aq, As, Bq, Bs, hip.operand(y, N), M, N, K, bias=bias, out_q=(q, sc))
+    finally:
+        hip.check(L.st5_gemm_set_mx8_tile(0), "st5_gemm_set_mx8_tile")
+
+
+@pytest.mark.parametrize("rows,cols", [(1000, 1024), (37, 768), (513, 256), (16, 2048)])
+def test_layernorm_written_fp8_image_is_the_quantiser_applied_to_its_output(cuda, rows, cols):
+    """Round 6 (st5_layernorm_fwd_q8): same output, mean and rstd as st5_layernorm_fwd, and the fp8 image == st5_quant_mxfp8(y)."""
+    torch.manual_seed(rows)
+    L = hip.lib()
+    x = (torch.randn(rows, cols, device=cuda) * 3.0 + 0.5).to(torch.bfloat16)
+    x[1] *= 1e-3
+    g = torch.randn(cols, device=cuda) * 0.5 + 1.0
+    b = torch.randn(cols, device=cuda) * 0.1
+    outs = []
+    for fused in (False, True):
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=cuda); rstd = torch.empty(rows, device=cuda)
+        if fused:
+            q = torch.full((rows, cols), 0xAA, dtype=torch.uint8, device=cuda)
+            sc = torch.full((rows, cols // 32), 0xAA, dtype=torch.uint8, device=cuda)
+            hip.check(L.st5_layernorm_fwd_q8(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             q.data_ptr(), sc.data_ptr(), rows, cols, 1e-5, hip.stream()), "st5_layernorm_fwd_q8")
+        else:
+            hip.check(L.st5_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                          rows, cols, 1e-5, hip.BF16, hip.stream()), "st5_layernorm_fwd")
+        outs.append((y, mean, rstd))
+    wq, ws = hip.quant_mxfp8(outs[0][0])
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.equal(sc, ws) and torch.equal(q, wq), (int((sc != ws).sum()), int((q != wq).sum()))
+
+
+def test_batched_weight_quantiser_matches_the_single_matrix_one(cuda):
+    """Round 6 (st5_multi_quant_mxfp8): many contiguous matrices in one launch == st5_quant_mxfp8 on each."""
+    import struct
+    torch.manual_seed(5)
+    L = hip.lib()
+    mats = [torch.randn(r, c, device=cuda).mul_(sc).to(torch.bfloat16) for (r, c, sc) in
+            ((1024, 1024, 0.03), (4096, 1024, 1.0), (96, 32, 50.0), (1024, 4096, 0.02), (7, 128, 1.0), (3072, 1024, 0.05))]
+    outs, recs, blk0 = [], [], 0
+    for m in mats:
+        q = torch.full(m.shape, 0xAA, dtype=torch.uint8, device=cuda)
+        sc = torch.full((m.shape[0], m.shape[1] // 32), 0xAA, dtype=torch.uint8, device=cuda)
+        outs.append((q, sc))
+        recs.append(struct.pack("<QQQqii", m.data_ptr(), q.data_ptr(), sc.data_ptr(), m.numel(), m.shape[1], blk0))
+        blk0 += (m.numel() + 2047) // 2048
+    jobs = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(cuda)
+    hip.check(L.st5_multi_quant_mxfp8(jobs.data_ptr(), len(mats), blk0, hip.stream()), "st5_multi_quant_mxfp8")
+    torch.cuda.synchronize()
+    for m, (q, sc) in zip(mats, outs):
+        wq, ws = hip.quant_mxfp8(m)
+        torch.cuda.synchronize()
+        assert torch.equal(sc, ws) and torch.equal(q, wq), m.shape
+
+
 def test_fp8_linear_against_bf16_linear(cuda):
     """The quantisation error of one Linear at Large's shapes: cosine with the bf16 result."""
     torch.manual_seed(0)
@@ -330,3 +427,67 @@ def test_large_fp8_mode_against_the_oracle(cuda):
         Fn.bf16_mirror.__init__()
         Fn.weight_cache.clear()
         Fn.set_compute_dtype(torch.float32)
+
+
+def test_producer_side_quantisation_changes_no_bit_of_the_update(cuda):
+    """Round 6: fp8 images written by the producers (LayerNorm forward, GELU epilogue, data gradient through the GELU) and the batched
+    weight images are the bytes the stand-alone quantiser makes -- so the update's losses and EVERY gradient element must be identical
+    with the fusion on and off."""
+    from speecht5_amd import functional as Fn
+    old = Fn._FP8.fuse
+    try:
+        Fn._FP8.fuse = 0
+        l0, g0, n0 = _large_grads(cuda, True)
+        Fn._FP8.fuse = 7
+        l1, g1, n1 = _large_grads(cuda, True)
+    finally:
+        Fn._FP8.fuse = old
+    assert n0 == n1 and l0 == l1, (n0, n1, l0, l1)
+    bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not bad, bad[:8]
+
+
+def _fp8_updates(cuda, graph, micro, n_updates, fuse):
+    """State after n updates of t5_transformer_large in fp8 mode (speech 4 x 4 s + text 4 x 256: 796 / 1024 rows, above the fp8 row floor)."""
+    import bench
+    from speecht5_amd import functional as Fn
+    upd = None
+    old = Fn._FP8.fuse
+    try:
+        Fn._FP8.fuse = fuse
+        Fn.set_fp8(True)
+        Fn._FP8.launches = 0
+        _, _, model, upd = bench.make_update(cuda, torch.bfloat16, "large", 4, 0, graph=graph, micro=micro, layerdrop=0.05,
+                                             text_batch=4, text_len=256, seconds=4.0)
+        if graph:
+            upd.prepare_graph()
+            for _ in range(n_updates - 2):
+                upd.update()
+            upd.finish()
+        else:
+            Fn._S.force_static = True
+            for _ in range(n_updates):
+                upd.eager_update()
+        return upd.state(), Fn._FP8.launches
+    finally:
+        Fn._S.force_static = False
+        Fn._FP8.fuse = old
+        Fn.set_fp8(False)
+        if upd is not None:
+            upd.close()
+        Fn.bf16_mirror.__init__()
+        Fn.weight_cache.clear()
+        Fn.set_layer_boundary_hook(None)
+        Fn.set_compute_dtype(torch.float32)
+
+
+def test_fp8_updates_with_mirrored_weight_images_replayed_equal_the_unfused_eager_ones(cuda):
+    """Round 6: 4 fp8-mode updates (2 recorded + 2 replayed, micro-batches side by side; weight images from the batched refresh behind
+    every optimizer step, activation images from the producers) == the same 4 updates enqueued eagerly in turn with every image made
+    by the stand-alone quantiser at its consumer -- parameters and both Adam moments bit for bit."""
+    ref, n_ref = _fp8_updates(cuda, False, "in_turn", 4, fuse=0)
+    got, n_got = _fp8_updates(cuda, True, "side_by_side", 4, fuse=7)
+    assert n_ref > 400 and n_got > 200, (n_ref, n_got)
+    assert ref[3] == got[3] == 4 and torch.isfinite(got[0]).all()
+    for x, y, name in zip(ref[:3], got[:3], ("parameters", "first moment", "second moment")):
+        assert torch.equal(x, y), f"{name} differ, max {float((x - y).abs().max()):.3e}"

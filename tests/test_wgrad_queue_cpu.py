@@ -23,14 +23,28 @@ class _Asum:
         return self.p
 
 
-@pytest.fixture
-def queue(monkeypatch):
+def _fixture(monkeypatch, tile_mode):
     launched = []
     cur = {"s": 11}
     monkeypatch.setattr(hip, "stream", lambda: cur["s"])
     monkeypatch.setattr(hip, "gemm_tn_group", lambda problems, dt: launched.append((cur["s"], [p[2].ptr for p in problems], dt)))
     Fn._S.__dict__.pop("wq", None)
-    yield SimpleNamespace(launched=launched, cur=cur)
+    hip.check(hip.lib().st5_gemm_set_tn_group_tile(tile_mode), "st5_gemm_set_tn_group_tile")     # (host state of the library: no GPU needed)
+    return SimpleNamespace(launched=launched, cur=cur)
+
+
+@pytest.fixture
+def queue(monkeypatch):
+    """128 x 128 accounting (st5_gemm_set_tn_group_tile(1); also what shapes that are no multiples of 256 get)."""
+    yield _fixture(monkeypatch, 1)
+    Fn._S.__dict__.pop("wq", None)
+    hip.lib().st5_gemm_set_tn_group_tile(0)
+
+
+@pytest.fixture
+def queue256(monkeypatch):
+    """The default: problems whose M, N are multiples of 256 are counted in 256 x 256 tiles (phased grouped kernel, round 6)."""
+    yield _fixture(monkeypatch, 0)
     Fn._S.__dict__.pop("wq", None)
 
 
@@ -60,6 +74,31 @@ def test_a_group_never_exceeds_a_round_or_eight_problems_and_keeps_order(queue):
     assert queue.launched == [(11, list(range(10, 18)), hip.BF16)]
     Fn.flush_wgrads()
     assert queue.launched[-1] == (11, [18, 19], hip.BF16)
+
+
+def test_two_encoder_layers_are_one_round_of_the_phased_kernel(queue256):
+    """Round 6: a Base encoder layer is 36 + 36 + 9 + 27 = 108 tiles of 256 x 256; a round is 256, launched from 200 on: two layers."""
+    layer = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    for c, (M, N) in enumerate(layer + layer):
+        assert not queue256.launched
+        _q(100 + c, M, N)
+    assert queue256.launched == [(11, list(range(100, 108)), hip.BF16)]
+    queue256.launched.clear()
+    # Large: 64 + 64 + 16 + 48 = 192 per layer; the next layer's fc2 would make 256 > ... no: 192 + 64 = 256 <= 256 and >= 200: five problems
+    large = [(1024, 4096), (4096, 1024), (1024, 1024), (3072, 1024)]
+    for c, (M, N) in enumerate(large + large[:1]):
+        _q(200 + c, M, N)
+    assert queue256.launched == [(11, [200, 201, 202, 203, 204], hip.BF16)]
+
+
+def test_block_tile_classes_are_never_mixed_in_one_launch(queue256):
+    _q(1, 768, 768)            # phased class (multiples of 256)
+    _q(2, 83, 768)             # the vocabulary projection: 128 x 128 class -> the phased problem goes out first
+    assert queue256.launched == [(11, [1], hip.BF16)]
+    _q(3, 768, 768)            # and back
+    assert queue256.launched[-1] == (11, [2], hip.BF16)
+    Fn.flush_wgrads()
+    assert queue256.launched[-1] == (11, [3], hip.BF16)
 
 
 def test_the_same_output_twice_is_never_in_one_launch(queue):
