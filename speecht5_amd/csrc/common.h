@@ -94,6 +94,93 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// OCP MX quantisation (e4m3 elements, one e8m0 scale byte per 32 consecutive elements) of the NE = 4 or 8 consecutive elements one
+// lane holds; 32 / NE neighbouring lanes (aligned in the wave) hold one block.  scale = floor(log2(max|finite elements|)) - 8 + 127,
+// elements = RNE(x * 2^(127 - scale)) saturating finite values at +-448; a NaN / Inf element becomes the e4m3 NaN code 0x7f and its
+// block's scale the e8m0 NaN 0xff (a diverged tensor must reach the loss, not be clamped).
+// Round 6: fast path.  The block maximum is taken on the integer image of |x| (for finite values the integer order IS the float order,
+// and a value >= 0x7f800000 is exactly "NaN or Inf"): v_and + v_max3_u32 instead of a compare / select pair per element, the cross-lane
+// step on DPP quad permutes instead of ds_bpermute; when NO lane of the wave saw a non-finite value -- one ballot -- the elements are
+// scaled, clamped with v_med3_f32 and converted without any per-element non-finite bookkeeping.  ~5 VALU slots per element instead of
+// ~17: what made the quantiser affordable inside GEMM / LayerNorm epilogues.  Same bytes as the careful path for every input.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int mx8_dpp_max(unsigned int m, const int ctrl_sel) {
+  unsigned int o;
+  if (ctrl_sel == 0) o = (unsigned int)__builtin_amdgcn_update_dpp((int)m, (int)m, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+  else if (ctrl_sel == 1) o = (unsigned int)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  else o = (unsigned int)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x141, 0xf, 0xf, false);                    // row_half_mirror (quad 0 <-> quad 1 of 8 lanes)
+  return o > m ? o : m;
+}
+template <int NE>
+__device__ __forceinline__ void mx8_quant_careful(const float (&v)[NE], unsigned int (&q)[NE / 4], unsigned int& scale_byte) {
+  float amax = 0.f;
+  unsigned int nf = 0u;          // bit e: element e is NaN or Inf
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const bool bad = (__float_as_uint(v[e]) & 0x7f800000u) == 0x7f800000u;
+    nf |= bad ? (1u << e) : 0u;
+    amax = fmaxf(amax, bad ? 0.f : fabsf(v[e]));
+  }
+  unsigned int am = __float_as_uint(amax), nf_blk = nf != 0u ? 1u : 0u;
+#pragma unroll
+  for (int st = 0; st < (NE == 8 ? 2 : 3); ++st) {
+    am = mx8_dpp_max(am, st);
+    nf_blk = mx8_dpp_max(nf_blk, st);
+  }
+  int E = (int)((am >> 23) & 0xffu) - 8;      // biased exponent of amax, minus emax(e4m3)
+  E = E < 0 ? 0 : (E > 254 ? 254 : E);
+  const float inv = __uint_as_float((unsigned int)(254 - E) << 23);    // 2^(127 - E)
+#pragma unroll
+  for (int w = 0; w < NE / 4; ++w) {
+    float f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = ((nf >> (4 * w + e)) & 1u) ? 0.f : v[4 * w + e] * inv;
+      f[e] = fminf(fmaxf(t, -448.f), 448.f);
+    }
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+    unsigned int u = (unsigned int)pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((nf >> (4 * w + e)) & 1u) u = (u & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
+    q[w] = u;
+  }
+  scale_byte = nf_blk ? 0xffu : (unsigned int)E;
+}
+template <int NE>
+__device__ __forceinline__ void mx8_quant(const float (&v)[NE], unsigned int (&q)[NE / 4], unsigned int& scale_byte) {
+  static_assert(NE == 4 || NE == 8, "a lane holds 4 or 8 elements of a 32-element block");
+  unsigned int m = 0u;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const unsigned int a = __float_as_uint(v[e]) & 0x7fffffffu;
+    m = a > m ? a : m;
+  }
+#pragma unroll
+  for (int st = 0; st < (NE == 8 ? 2 : 3); ++st) m = mx8_dpp_max(m, st);
+  if (__ballot(m >= 0x7f800000u) != 0ull) {       // (wave-uniform; never taken in a healthy run)
+    mx8_quant_careful<NE>(v, q, scale_byte);
+    return;
+  }
+  int E = (int)(m >> 23) - 8;
+  E = E < 0 ? 0 : E;                               // (m < 0x7f800000: E <= 246)
+  const float inv = __uint_as_float((unsigned int)(254 - E) << 23);
+#pragma unroll
+  for (int w = 0; w < NE / 4; ++w) {
+    float f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = __builtin_amdgcn_fmed3f(v[4 * w + e] * inv, -448.f, 448.f);
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+    q[w] = (unsigned int)pk;
+  }
+  scale_byte = (unsigned int)E;
+}
+
 // exact (erf) GELU as torch.nn.GELU() / fairseq "gelu" in fp32
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
@@ -269,6 +356,32 @@ __device__ __forceinline__ void dropout_scale8(unsigned long long seed, unsigned
   const unsigned int p0 = ((unsigned int)idx8 & 63u) >> 1;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
+    const unsigned int bits = drop_pair_bits(key, p0 + e);
+    out[2 * e] = drop_pick(bits, 0, thresh16, inv_keep);
+    out[2 * e + 1] = drop_pick(bits, 1, thresh16, inv_keep);
+  }
+}
+// The same with the seed part of the block key computed by the caller ONCE (drop_seed_fold): the splitmix hash of the seed -- 64-bit
+// multiplies at a quarter of the VALU rate, behind a conditional load when the seed is a device slot -- is loop-invariant, but sits under
+// the callers' row / column predicates where hipcc does not hoist it (round 6: the LayerNorm backward's dropped second output cost
+// +9 us on a 13 us kernel, the dropout epilogue of the GEMMs +4 .. 15 us).  Same bits.
+__device__ __forceinline__ void dropout_scale8_folded(unsigned int seed_fold, unsigned long long idx8, unsigned int thresh16, float inv_keep,
+                                                      float (&out)[8]) {
+  const unsigned int key = drop_block_key_folded(seed_fold, idx8 >> 6);
+  const unsigned int p0 = ((unsigned int)idx8 & 63u) >> 1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned int bits = drop_pair_bits(key, p0 + e);
+    out[2 * e] = drop_pick(bits, 0, thresh16, inv_keep);
+    out[2 * e + 1] = drop_pick(bits, 1, thresh16, inv_keep);
+  }
+}
+__device__ __forceinline__ void dropout_scale4_folded(unsigned int seed_fold, unsigned long long idx4, unsigned int thresh16, float inv_keep,
+                                                      float (&out)[4]) {
+  const unsigned int key = drop_block_key_folded(seed_fold, idx4 >> 6);
+  const unsigned int p0 = ((unsigned int)idx4 & 63u) >> 1;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
     const unsigned int bits = drop_pair_bits(key, p0 + e);
     out[2 * e] = drop_pick(bits, 0, thresh16, inv_keep);
     out[2 * e + 1] = drop_pick(bits, 1, thresh16, inv_keep);

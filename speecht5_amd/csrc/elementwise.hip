@@ -59,16 +59,17 @@ __global__ void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict_
 template <typename T, typename F>
 __global__ void map1_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, F f) {
   const long long nv = n / 8;
+  const unsigned int st = f.init();       // (loop-invariant state of the functor, computed once per thread: Drop's seed hash)
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
     float v[8];
     load8f<T>(x + i * 8, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = f(v[e], i * 8 + e);
+    for (int e = 0; e < 8; ++e) v[e] = f(v[e], i * 8 + e, st);
     store8f<T>(y + i * 8, v);
   }
   for (long long i = nv * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
-    y[i] = Elem<T>::from_f(f(Elem<T>::to_f(x[i]), i));
+    y[i] = Elem<T>::from_f(f(Elem<T>::to_f(x[i]), i, st));
 }
 template <typename T, typename F>
 __global__ void map2_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n, F f) {
@@ -86,12 +87,20 @@ __global__ void map2_kernel(const T* __restrict__ a, const T* __restrict__ b, T*
     y[i] = Elem<T>::from_f(f(Elem<T>::to_f(a[i]), Elem<T>::to_f(b[i])));
 }
 
-struct ActF { int act; __device__ float operator()(float x, long long) const { return act_f(act, x); } };
+struct ActF {
+  int act;
+  __device__ unsigned int init() const { return 0u; }
+  __device__ float operator()(float x, long long, unsigned int) const { return act_f(act, x); }
+};
 struct ActB { int act; __device__ float operator()(float dy, float x) const { return dy * act_grad_f(act, x); } };
 struct Axpby { float a, b; __device__ float operator()(float x, float y) const { return a * x + b * y; } };
 struct Drop {
   unsigned long long seed; unsigned int thresh; float inv_keep;
-  __device__ float operator()(float x, long long i) const { return x * dropout_scale(seed, (unsigned long long)i, thresh, inv_keep); }
+  __device__ unsigned int init() const { return drop_seed_fold(seed); }      // (dropout_scale's seed part: same bits, once instead of per element)
+  __device__ float operator()(float x, long long i, unsigned int seed_fold) const {
+    const unsigned int key = drop_block_key_folded(seed_fold, (unsigned long long)i >> 6);
+    return x * drop_pick(drop_pair_bits(key, ((unsigned int)i & 63u) >> 1), (int)(i & 1), thresh, inv_keep);
+  }
 };
 
 // ---- LayerDrop as a device-side select (a captured step cannot branch on the host draw; encoder.py:251-257, decoder.py:64-67) ----

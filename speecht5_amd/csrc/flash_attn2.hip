@@ -128,10 +128,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off0, int off1) 
   return u.v;
 }
 
+// (pairs through v_cvt_pk_bf16_f32: written element by element hipcc converted every score on its own -- one convert + half a v_perm per
+//  element instead of half a convert; same round-to-nearest-even bits)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
   bf16x8 r;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (bf16_t)s[base + j];
+  for (int j = 0; j < 4; ++j) {
+    const f32x2_t p = {s[base + 2 * j], s[base + 2 * j + 1]};
+    const bf16x2_t q = __builtin_convertvector(p, bf16x2_t);
+    r[2 * j] = q[0]; r[2 * j + 1] = q[1];
+  }
   return r;
 }
 

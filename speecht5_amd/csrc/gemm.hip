@@ -253,48 +253,14 @@ __device__ __forceinline__ void store_vec(U* p, bool full, int ne, const float (
 }
 
 // One lane's share of an MX block: 8 consecutive bf16 of a row (4 lanes = one 32-element block, aligned in the wave) -> 8 e4m3 bytes
-// and, from the block's first lane, the e8m0 scale byte.
+// and, from the block's first lane, the e8m0 scale byte (common.h mx8_quant: the rule, the non-finite handling and the fast path).
 __device__ __forceinline__ void mx8_quant8(const float (&v)[8], unsigned char* __restrict__ q8, unsigned char* __restrict__ sbyte, const bool leader) {
-  // Non-finite inputs PROPAGATE: fmaxf ignores a NaN and the clamp below would turn NaN / Inf into +-448, so a diverged
-  // activation or gradient would never reach the loss / the gradient norm in fp8 mode.  The block maximum is taken over the FINITE
-  // elements (an Inf must not push the scale to 2^120 and zero its 31 neighbours); a non-finite element gets the e4m3 NaN code
-  // 0x7f, and the block's scale byte becomes the e8m0 NaN 0xff (OCP MX: the whole block then dequantises to NaN).
-  float amax = 0.f;
-  unsigned int nf = 0u;          // bit e: element e is NaN or Inf
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const bool bad = (__float_as_uint(v[e]) & 0x7f800000u) == 0x7f800000u;
-    nf |= bad ? (1u << e) : 0u;
-    amax = fmaxf(amax, bad ? 0.f : fabsf(v[e]));
-  }
-  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-  unsigned int nf_blk = nf != 0u ? 1u : 0u;
-  nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 1, 64);
-  nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, 2, 64);
-  int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;      // biased exponent of amax, minus emax(e4m3)
-  E = E < 0 ? 0 : (E > 254 ? 254 : E);
-  const float inv = __uint_as_float((unsigned int)(254 - E) << 23);    // 2^(127 - E)
+  unsigned int q[2], sc;
+  mx8_quant<8>(v, q, sc);
   u32x2 o;
-#pragma unroll
-  for (int w = 0; w < 2; ++w) {
-    float f[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float t = ((nf >> (4 * w + e)) & 1u) ? 0.f : v[4 * w + e] * inv;
-      f[e] = fminf(fmaxf(t, -448.f), 448.f);
-    }
-    int pk = 0;
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], pk, false);
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
-    unsigned int u = (unsigned int)pk;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if ((nf >> (4 * w + e)) & 1u) u = (u & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
-    o[w] = u;
-  }
+  o[0] = q[0]; o[1] = q[1];
   *reinterpret_cast<u32x2*>(q8) = o;
-  if (leader) *sbyte = nf_blk ? (unsigned char)0xff : (unsigned char)E;
+  if (leader) *sbyte = (unsigned char)sc;
 }
 
 struct EpiArgs {  // everything the epilogue needs, by value
@@ -430,6 +396,7 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
   const bool drop = RT ? ea.dropout_p > 0.f : (FEAT & F_DROP) != 0;
   const unsigned int thresh = drop ? dropout_thresh(ea.dropout_p) : 0u;
   const float inv_keep = drop ? 1.f / (1.f - ea.dropout_p) : 1.f;
+  const unsigned int seedf = drop ? drop_seed_fold(ea.seed) : 0u;      // (once per tile: see dropout_scale8_folded)
   OUT* const Cb = reinterpret_cast<OUT*>(ea.C) + gn;
   const bool has_res = RT ? ea.R != nullptr : (FEAT & F_RES) != 0;
   const bool has_pre = RT ? ea.Cpre != nullptr : (FEAT & F_PRE) != 0;
@@ -439,6 +406,17 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
   const OUT* const Rb = has_res ? reinterpret_cast<const OUT*>(ea.R) + gn : nullptr;
   const T* const Pb = dact ? reinterpret_cast<const T*>(ea.P) + gn : nullptr;
   T* const Qb = has_pre ? reinterpret_cast<T*>(ea.Cpre) + gn : nullptr;
+  // Row offsets (round 6).  A lane's rows are mbase + rsub + rr with rr = 32 h + 8 (2 pp + k) the SAME for every lane: the per-lane part
+  // (row0 * ld: one 64-bit multiply per operand) is formed once per call, the per-row part rr * ld on the scalar unit.  The first form
+  // multiplied row * ld per operand and row (and row * N for the dropout counter) on the VALU: ~34 quarter-rate integer multiplies per
+  // 16 output elements, a third of the epilogue's issue time (the ISA of the bias + dropout + residual epilogue: 352 instructions per
+  // two row passes).  Row-split operands (convolution layouts, rpb != 0) keep the division per row.
+  const bool split = ea.rpb != 0;
+  const long long row0 = (long long)mbase + rsub;
+  long long co0 = row0 * ea.c_ld, ro0 = has_res ? row0 * ea.r_ld : 0, po0 = dact ? row0 * ea.p_ld : 0, qo0 = has_pre ? row0 * ea.q_ld : 0;
+  unsigned long long ctr0 = drop ? ea.ctr_base + (unsigned long long)row0 * (unsigned long long)ea.N + (unsigned long long)gn : 0ull;
+  // (opaque to the optimiser: hipcc otherwise re-associates co0 + rr * ld back into (row0 + rr) * ld -- one register less, the multiplies back)
+  asm volatile("" : "+v"(co0), "+v"(ro0), "+v"(po0), "+v"(qo0), "+v"(ctr0));
 #pragma unroll
   for (int h = 0; h < HALVES; ++h) {
     if (h == 0) stage_write(stage, acc00, acc01, lane);
@@ -457,21 +435,28 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int gm = mbase + h * 32 + (pp * 2 + k) * 8 + rsub;
+        const int rr = h * 32 + (pp * 2 + k) * 8;          // (uniform)
+        const int gm = mbase + rr + rsub;
         if (gm < ea.M && col_ok) {
-          // row -> (block q, row rm inside the block) when the C-class operands are split every `rpb` rows
-          // (convolution layouts: per-utterance halo rows); every operand has its own row / block stride
-          long long q = 0, rm = gm;
-          if (ea.rpb) { q = gm / ea.rpb; rm = gm - q * ea.rpb; }
-          const long long c_off = q * ea.c_bs + rm * ea.c_ld;
+          long long c_off, r_off, p_off, q_off;
+          if (split) {
+            // row -> (block q, row rm inside the block) when the C-class operands are split every `rpb` rows
+            // (convolution layouts: per-utterance halo rows); every operand has its own row / block stride
+            const long long q = gm / ea.rpb, rm = gm - q * ea.rpb;
+            c_off = q * ea.c_bs + rm * ea.c_ld; r_off = q * ea.r_bs + rm * ea.r_ld;
+            p_off = q * ea.p_bs + rm * ea.p_ld; q_off = q * ea.q_bs + rm * ea.q_ld;
+          } else {
+            c_off = co0 + (long long)rr * ea.c_ld; r_off = ro0 + (long long)rr * ea.r_ld;
+            p_off = po0 + (long long)rr * ea.p_ld; q_off = qo0 + (long long)rr * ea.q_ld;
+          }
           float rv[8], pv[8], ov[8];
-          if (has_res) load8f<OUT>(Rb + q * ea.r_bs + rm * ea.r_ld, rv);
-          if (dact) load8f<T>(Pb + q * ea.p_bs + rm * ea.p_ld, pv);
+          if (has_res) load8f<OUT>(Rb + r_off, rv);
+          if (dact) load8f<T>(Pb + p_off, pv);
           if (has_beta) load8f<OUT>(Cb + c_off, ov);
           float x[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = fmaf(v[k][e], ea.alpha, bias8[e]);
-          if (has_pre) store8f<T>(Qb + q * ea.q_bs + rm * ea.q_ld, x);
+          if (has_pre) store8f<T>(Qb + q_off, x);
           if (dact) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] *= act_grad_f<FASTACT>(act, pv[e]);
@@ -481,7 +466,7 @@ __device__ __forceinline__ void epilogue_fast(const EpiArgs& ea, float* stage, c
           }
           if (drop) {
             float dsc[8];
-            dropout_scale8(ea.seed, ea.ctr_base + (unsigned long long)gm * (unsigned long long)ea.N + gn, thresh, inv_keep, dsc);
+            dropout_scale8_folded(seedf, ctr0 + (unsigned long long)rr * (unsigned long long)ea.N, thresh, inv_keep, dsc);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] *= dsc[e];
           }

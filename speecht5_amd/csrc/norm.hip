@@ -218,39 +218,12 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
           store4f<T>(y + (row0 + r) * cols + c, o);
           if constexpr (Q8) {
             // (cols % 32 == 0: the 8 lanes of a block are all inside the row or all outside)
-            float amax = 0.f;
-            unsigned int nf = 0u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              o[e] = Elem<T>::to_f(Elem<T>::from_f(o[e]));        // the value the bf16 output holds
-              const bool bad = (__float_as_uint(o[e]) & 0x7f800000u) == 0x7f800000u;
-              nf |= bad ? (1u << e) : 0u;
-              amax = fmaxf(amax, bad ? 0.f : fabsf(o[e]));
-            }
-            unsigned int nf_blk = nf != 0u ? 1u : 0u;
-#pragma unroll
-            for (int m = 1; m < 8; m <<= 1) {
-              amax = fmaxf(amax, __shfl_xor(amax, m, 64));
-              nf_blk |= (unsigned int)__shfl_xor((int)nf_blk, m, 64);
-            }
-            int E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;
-            E = E < 0 ? 0 : (E > 254 ? 254 : E);
-            const float inv = __uint_as_float((unsigned int)(254 - E) << 23);
-            float f4[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float t = ((nf >> e) & 1u) ? 0.f : o[e] * inv;
-              f4[e] = fminf(fmaxf(t, -448.f), 448.f);
-            }
-            int pk = 0;
-            pk = __builtin_amdgcn_cvt_pk_fp8_f32(f4[0], f4[1], pk, false);
-            pk = __builtin_amdgcn_cvt_pk_fp8_f32(f4[2], f4[3], pk, true);
-            unsigned int u = (unsigned int)pk;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if ((nf >> e) & 1u) u = (u & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
-            *reinterpret_cast<unsigned int*>(q8 + (row0 + r) * cols + c) = u;
-            if ((lane & 7) == 0) s8[(row0 + r) * (cols >> 5) + (c >> 5)] = nf_blk ? (unsigned char)0xff : (unsigned char)E;
+            for (int e = 0; e < 4; ++e) o[e] = Elem<T>::to_f(Elem<T>::from_f(o[e]));        // the values the bf16 output holds
+            unsigned int qw[1], qs;
+            mx8_quant<4>(o, qw, qs);
+            *reinterpret_cast<unsigned int*>(q8 + (row0 + r) * cols + c) = qw[0];
+            if ((lane & 7) == 0) s8[(row0 + r) * (cols >> 5) + (c >> 5)] = (unsigned char)qs;
           }
         }
       }
@@ -274,6 +247,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
   const bool dropped = keep != nullptr && *keep == 0.f;
   const unsigned int thresh = dxd ? dropout_thresh(drop_p) : 0u;
   const float inv_keep = dxd ? 1.f / (1.f - drop_p) : 1.f;
+  const unsigned int seedf = dxd ? drop_seed_fold(seed) : 0u;      // (once: see dropout_scale4_folded)
   extern __shared__ float red[];   // PG: [4 waves][2][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float g[NV][4], dg[NV][4], db[NV][4];
@@ -338,7 +312,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
             store4f<T>(dx + (row0 + r) * cols + c, o);
             if (dxd) {
               float dsc[4];
-              dropout_scale4(seed, (unsigned long long)((row0 + r) * cols + c), thresh, inv_keep, dsc);
+              dropout_scale4_folded(seedf, (unsigned long long)((row0 + r) * cols + c), thresh, inv_keep, dsc);
 #pragma unroll
               for (int e = 0; e < 4; ++e) o[e] = Elem<T>::to_f(Elem<T>::from_f(o[e])) * dsc[e];  // mask the ROUNDED dX
               store4f<T>(dxd + (row0 + r) * cols + c, o);

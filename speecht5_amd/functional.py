@@ -1417,13 +1417,13 @@ def guided_attention_loss(att, ilens, olens, sigma, alpha):
 # -------------------------------------------------------------------------------------------------
 class LayerNormFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, gate=None):
+    def forward(ctx, x, weight, bias, eps, gate=None, q8=False):
         x2 = _rows(x)
         rows, cols = x2.shape
         y = torch.empty_like(x2)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        if gate is None and _FP8.enabled and (_FP8.fuse & 1) and x2.dtype == torch.bfloat16 and cols % 128 == 0 and cols <= 2048 and \
+        if q8 and gate is None and _FP8.enabled and (_FP8.fuse & 1) and x2.dtype == torch.bfloat16 and cols % 128 == 0 and cols <= 2048 and \
                 rows >= _FP8.min_rows:
             # fp8 mode: the consumer of a pre-LN layer's LayerNorm is an fp8 GEMM (QKV / fc1) -- its operand image comes out of this pass
             q, sc = _q8_buffers(rows, cols, x.device)
@@ -1482,13 +1482,17 @@ class LayerNormFunction(torch.autograd.Function):
             _grad_done(weight)
         if gb is not None:
             _grad_done(bias)
-        return (dx.view(xshape) if dx is not None else None), None, None, None, None
+        return (dx.view(xshape) if dx is not None else None), None, None, None, None, None
 
 
-def layer_norm(x, weight, bias, eps=1e-5, gate=None):
+def layer_norm(x, weight, bias, eps=1e-5, gate=None, q8=False):
+    """q8: the output's consumer is a Linear that may run on the fp8 GEMM (a pre-LN layer's QKV projection / fc1): in fp8 compute mode
+    the kernel then writes the output's MX-fp8 image beside it (st5_layernorm_fwd_q8) and that Linear launches no quantiser."""
     if gate is not None:
         gate.used = True
         return LayerNormFunction.apply(x.contiguous(), weight, bias, float(eps), gate)
+    if q8 and _FP8.enabled:
+        return LayerNormFunction.apply(x.contiguous(), weight, bias, float(eps), None, True)
     return LayerNormFunction.apply(x.contiguous(), weight, bias, float(eps))
 
 

@@ -41,12 +41,12 @@ class TransformerSentenceEncoderLayer(nn.Module):
         p, pa = (self.dropout if tr else 0.0), (self.activation_dropout if tr else 0.0)
         x = Fn.layer_boundary(x, self)
         if self.layer_norm_first:
-            h = self.self_attn_layer_norm(x)
+            h = self.self_attn_layer_norm(x, q8=True)       # (consumer: the QKV projection; fp8 mode takes its fp8 image from this pass)
             pb = pos_bias
             if pos_bias is not None:
                 pb = RelPosKeys(self.norm_k(pos_bias.table), pos_bias.maxlen)
             x, _ = self.self_attn.forward_rows(h, B, T, key_padding_mask=padding_mask, position_bias=pb, residual=x, out_dropout=p)
-            h = self.final_layer_norm(x)
+            h = self.final_layer_norm(x, q8=True)           # (consumer: fc1)
             x = Fn.ffn(h, x, self.fc1, self.fc2, self.act, pa, p)
         else:
             x, _ = self.self_attn.forward_rows(x, B, T, key_padding_mask=padding_mask, position_bias=pos_bias, residual=x,
@@ -110,20 +110,20 @@ class TransformerDecoderLayer(nn.Module):
         nb = self.normalize_before
         x = Fn.layer_boundary(x, self)
         with torch.no_grad() if not ft else contextlib.ExitStack():
-            h = self.self_attn_layer_norm(x) if nb else x
+            h = self.self_attn_layer_norm(x, q8=True) if nb else x
             x, _ = self.self_attn.forward_rows(h, B, T, key_padding_mask=self_padding_mask, causal=causal, residual=x,
                                                out_dropout=p)
             if not nb:
                 x = self.self_attn_layer_norm(x)
         attn = None
         if self.encoder_attn is not None and enc_rows is not None:
-            h = self.encoder_attn_layer_norm(x) if nb else x
+            h = self.encoder_attn_layer_norm(x, q8=True) if nb else x
             x, attn = self.encoder_attn.forward_rows(h, B, T, kv=enc_rows, S=S, key_padding_mask=enc_padding_mask, residual=x,
                                                      out_dropout=p, need_weights=need_attn or (not tr and self.need_attn), kv_all=kv_all)
             if not nb:
                 x = self.encoder_attn_layer_norm(x)
         with torch.no_grad() if not ft else contextlib.ExitStack():
-            h = self.final_layer_norm(x) if nb else x
+            h = self.final_layer_norm(x, q8=True) if nb else x
             x = Fn.ffn(h, x, self.fc1, self.fc2, self.act, pa, p)
             if not nb:
                 x = self.final_layer_norm(x, gate=gate)
