@@ -408,7 +408,16 @@ __device__ __forceinline__ long long drop_row_stride(int row_len) { return ((lon
 // NT or TN form alike; never with one such wave, never with a copy kernel) had lanes 48..63 of its registers corrupted in
 // 10-16 of 16 runs -- the source of the run-to-run differences of the side-by-side micro-batches at full size.  With the
 // padding the combination cannot be scheduled; the GEMM kernels' own occupancy (2 waves/SIMD) is unchanged.
+// Round 6: OFF by default.  Section 4c of DESIGN.md traced the corruption this padding was built against to one missing LDS wait in
+// fa2::bwd_dkv_kernel -- the padded library of round 4 showed it all the same (tools/r5/dkv_pair.py) -- so what the padding still did
+// was keep small kernels of the OTHER micro-batch's stream off the SIMDs of the 128x128 GEMMs (122-189 registers without it).  Measured
+// on the benched update, same box, alternating (profiles/r6b_knob_ab.txt): 28.67 / 28.80 / 28.96 ms without against 28.82 / 28.95 /
+// 29.05 with; replayed side by side == eager in turn bit for bit either way.  -DST5_PAD256 (tools/r6b/build_pad_lib.sh) restores it.
+#ifdef ST5_PAD256
 #define ST5_PAD_TO_256_VGPRS() asm volatile("; vgpr allocation padded to 256" ::: "v255")
+#else
+#define ST5_PAD_TO_256_VGPRS()
+#endif
 
 // Device allocation of the library's own workspaces / arenas.  ST5_POISON=1 (debug, read once) fills every new allocation with
 // 0xFF bytes -- NaN as bf16 and fp32, -1 as an index -- so that a kernel consuming workspace it never wrote shows up as NaN /

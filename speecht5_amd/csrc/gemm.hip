@@ -2148,13 +2148,23 @@ __global__ __launch_bounds__(512) void gemm_tn8p_kernel(const st5_gemm_params p,
 // ranges start at multiples of 8 (XCD-aware tile order inside every problem), a problem's result does not depend on its group.  Every
 // output element sees the MFMA chain of the 128^2 kernels (k-tiles ascending, four 16-deep groups each): the WEIGHT gradients are
 // bit-identical to gemm_tn_group_kernel's; the bias-gradient column is summed on the VALU here (tn8p_body), in another -- fixed -- order.
+// (a problem as the phased body needs it -- 72 bytes instead of st5_gemm_params' 400+, so that SIXTEEN fit into the kernel arguments: a
+//  Base decoder layer has six weight gradients of 9-36 tiles, and eight problems filled only 56-77 % of a round)
+constexpr int TNG8P_MAX = 16;
+struct Tn8pProb { const void* A; const void* B; void* C; float* asum; long long lda, ldb, ldc; int M, N, K; float beta; };
+struct Tn8pGroupArgs { Tn8pProb p[TNG8P_MAX]; int first[TNG8P_MAX + 1]; int tiles[TNG8P_MAX]; int n; };
 template <int FEAT>
-__global__ __launch_bounds__(512) void gemm_tn8p_group_kernel(const TnGroupArgs g) {
+__global__ __launch_bounds__(512) void gemm_tn8p_group_kernel(const Tn8pGroupArgs g) {
   int j = 0;
   while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
   const int lb = (int)blockIdx.x - g.first[j];
   if (lb >= g.tiles[j]) return;
-  tn8p_body<FEAT, true>(g.p[j], 1, lb, g.tiles[j], 0, 1);
+  st5_gemm_params p = {};
+  p.A.ptr = g.p[j].A; p.A.ld = g.p[j].lda; p.B.ptr = g.p[j].B; p.B.ld = g.p[j].ldb; p.C.ptr = g.p[j].C; p.C.ld = g.p[j].ldc;
+  p.asum = g.p[j].asum; p.M = g.p[j].M; p.N = g.p[j].N; p.K = g.p[j].K; p.batch = 1; p.zdiv = 1;
+  p.alpha = 1.f; p.beta = g.p[j].beta; p.act = ACT_NONE;
+  p.flags = ST5_GEMM_A_KSTRIDED | ST5_GEMM_B_KSTRIDED | ST5_GEMM_OUT_F32;
+  tn8p_body<FEAT, true>(p, 1, lb, g.tiles[j], 0, 1);
 }
 
 int g_tn8p = 0;   // st5_gemm_set_tn_phased: 0 (default) = always the 128^2 kernel; 1 / 2 = eligible weight-gradient GEMMs on the phased 256^2 kernel (staggered / not).
@@ -2824,18 +2834,21 @@ extern "C" int st5_gemm_tn_group(const st5_gemm_params* list, int32_t n, int dty
       return ST5_ERR_LAUNCH;
     attr = true;
   }
-  TnGroupArgs g;
-  int m = 0;             // problems in g
+  TnGroupArgs g;          // 128 x 128 class: up to TNG_MAX problems
+  Tn8pGroupArgs g8;       // phased 256 x 256 class: up to TNG8P_MAX
+  int m = 0;             // problems in the open group
   long long padded = 0;
   bool accum = false, phased = false;
   auto launch = [&]() {
     if (m == 0) return (int)ST5_OK;
-    g.first[m] = (int)padded; g.n = m;
-    for (int i = m; i < TNG_MAX; ++i) { g.tiles[i] = 0; g.first[i + 1] = (int)padded; }
     if (phased) {
-      if (accum) hipLaunchKernelGGL(gemm_tn8p_group_kernel<F_BETA>, dim3((unsigned)padded), dim3(512), (size_t)8 * TILE_BYTES, s, g);
-      else hipLaunchKernelGGL(gemm_tn8p_group_kernel<0>, dim3((unsigned)padded), dim3(512), (size_t)8 * TILE_BYTES, s, g);
+      g8.first[m] = (int)padded; g8.n = m;
+      for (int i = m; i < TNG8P_MAX; ++i) { g8.tiles[i] = 0; g8.first[i + 1] = (int)padded; }
+      if (accum) hipLaunchKernelGGL(gemm_tn8p_group_kernel<F_BETA>, dim3((unsigned)padded), dim3(512), (size_t)8 * TILE_BYTES, s, g8);
+      else hipLaunchKernelGGL(gemm_tn8p_group_kernel<0>, dim3((unsigned)padded), dim3(512), (size_t)8 * TILE_BYTES, s, g8);
     } else {
+      g.first[m] = (int)padded; g.n = m;
+      for (int i = m; i < TNG_MAX; ++i) { g.tiles[i] = 0; g.first[i + 1] = (int)padded; }
       if (accum) hipLaunchKernelGGL(gemm_tn_group_kernel<F_BETA>, dim3((unsigned)padded), dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, g);
       else hipLaunchKernelGGL(gemm_tn_group_kernel<0>, dim3((unsigned)padded), dim3(NTHREADS), (size_t)4 * TILE_BYTES, s, g);
     }
@@ -2862,13 +2875,21 @@ extern "C" int st5_gemm_tn_group(const st5_gemm_params* list, int32_t n, int dty
       if (rc) return rc;
       continue;
     }
-    const bool ph = tn_group_phased(p);
-    bool clash = m == TNG_MAX || (m > 0 && ((p.beta != 0.f) != accum || ph != phased));
-    for (int j = 0; j < m && !clash; ++j) clash = g.p[j].C.ptr == p.C.ptr || (p.asum && g.p[j].asum == p.asum);
+    const bool ph = tn_group_phased(p) && p.alpha == 1.f && p.A.zs0 == 0 && p.A.zs1 == 0 && p.B.zs0 == 0 && p.B.zs1 == 0;
+    bool clash = (m > 0 && m == (phased ? TNG8P_MAX : TNG_MAX)) || (m > 0 && ((p.beta != 0.f) != accum || ph != phased));
+    for (int j = 0; j < m && !clash; ++j)
+      clash = phased ? (g8.p[j].C == p.C.ptr || (p.asum && g8.p[j].asum == p.asum)) : (g.p[j].C.ptr == p.C.ptr || (p.asum && g.p[j].asum == p.asum));
     if (clash) { const int rc = launch(); if (rc) return rc; }      // (same output twice, mixed beta or block tile: in order, one launch each)
     if (m == 0) { accum = p.beta != 0.f; phased = ph; }
     const int tiles = ph ? (p.M / 256) * (p.N / 256) : ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    g.p[m] = p; g.tiles[m] = tiles; g.first[m] = (int)padded;
+    if (ph) {
+      Tn8pProb& q = g8.p[m];
+      q.A = p.A.ptr; q.B = p.B.ptr; q.C = const_cast<void*>(p.C.ptr); q.asum = p.asum; q.lda = p.A.ld; q.ldb = p.B.ld; q.ldc = p.C.ld;
+      q.M = p.M; q.N = p.N; q.K = p.K; q.beta = p.beta;
+      g8.tiles[m] = tiles; g8.first[m] = (int)padded;
+    } else {
+      g.p[m] = p; g.tiles[m] = tiles; g.first[m] = (int)padded;
+    }
     padded += (tiles + 7) / 8 * 8;
     ++m;
   }

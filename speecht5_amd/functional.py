@@ -810,6 +810,9 @@ _WG_ROUND, _WG_FLUSH_AT, _WG_MAX = [int(v) for v in os.environ.get("ST5_WGRAD_RO
 # (round 6) problems whose M, N are multiples of 256 -- every Linear of the transformer -- run on the phased 256 x 256 grouped kernel, one
 # block per CU: a round is 256 tiles of 256^2 (two Base layers are 216, a Large layer and the next one's first problems 208-240)
 _WG_ROUND_P, _WG_FLUSH_AT_P = [int(v) for v in os.environ.get("ST5_WGRAD_ROUND_P", "256,200").split(",")]
+# (problems per phased launch: the library takes up to sixteen -- compact 72-byte records in the kernel arguments; a decoder layer has six.
+#  Sixteen measured no better than eight on the benched update -- 29.38 / 29.64 / 29.46 against 29.51 / 29.34 / 29.11 ms, same box -- so eight it stays)
+_WG_MAX_P = int(os.environ.get("ST5_WG_MAX_P", "8"))
 
 
 def set_wgrad_grouping(on):
@@ -920,7 +923,7 @@ def _wgrad_queue(A, B, C, M, N, K, dt, flags, asum, keep):
 
     def launch():
         _launch_wgrad_group(st, q.pop(st))
-    if ent is not None and ent[0] and (ent[2] + tiles > round_ or len(ent[0]) == _WG_MAX or ent[3] != dt or ent[4] != phased
+    if ent is not None and ent[0] and (ent[2] + tiles > round_ or len(ent[0]) == (_WG_MAX_P if ent[4] else _WG_MAX) or ent[3] != dt or ent[4] != phased
                                        or any(p[2].ptr == C.ptr or (asum is not None and p[8] is not None and p[8].data_ptr() == asum.data_ptr())
                                               for p in ent[0])):
         launch()            # (the round is full, another block tile, or the same gradient twice -- tied weights -- would race inside one launch)

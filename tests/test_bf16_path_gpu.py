@@ -239,6 +239,10 @@ def test_phased_weight_gradient_group_equals_the_128_tile_group_bit_for_bit(cuda
         assert (d1 - d0).abs().max().item() <= 1e-3 * max(rb.abs().max().item(), math.sqrt(K))
     alone = run(0, [1])[0]
     assert torch.equal(alone[0], big[1][0]) and torch.equal(alone[1], big[1][1])
+    # twelve problems in ONE phased launch (compact records: up to sixteen per launch; a Base decoder layer has six)
+    which = [0, 1, 2, 3, 4, 5, 1, 4, 5, 1, 4, 5]
+    for i, (C, d) in zip(which, run(0, which)):
+        assert torch.equal(C, big[i][0]) and torch.equal(d, big[i][1]), f"problem {shapes[i]} inside a group of twelve"
 
 
 @pytest.mark.parametrize("mode", [3, 4])
