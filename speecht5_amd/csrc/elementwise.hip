@@ -292,13 +292,16 @@ template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (
   v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
 }
 constexpr int RS_CHUNK = 2048;
-// block = 64 rows x 4 parts: part p counts inside its quarter of every staged chunk, the four counts are added at the end
+// block = RS_ROWS rows x RS_PARTS parts: part p counts inside its share of every staged chunk, the counts are added at the end.
+// (Round 6: 32 rows x 8 parts instead of 64 x 4 -- 8192 tokens were 128 blocks on 256 CUs, each thread walking 2048 ids; now every CU has
+//  a block and a thread walks 1024.  Same ranks.)
+constexpr int RS_ROWS = 32, RS_PARTS = 256 / RS_ROWS;
 __global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t* __restrict__ tok, int32_t* __restrict__ order,
                                                         int32_t* __restrict__ sid, int n) {
   __shared__ __attribute__((aligned(16))) int32_t ids[RS_CHUNK];
-  __shared__ int cnt[4][64];
-  const int tl = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int t = blockIdx.x * 64 + tl;
+  __shared__ int cnt[RS_PARTS][RS_ROWS];
+  const int tl = threadIdx.x % RS_ROWS, part = threadIdx.x / RS_ROWS;
+  const int t = blockIdx.x * RS_ROWS + tl;
   const int my = t < n ? tok[t] : 0x7fffffff;
   int rank = 0;
   for (int base = 0; base < n; base += RS_CHUNK) {
@@ -307,22 +310,27 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t* __restric
     for (int i = threadIdx.x; i < RS_CHUNK; i += 256) ids[i] = i < m ? tok[base + i] : 0x7fffffff;
     __syncthreads();
     // (slots past m hold INT_MAX and never count, so whole pieces are walked with 16-byte LDS reads: 4 ids per round trip)
-    const int lo = part * (RS_CHUNK / 4), hi = lo + RS_CHUNK / 4;
+    const int lo = part * (RS_CHUNK / RS_PARTS), hi = lo + RS_CHUNK / RS_PARTS;
     if (lo >= m) continue;
     const int4* v4 = reinterpret_cast<const int4*>(ids + lo);
     if (base + hi <= t) {                        // the whole piece lies before t: ties count
 #pragma unroll 2
-      for (int i = 0; i < RS_CHUNK / 16; ++i) { const int4 v = v4[i]; rank += (v.x <= my) + (v.y <= my) + (v.z <= my) + (v.w <= my); }
+      for (int i = 0; i < RS_CHUNK / (4 * RS_PARTS); ++i) { const int4 v = v4[i]; rank += (v.x <= my) + (v.y <= my) + (v.z <= my) + (v.w <= my); }
     } else if (base + lo > t) {                  // the whole piece lies after t: ties do not count
 #pragma unroll 2
-      for (int i = 0; i < RS_CHUNK / 16; ++i) { const int4 v = v4[i]; rank += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my); }
+      for (int i = 0; i < RS_CHUNK / (4 * RS_PARTS); ++i) { const int4 v = v4[i]; rank += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my); }
     } else {
       for (int i = lo; i < hi; ++i) rank += ids[i] < my || (ids[i] == my && base + i < t);
     }
   }
   cnt[part][tl] = rank;
   __syncthreads();
-  if (part == 0 && t < n) { const int r = cnt[0][tl] + cnt[1][tl] + cnt[2][tl] + cnt[3][tl]; order[r] = t; sid[r] = my; }
+  if (part == 0 && t < n) {
+    int r = 0;
+#pragma unroll
+    for (int p = 0; p < RS_PARTS; ++p) r += cnt[p][tl];
+    order[r] = t; sid[r] = my;
+  }
 }
 // Segmented sums over the sorted order, balanced for runs of any length.  The sorted entries are cut into chunks of SEG; block
 // (chunk, 256-column slab) sums every PIECE (maximal range of equal ids inside the chunk) -- wave w takes pieces w, w + 4, ...,
@@ -874,7 +882,7 @@ extern "C" int st5_embed_rows_bwd_det_w(const void* dy, const int32_t* tok, floa
   int32_t* sid = order + rows;
   float* head = reinterpret_cast<float*>(g_scatter_ws + ints);
   float* tail = head + (size_t)nch * cols;
-  hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, tok, order, sid, (int)rows);
+  hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)((rows + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0, s, tok, order, sid, (int)rows);
   dim3 grid((unsigned)nch, (unsigned)((cols + 255) / 256));
   DISPATCH(dtype, hipLaunchKernelGGL(seg_pieces_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, order, sid, dtable, head, tail, (long long)rows, cols, vocab, scale, row_w, rw_div, rw_mod),
            hipLaunchKernelGGL(seg_pieces_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, order, sid, dtable, head, tail, (long long)rows, cols, vocab, scale, row_w, rw_div, rw_mod));

@@ -165,6 +165,7 @@ __device__ __forceinline__ void read_bias(unsigned int (&braw)[32], const char* 
 // =====================================================================================================================
 // QP table: qp[bh][q][QP_PAD + b] = bf16(sc2 * q . pe[b]), end chunks replicated.  grid (ceil(T/128), B*H), 256 threads.
 // =====================================================================================================================
+template <bool PE_LDS>
 __global__ __launch_bounds__(256) void qp_table_kernel(const bf16_t* __restrict__ qg, long long q_ld, const bf16_t* __restrict__ pe,
                                                        bf16_t* __restrict__ qp, int H, int T, int nb, float sc2) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -179,6 +180,18 @@ __global__ __launch_bounds__(256) void qp_table_kernel(const bf16_t* __restrict_
     qf[ks] = *reinterpret_cast<const bf16x8*>(qg + ((long long)b * T + qc) * q_ld + h * HD + ks * 16 + hi * 8);
   bf16_t* row = qp + ((long long)bh * T + qc) * nbp + QP_PAD;
   const int nbt = (nb + 31) / 32;
+  // Round 6: the PE table (nb x 64 bf16: 40 KB at nb = 320) is staged in LDS once per block, swizzled like every [row][64] tile of this
+  // file.  Before, every bucket tile began with four dependent global loads of its PE fragment (L2 hits, ~1 us with the MFMAs and stores
+  // behind them) and a wave walked its ten tiles one after the other: the kernel was bound by that chain, not by its 66 MB of stores.
+  // Same fragments, same MFMA order: the table is bit-identical.  (PE_LDS == false: tables too large for LDS keep the global loads.)
+  extern __shared__ __attribute__((aligned(16))) char pe_lds[];
+  if (PE_LDS) {
+    for (int ch = tid; ch < nb * 8; ch += 256) {
+      const int r = ch >> 3, c = ch & 7;
+      *reinterpret_cast<u32x4*>(pe_lds + lds_off(r, c)) = *reinterpret_cast<const u32x4*>(pe + r * HD + c * 8);
+    }
+    __syncthreads();
+  }
   // The PE rows go into the MFMA's A operand PERMUTED (row m of the tile = bucket 16 ((m >> 2) & 1) + (m & 3) + 4 (m >> 3) of it), so
   // that accumulator register r of lane (query, hi) is bucket 32 bt + 16 hi + r: 16 CONSECUTIVE buckets = two 16-byte stores per lane
   // and tile (round 5; the natural order gave every lane groups of 4 buckets = 8-byte pieces 672 bytes apart, 2.4 TB/s of writes).
@@ -192,7 +205,8 @@ __global__ __launch_bounds__(256) void qp_table_kernel(const bf16_t* __restrict_
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 pf = *reinterpret_cast<const bf16x8*>(pe + brow * HD + ks * 16 + hi * 8);
+      const bf16x8 pf = PE_LDS ? *reinterpret_cast<const bf16x8*>(pe_lds + lds_off(brow, 2 * ks + hi))
+                               : *reinterpret_cast<const bf16x8*>(pe + brow * HD + ks * 16 + hi * 8);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qf[ks], acc, 0, 0, 0);
     }
     if (qi < T) {
@@ -1127,8 +1141,19 @@ extern "C" int32_t st5_flash_attn_qp_row(int32_t nb) { return g_impl == 2 ? nb +
 extern "C" int st5_flash_attn_qp_table(const void* q, int64_t q_ld, const void* pe, void* qp_out, int32_t B, int32_t H, int32_t T,
                                        int32_t nb, float scale, int dtype, void* stream) {
   if (!q || !pe || !qp_out || B <= 0 || H <= 0 || T <= 0 || nb <= 0 || nb % 8 || dtype != ST5_BF16 || q_ld % 8) return ST5_ERR_ARG;
-  hipLaunchKernelGGL(fa2::qp_table_kernel, dim3((T + 127) / 128, B * H), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
-                     (long long)q_ld, (const bf16_t*)pe, (bf16_t*)qp_out, H, T, nb, scale * fa2::LOG2E);
+  const size_t pe_bytes = (size_t)nb * fa2::HD * 2;
+  if (pe_bytes <= 64 * 1024) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)fa2::qp_table_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
+      attr = true;
+    }
+    hipLaunchKernelGGL(fa2::qp_table_kernel<true>, dim3((T + 127) / 128, B * H), dim3(256), pe_bytes, (hipStream_t)stream, (const bf16_t*)q,
+                       (long long)q_ld, (const bf16_t*)pe, (bf16_t*)qp_out, H, T, nb, scale * fa2::LOG2E);
+  } else {
+    hipLaunchKernelGGL(fa2::qp_table_kernel<false>, dim3((T + 127) / 128, B * H), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
+                       (long long)q_ld, (const bf16_t*)pe, (bf16_t*)qp_out, H, T, nb, scale * fa2::LOG2E);
+  }
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

@@ -175,10 +175,12 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const long long row = row0 + r < rows ? row0 + r : rows - 1;
+    long long ro = row * cols;             // (once per row, opaque: see ln_bwd_vec_kernel)
+    asm volatile("" : "+v"(ro));
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
-      if (c < cols) load4f<T>(x + row * cols + c, v[r][i]);
+      if (c < cols) load4f<T>(x + ro + c, v[r][i]);
       else { v[r][i][0] = v[r][i][1] = v[r][i][2] = v[r][i][3] = 0.f; }
     }
   }
@@ -207,6 +209,8 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
     }
     const float rs = rsqrtf(wave_sum(q) * inv_n + eps);
     if (row0 + r < rows) {
+      long long ro = (row0 + r) * cols;
+      asm volatile("" : "+v"(ro));
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
@@ -214,15 +218,15 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = fmaf(v[r][i][e] * rs, g[i][e], b[i][e]);
-          if (dropped) load4f<T>(skip + (row0 + r) * cols + c, o);
-          store4f<T>(y + (row0 + r) * cols + c, o);
+          if (dropped) load4f<T>(skip + ro + c, o);
+          store4f<T>(y + ro + c, o);
           if constexpr (Q8) {
             // (cols % 32 == 0: the 8 lanes of a block are all inside the row or all outside)
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = Elem<T>::to_f(Elem<T>::from_f(o[e]));        // the values the bf16 output holds
             unsigned int qw[1], qs;
             mx8_quant<4>(o, qw, qs);
-            *reinterpret_cast<unsigned int*>(q8 + (row0 + r) * cols + c) = qw[0];
+            *reinterpret_cast<unsigned int*>(q8 + ro + c) = qw[0];
             if ((lane & 7) == 0) s8[(row0 + r) * (cols >> 5) + (c >> 5)] = (unsigned char)qs;
           }
         }
@@ -266,21 +270,33 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
   struct alignas(sizeof(T) * 4) Raw4 { T v[4]; };
   struct Set { Raw4 xv[BRPW][NV], gv[BRPW][NV]; float mu[BRPW], rs[BRPW]; };
   auto load_set = [&](Set& S, long long row0) {
+    // (row offsets: ONE 64-bit multiply per set, opaque, + r * cols on the scalar unit; hipcc otherwise forms row * cols + c as a 64-bit
+    //  multiply-add -- a quarter-rate instruction -- per access: 120 of them per trip of this loop at 768 columns, on a kernel that runs
+    //  one wave per SIMD)
+    long long ro0 = row0 * cols;
+    asm volatile("" : "+v"(ro0));
+    const long long ro_last = (rows - 1) * cols;
 #pragma unroll
     for (int r = 0; r < BRPW; ++r) {
       const long long row = row0 + r < rows ? row0 + r : rows - 1;
+      long long ro = ro0 + (long long)r * cols;
+      ro = ro < ro_last ? ro : ro_last;
+      const T* const xr = x + ro;
+      const T* const gr = dy + ro;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < cols) {
-          S.xv[r][i] = *reinterpret_cast<const Raw4*>(x + row * cols + c);
-          S.gv[r][i] = *reinterpret_cast<const Raw4*>(dy + row * cols + c);
+          S.xv[r][i] = *reinterpret_cast<const Raw4*>(xr + c);
+          S.gv[r][i] = *reinterpret_cast<const Raw4*>(gr + c);
         }
       }
       S.mu[r] = mean[row]; S.rs[r] = rstd[row];
     }
   };
   auto finish_set = [&](Set& S, long long row0) {
+    long long fo0 = row0 * cols;
+    asm volatile("" : "+v"(fo0));
 #pragma unroll
     for (int r = 0; r < BRPW; ++r) {
       const bool live = row0 + r < rows;
@@ -302,6 +318,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
       s1 = wave_sum(s1) * inv_n;
       s2 = wave_sum(s2) * inv_n;
       if (live) {
+        const long long ro = fo0 + (long long)r * cols;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           const int c = (i * 64 + lane) * 4;
@@ -309,13 +326,13 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = S.rs[r] * (gg_[i][e] - s1 - xh_[i][e] * s2);
-            store4f<T>(dx + (row0 + r) * cols + c, o);
+            store4f<T>(dx + ro + c, o);
             if (dxd) {
               float dsc[4];
-              dropout_scale4_folded(seedf, (unsigned long long)((row0 + r) * cols + c), thresh, inv_keep, dsc);
+              dropout_scale4_folded(seedf, (unsigned long long)(ro + c), thresh, inv_keep, dsc);
 #pragma unroll
               for (int e = 0; e < 4; ++e) o[e] = Elem<T>::to_f(Elem<T>::from_f(o[e])) * dsc[e];  // mask the ROUNDED dX
-              store4f<T>(dxd + (row0 + r) * cols + c, o);
+              store4f<T>(dxd + ro + c, o);
             }
           }
         }
