@@ -1948,7 +1948,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_group_kernel(const TnGrou
 // ------------------------------------------------------------------------------------------------------
 // (bx of nwg: this block's tile among the problem's 256 x 256 tiles; by of ny: its split of the reduction -- the launch grid's own numbers
 //  for the single-problem kernel, problem-local ones inside a grouped launch)
-template <int FEAT, bool STAGGER>
+template <int FEAT, bool STAGGER, bool REMAP = true>
 __device__ __forceinline__ void tn8p_body(const st5_gemm_params& p, const int c_vec_ok, const int bx, const int nwg_, const int by, const int ny) {
   typedef bf16_t T;
   constexpr int BK = 64;
@@ -1960,7 +1960,7 @@ __device__ __forceinline__ void tn8p_body(const st5_gemm_params& p, const int c_
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_n = (p.N + 255) / 256;
   int bid = bx;
-  {
+  if (REMAP) {     // (the grouped launch remaps over ALL its tiles and passes the problem-local tile number)
     const int nwg = nwg_, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
@@ -2155,16 +2155,26 @@ struct Tn8pProb { const void* A; const void* B; void* C; float* asum; long long 
 struct Tn8pGroupArgs { Tn8pProb p[TNG8P_MAX]; int first[TNG8P_MAX + 1]; int tiles[TNG8P_MAX]; int n; };
 template <int FEAT>
 __global__ __launch_bounds__(512) void gemm_tn8p_group_kernel(const Tn8pGroupArgs g) {
+  // XCD-aware order over the WHOLE launch (round 6): block b runs on XCD b % 8; XCD x takes the x-th contiguous eighth of the launch's tile
+  // list (problems in queue order, tiles of a problem in tile_of's patch-friendly order), i.e. ~27-32 consecutive tiles of ONE or two
+  // problems: a 9 x 3 patch reads 12 operand panels per k-step for 27 tiles.  The first form remapped inside every problem: with 9-36
+  // tiles per problem every XCD held 1-5 tiles of EACH of the launch's eight problems -- ~35 panels for the same 27 tiles -- and the
+  // counters showed it: 921 MB through the fabric per launch (2.1x the algorithmic bytes) at 4 TB/s, the bound of the kernel.
+  const int T = g.first[g.n];
+  int gidx;
+  {
+    const int b = (int)blockIdx.x, xcd = b & 7, q = T >> 3, rmd = T & 7;
+    gidx = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
+  }
   int j = 0;
-  while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
-  const int lb = (int)blockIdx.x - g.first[j];
-  if (lb >= g.tiles[j]) return;
+  while (j + 1 < g.n && gidx >= g.first[j + 1]) ++j;
+  const int lb = gidx - g.first[j];
   st5_gemm_params p = {};
   p.A.ptr = g.p[j].A; p.A.ld = g.p[j].lda; p.B.ptr = g.p[j].B; p.B.ld = g.p[j].ldb; p.C.ptr = g.p[j].C; p.C.ld = g.p[j].ldc;
   p.asum = g.p[j].asum; p.M = g.p[j].M; p.N = g.p[j].N; p.K = g.p[j].K; p.batch = 1; p.zdiv = 1;
   p.alpha = 1.f; p.beta = g.p[j].beta; p.act = ACT_NONE;
   p.flags = ST5_GEMM_A_KSTRIDED | ST5_GEMM_B_KSTRIDED | ST5_GEMM_OUT_F32;
-  tn8p_body<FEAT, true>(p, 1, lb, g.tiles[j], 0, 1);
+  tn8p_body<FEAT, true, false>(p, 1, lb, g.tiles[j], 0, 1);
 }
 
 int g_tn8p = 0;   // st5_gemm_set_tn_phased: 0 (default) = always the 128^2 kernel; 1 / 2 = eligible weight-gradient GEMMs on the phased 256^2 kernel (staggered / not).
@@ -2841,7 +2851,7 @@ extern "C" int st5_gemm_tn_group(const st5_gemm_params* list, int32_t n, int dty
   bool accum = false, phased = false;
   auto launch = [&]() {
     if (m == 0) return (int)ST5_OK;
-    if (phased) {
+    if (phased) {      // (first[]: cumulative tile counts, no padding -- the kernel remaps over the whole launch)
       g8.first[m] = (int)padded; g8.n = m;
       for (int i = m; i < TNG8P_MAX; ++i) { g8.tiles[i] = 0; g8.first[i + 1] = (int)padded; }
       if (accum) hipLaunchKernelGGL(gemm_tn8p_group_kernel<F_BETA>, dim3((unsigned)padded), dim3(512), (size_t)8 * TILE_BYTES, s, g8);
@@ -2890,7 +2900,7 @@ extern "C" int st5_gemm_tn_group(const st5_gemm_params* list, int32_t n, int dty
     } else {
       g.p[m] = p; g.tiles[m] = tiles; g.first[m] = (int)padded;
     }
-    padded += (tiles + 7) / 8 * 8;
+    padded += ph ? tiles : (tiles + 7) / 8 * 8;
     ++m;
   }
   return launch();
