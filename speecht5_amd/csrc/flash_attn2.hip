@@ -52,6 +52,22 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Block -> (tile index along x, batch x head) with the XCDs in mind (round 6).  Workgroups go to XCDs round-robin in linear order (x
+// fastest), so the 4 query (key) blocks of one head sat on 4 DIFFERENT XCDs and every private L2 fetched that head's K / V (Q / dO)
+// tiles through the fabric on its own.  Here the blocks of a head share an XCD: of every 8 * gridDim.x consecutive blocks, XCD k gets
+// the gridDim.x blocks of head 8 * group + k.  (BH not a multiple of 8: the plain mapping.)  Results do not depend on the mapping.
+__device__ __forceinline__ void block_coords(int& xb, int& bh) {
+  const int nx = (int)gridDim.x, ny = (int)gridDim.y;
+  if ((ny & 7) == 0) {
+    const int lin = (int)blockIdx.y * nx + (int)blockIdx.x;
+    const int per = 8 * nx, grp = lin / per, r = lin - grp * per;
+    bh = grp * 8 + (r & 7);
+    xb = r >> 3;
+  } else {
+    xb = (int)blockIdx.x; bh = (int)blockIdx.y;
+  }
+}
+
 // ---- LDS-DMA staging of one [64][64] bf16 tile: 8 wave-instructions of 8 rows, two per wave -------------------------
 // Lane l of instruction i (rows (i*4+wave)*8 .. +7) lands at physical chunk l&7 of row r = (i*4+wave)*8 + (l>>3) and
 // therefore fetches logical chunk (l&7) ^ ((r>>1)&7).  Rows past `nrows` are clamped to the last valid row (their scores
@@ -317,8 +333,10 @@ __global__ __launch_bounds__(256, 2) void fwd_kernel(const Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* scratch = smem + 4 * TILE_B + wave * SCR_B;
   const int ql = lane & 31, hi = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-  const int qblk = blockIdx.x * 128;
+  int xb_, bh;
+  block_coords(xb_, bh);
+  const int b = bh / a.H, h = bh % a.H;
+  const int qblk = xb_ * 128;
   const int qw0 = qblk + wave * 32;
   const int qi = qw0 + ql;
   const int qc = qi < a.T ? qi : a.T - 1;
@@ -580,8 +598,10 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const BwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* scratch = smem + 4 * TILE_B + wave * SCR_B;
   const int ql = lane & 31, hi = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-  const int qblk = blockIdx.x * 128;
+  int xb_, bh;
+  block_coords(xb_, bh);
+  const int b = bh / a.H, h = bh % a.H;
+  const int qblk = xb_ * 128;
   const int qw0 = qblk + wave * 32;
   const int qi = qw0 + ql;
   const int qc = qi < a.T ? qi : a.T - 1;
@@ -871,8 +891,10 @@ __global__ __launch_bounds__(256, 2) void bwd_dkv_kernel(const BwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* scratch = smem + 2 * QBUF_B + wave * KSCR_B;
   const int kl = lane & 31, hi = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-  const int kblk = blockIdx.x * 128;
+  int xb_, bh;
+  block_coords(xb_, bh);
+  const int b = bh / a.H, h = bh % a.H;
+  const int kblk = xb_ * 128;
   const int kw0 = kblk + wave * 32;
   const int ki = kw0 + kl;
   const int kc = ki < a.S ? ki : a.S - 1;
