@@ -1736,7 +1736,7 @@ __device__ __forceinline__ bf16x8 tr_frag_asm(const unsigned lds_addr) {
 // The block program of the TN kernels: block bx of nwg (tile index before the XCD remap), split by of ny, batch z.
 template <int FEAT>   // (epilogue features, see epilogue_fast; >= 0: fp32 output in the fast layout, compile-time feature set)
 __device__ __forceinline__ void tn_glds_body(const st5_gemm_params& p, const int c_vec_ok, const int bx, const int nwg_, const int by,
-                                             const int ny, const int z) {
+                                             const int ny, const int z, const bool remap = true) {
   typedef bf16_t T;
   constexpr int BK = 64;
   extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -1744,7 +1744,7 @@ __device__ __forceinline__ void tn_glds_body(const st5_gemm_params& p, const int
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_n = (p.N + BN - 1) / BN;
   int bid = bx;
-  {
+  if (remap) {     // (remap == false: the caller has placed this block with the XCDs in mind already, see gemm_tn_glds_kernel)
     const int nwg = nwg_, xcd = bid & 7, q = nwg >> 3, rmd = nwg & 7;
     bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
   }
@@ -1882,7 +1882,11 @@ __device__ __forceinline__ void tn_glds_body(const st5_gemm_params& p, const int
 #undef TN_WAIT
 #undef TN_MMA
   __syncthreads();
-  if (do_asum) { bool acc_; float* dst_ = asum_target(p, acc_); flush_asum(dst_, acc_, sum0, sum1, m0 + wr * 64, p.M, lane); }
+  if (do_asum) {   // (asum_target's rule with THIS block's split number: in place without split-K, else the split's column behind the slabs)
+    const bool acc_ = ny == 1;
+    float* dst_ = acc_ ? p.asum : reinterpret_cast<float*>(const_cast<void*>(p.C.ptr)) + (long long)ny * p.M * p.N + (long long)by * p.M;
+    flush_asum(dst_, acc_, sum0, sum1, m0 + wr * 64, p.M, lane);
+  }
 
   EpiArgs ea;
   ea.C = const_cast<void*>(p.C.ptr); ea.R = p.R.ptr; ea.P = p.P.ptr; ea.Cpre = const_cast<void*>(p.Cpre.ptr);
@@ -1913,7 +1917,22 @@ __device__ __forceinline__ void tn_glds_body(const st5_gemm_params& p, const int
 template <int FEAT>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_glds_kernel(const st5_gemm_params p, const int c_vec_ok) {
   ST5_PAD_TO_256_VGPRS();
-  tn_glds_body<FEAT>(p, c_vec_ok, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y, (int)blockIdx.z);
+  // Split-K grids (round 6): the XCD-aware placement runs over the WHOLE (tile, split) grid, split-major -- XCD x takes the x-th
+  // contiguous eighth of the list, i.e. most of the tiles of one or two splits, which share their k-range of BOTH operands.  The
+  // first form remapped the tile index alone: every XCD held an eighth of the tiles of EVERY split, and each private L2 fetched every
+  // split's operand panels for itself (the convolution weight gradients: 48 tiles x 5-8 splits; 182 MB through the fabric per launch).
+  // A (tile, split) pair's slab does not depend on where it ran: same bits.
+  const int nx = (int)gridDim.x, ny = (int)gridDim.y;
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  const bool placed = ny > 1 && gridDim.z == 1;
+  if (placed) {
+    const int total = nx * ny, lin = by * nx + bx;
+    const int xcd = lin & 7, q = total >> 3, rmd = total & 7;
+    const int pidx = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (lin >> 3);
+    by = pidx / nx;
+    bx = pidx - by * nx;
+  }
+  tn_glds_body<FEAT>(p, c_vec_ok, bx, nx, by, ny, (int)blockIdx.z, !placed);
 }
 
 // Several weight-gradient GEMMs in ONE launch, no split-K (st5_gemm_tn_group): the four (encoder) or six (decoder) weight gradients of a
