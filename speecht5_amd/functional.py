@@ -2537,19 +2537,29 @@ class Conv1dStridedFunction(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.zeros(B, Lin, Cin, dtype=dtype, device=dev)
-            Wk = _conv_w_fwd(w, dtype)
-            if k == 2 and s == 2:
-                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wk, k * Cin),
-                         hip.operand(dx, 2 * Cin, rpb=Lo, bstride=Lin * Cin), B * Lo, 2 * Cin, Cout, _dt(dtype),
-                         flags=hip.B_KSTRIDED)
+            # (round 6: the K-major cached weight forms of ConvFeatureExtractorFunction -- these data gradients, the layer-norm extractor's
+            #  of t5_transformer_large, ran on the register-staged general kernel with a k-strided B operand: 16 launches of ~400 us per
+            #  Large B = 32 update)
+            if os.environ.get("ST5_LNX_DGRAD_KMAJOR", "1") == "0":       # (A/B: the k-strided forms on the general kernel)
+                if k == 2 and s == 2:
+                    hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(_conv_w_fwd(w, dtype), k * Cin),
+                             hip.operand(dx, 2 * Cin, rpb=Lo, bstride=Lin * Cin), B * Lo, 2 * Cin, Cout, _dt(dtype), flags=hip.B_KSTRIDED)
+                else:
+                    We, Wo = _conv_w_even_odd(w, dtype)
+                    hip.gemm(hip.operand(dpre, Cout, rpb=Lo + 1, bstride=(Lo + 2) * Cout), hip.operand(We, Cin),
+                             hip.operand(dx, 2 * Cin, rpb=Lo + 1, bstride=Lin * Cin), B * (Lo + 1), Cin, 2 * Cout, _dt(dtype), flags=hip.B_KSTRIDED)
+                    hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wo, Cin),
+                             hip.operand(dx, 2 * Cin, off=Cin, rpb=Lo, bstride=Lin * Cin), B * Lo, Cin, Cout, _dt(dtype), flags=hip.B_KSTRIDED)
+            elif k == 2 and s == 2:
+                Wd = _conv_w_dgrad_k2(w, dtype)   # [2*Cin, Cout]
+                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wd, Cout),
+                         hip.operand(dx, 2 * Cin, rpb=Lo, bstride=Lin * Cin), B * Lo, 2 * Cin, Cout, _dt(dtype))
             elif k == 3 and s == 2:
-                We, Wo = _conv_w_even_odd(w, dtype)
-                hip.gemm(hip.operand(dpre, Cout, rpb=Lo + 1, bstride=(Lo + 2) * Cout), hip.operand(We, Cin),
-                         hip.operand(dx, 2 * Cin, rpb=Lo + 1, bstride=Lin * Cin), B * (Lo + 1), Cin, 2 * Cout, _dt(dtype),
-                         flags=hip.B_KSTRIDED)
-                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wo, Cin),
-                         hip.operand(dx, 2 * Cin, off=Cin, rpb=Lo, bstride=Lin * Cin), B * Lo, Cin, Cout, _dt(dtype),
-                         flags=hip.B_KSTRIDED)
+                Wet, Wot = _conv_w_even_odd_t(w, dtype)
+                hip.gemm(hip.operand(dpre, Cout, rpb=Lo + 1, bstride=(Lo + 2) * Cout), hip.operand(Wet, 2 * Cout),
+                         hip.operand(dx, 2 * Cin, rpb=Lo + 1, bstride=Lin * Cin), B * (Lo + 1), Cin, 2 * Cout, _dt(dtype))
+                hip.gemm(hip.operand(dpre, Cout, off=ioff, rpb=Lo, bstride=(Lo + 2) * Cout), hip.operand(Wot, Cout),
+                         hip.operand(dx, 2 * Cin, off=Cin, rpb=Lo, bstride=Lin * Cin), B * Lo, Cin, Cout, _dt(dtype))
             else:
                 raise NotImplementedError(f"conv feature layer (k={k}, stride={s}) backward")
         return dx, None, None, None, None

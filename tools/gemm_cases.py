@@ -39,6 +39,10 @@ def nt_cases():
             line += f" | {name} {t*1e6:6.1f}us {2*M*N*K/t/1e12:4.0f}TF"
         t = timeit(lambda: torch.matmul(A, B.t()))
         print(line + f" | hipblaslt {t*1e6:6.1f}us {2*M*N*K/t/1e12:4.0f}TF", flush=True)
+        if (M, N, K) in ((8192, 768, 3072), (8192, 3072, 768)):     # the two rows that have to beat the library
+            t_plain = timeit(cases[0][1])
+            verdict = "MET" if t_plain <= t else "NOT MET"
+            print(f"   asserted row {M}x{N}x{K}: plain {2*M*N*K/t_plain/1e12:4.0f} TF against hipBLASLt {2*M*N*K/t/1e12:4.0f} TF -- {verdict}", flush=True)
 
 
 def tn_cases():
