@@ -186,6 +186,14 @@ int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
  * a pre-LN layer in fp8 compute mode (transformer_layer.py:103-110,124-126 with `encoder_normalize_before`). */
 int st5_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* q, uint8_t* sc,
                          int64_t rows, int32_t cols, float eps, void* stream);
+/* y = GELU(LN(x) * gamma + beta) in ONE pass and its backward (dx, dgamma += , dbeta += from the gradient of the activated output; LN(x) is
+ * recomputed, nothing but x, mean, rstd is kept): the LayerNorm + GELU behind every convolution of the layer-norm feature extractor
+ * (t5_transformer_large: speech_encoder_prenet.py:318-331 with extractor_mode=layer_norm).  cols % 4 == 0, cols <= 512; bf16 uses the GELU
+ * polynomials of the GEMM epilogues, fp32 the exact erf form.  ws as st5_layernorm_bwd_ws_bytes(rows, cols). */
+int st5_layernorm_gelu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int32_t cols,
+                           float eps, int dtype, void* stream);
+int st5_layernorm_gelu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd, void* dx,
+                           float* dgamma, float* dbeta, void* ws, int64_t rows, int32_t cols, int dtype, void* stream);
 /* The LayerDrop gate folded into a post-LN layer's LAST LayerNorm (modules/encoder.py:251-257, modules/decoder.py:64-67 inside a
  * replayed step, see st5_select): forward  y = *keep ? LN(x) * gamma + beta : skip  (skip = the layer's input, same shape and dtype);
  * backward  as st5_layernorm_bwd with dy counted as zero when *keep == 0 (dx = 0, nothing added to dgamma / dbeta).  The gradient

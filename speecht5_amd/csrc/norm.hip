@@ -159,7 +159,9 @@ template <> __device__ __forceinline__ void store4f<bf16_t>(bf16_t* p, const flo
 // byte per 32 columns) -- the bytes st5_quant_mxfp8 produces from y, so the fp8 GEMMs that read a pre-LN layer's LayerNorm output (QKV,
 // fc1: models/speecht5.py:1402-1425 `encoder_normalize_before`) need no quantisation pass.  A lane holds 4 consecutive columns, 8
 // lanes one MX block (blocks start at multiples of 32 columns = 8 lanes).
-template <typename T, int NV, bool Q8 = false>
+// ACT (round 6; the layer-norm convolution extractor of t5_transformer_large, speech_encoder_prenet.py:318-331: LayerNorm + GELU behind every
+// convolution): y = GELU(LN(x)) in one pass -- the composition ran a LayerNorm pass and an activation pass over 2 GB at B = 32.
+template <typename T, int NV, bool Q8 = false, bool ACT = false>
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
@@ -218,6 +220,10 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = fmaf(v[r][i][e] * rs, g[i][e], b[i][e]);
+          if constexpr (ACT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = act_f<sizeof(T) == 2>(ACT_GELU, o[e]);
+          }
           if (dropped) load4f<T>(skip + ro + c, o);
           store4f<T>(y + ro + c, o);
           if constexpr (Q8) {
@@ -240,13 +246,15 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
 // dxd (optional): second output dx * dropout_mask(seed, row * cols + c) -- the gradient the Linear in front of this
 // LayerNorm needs when its output went through the fused dropout epilogue (y = residual + drop(x W^T + b); LN(y)),
 // produced here instead of by a separate dropout kernel over dx.
-template <typename T, int NV, bool PG>
+// ACTB: the forward was y = GELU(LN(x)) (ln_fwd_vec_kernel<.., ACT>): the incoming gradient is multiplied by GELU'(z), z = LN(x) recomputed
+// from x, mean, rstd, gamma and `beta` -- no pre-activation tensor is kept and no activation-backward pass runs.
+template <typename T, int NV, bool PG, bool ACTB = false>
 __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, T* __restrict__ dx,
                                                          float* __restrict__ part, long long rows, int cols,
                                                          T* __restrict__ dxd, float drop_p, unsigned long long seed,
-                                                         const float* __restrict__ keep) {
+                                                         const float* __restrict__ keep, const float* __restrict__ beta = nullptr) {
   // keep (LayerDrop gate, st5_layernorm_gated_bwd): *keep == 0 -> the incoming gradient counts as zero (dx = 0, no dgamma / dbeta)
   const bool dropped = keep != nullptr && *keep == 0.f;
   const unsigned int thresh = dxd ? dropout_thresh(drop_p) : 0u;
@@ -255,11 +263,16 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
   extern __shared__ float red[];   // PG: [4 waves][2][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float g[NV][4], dg[NV][4], db[NV][4];
+  float bb[ACTB ? NV : 1][4];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < cols) load4f<float>(gamma + c, g[i]);
     else { g[i][0] = g[i][1] = g[i][2] = g[i][3] = 0.f; }
+    if constexpr (ACTB) {
+      if (c < cols) load4f<float>(beta + c, bb[i]);
+      else { bb[i][0] = bb[i][1] = bb[i][2] = bb[i][3] = 0.f; }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
   }
@@ -308,7 +321,8 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = in ? (Elem<T>::to_f(S.xv[r][i].v[e]) - S.mu[r]) * S.rs[r] : 0.f;
-          const float d = (in && !dropped) ? Elem<T>::to_f(S.gv[r][i].v[e]) : 0.f;
+          float d = (in && !dropped) ? Elem<T>::to_f(S.gv[r][i].v[e]) : 0.f;
+          if constexpr (ACTB) d *= act_grad_f<sizeof(T) == 2>(ACT_GELU, fmaf(xh, g[i][e], bb[i][e]));
           if (PG && live) { dg[i][e] = fmaf(d, xh, dg[i][e]); db[i][e] += d; }
           const float gg = d * g[i][e];
           xh_[i][e] = xh; gg_[i][e] = gg;
@@ -604,6 +618,50 @@ extern "C" int st5_layernorm_fwd_q8(const void* x, const float* gamma, const flo
   if (cols <= 256) LNQ(1); else if (cols <= 512) LNQ(2); else if (cols <= 768) LNQ(3);
   else if (cols <= 1024) LNQ(4); else if (cols <= 1536) LNQ(6); else LNQ(8);
 #undef LNQ
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+/* y = GELU(LN(x) * gamma + beta) in one pass (cols % 4 == 0, cols <= 512: the layer-norm convolution extractor of t5_transformer_large,
+ * speech_encoder_prenet.py:318-331); mean / rstd as st5_layernorm_fwd.  The bf16 form uses the GELU polynomial of the GEMM epilogues. */
+extern "C" int st5_layernorm_gelu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                      int64_t rows, int32_t cols, float eps, int dtype, void* stream) {
+  if (!x || !y || !gamma || !beta || rows < 0 || cols <= 0 || cols % 4 || cols > 512) return ST5_ERR_ARG;
+  if (dtype != ST5_BF16 && dtype != ST5_F32) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 vgrid((unsigned)((rows + 4 * RPW - 1) / (4 * RPW)));
+#define LNA(TT, NV_)                                                                                                                      \
+  hipLaunchKernelGGL((ln_fwd_vec_kernel<TT, NV_, false, true>), vgrid, dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd,    \
+                     (long long)rows, cols, eps, (const float*)nullptr, (const TT*)nullptr, (unsigned char*)nullptr, (unsigned char*)nullptr)
+  if (dtype == ST5_BF16) { if (cols <= 256) LNA(bf16_t, 1); else LNA(bf16_t, 2); }
+  else { if (cols <= 256) LNA(float, 1); else LNA(float, 2); }
+#undef LNA
+  HIP_CHECK_LAUNCH();
+  return ST5_OK;
+}
+/* Backward of st5_layernorm_gelu_fwd: dx (and dgamma / dbeta accumulated, ws as st5_layernorm_bwd_ws_bytes says) from the gradient of
+ * the ACTIVATED output; the pre-activation LN(x) is recomputed from x, mean, rstd, gamma, beta. */
+extern "C" int st5_layernorm_gelu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                      void* dx, float* dgamma, float* dbeta, void* ws, int64_t rows, int32_t cols, int dtype, void* stream) {
+  if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || rows < 0 || cols <= 0 || cols % 4 || cols > 512) return ST5_ERR_ARG;
+  if ((dgamma || dbeta) && !ws) return ST5_ERR_ARG;
+  if (dtype != ST5_BF16 && dtype != ST5_F32) return ST5_ERR_ARG;
+  if (rows == 0) return ST5_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = ln_blocks(rows);
+  const bool pg = dgamma || dbeta;
+  const size_t shm = pg ? (size_t)8 * cols * sizeof(float) : 0;
+#define LBA(TT, NV_)                                                                                                                       \
+  do {                                                                                                                                     \
+    if (pg) hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, true, true>), dim3(nb), dim3(256), shm, s, (const TT*)dy, (const TT*)x, gamma,  \
+                               mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols, (TT*)nullptr, 0.f, 0ull, (const float*)nullptr, beta); \
+    else hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, false, true>), dim3(nb), dim3(256), 0, s, (const TT*)dy, (const TT*)x, gamma,      \
+                            mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols, (TT*)nullptr, 0.f, 0ull, (const float*)nullptr, beta); \
+  } while (0)
+  if (dtype == ST5_BF16) { if (cols <= 256) LBA(bf16_t, 1); else LBA(bf16_t, 2); }
+  else { if (cols <= 256) LBA(float, 1); else LBA(float, 2); }
+#undef LBA
+  if (pg) hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((2 * cols + 63) / 64), dim3(1024), 0, s, (const float*)ws, dgamma, dbeta, nb, cols);
   HIP_CHECK_LAUNCH();
   return ST5_OK;
 }

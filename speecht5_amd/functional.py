@@ -1488,6 +1488,51 @@ class LayerNormFunction(torch.autograd.Function):
         return (dx.view(xshape) if dx is not None else None), None, None, None, None, None
 
 
+class LayerNormGeluFunction(torch.autograd.Function):
+    """GELU(LayerNorm(x)) as one forward and one backward pass (st5_layernorm_gelu_fwd / _bwd): the layer-norm feature extractor of
+    t5_transformer_large (speech_encoder_prenet.py:318-331) ran LayerNorm and GELU as two passes each way over [B * T, 512] rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x2 = _rows(x)
+        rows, cols = x2.shape
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().st5_layernorm_gelu_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                   rstd.data_ptr(), rows, cols, eps, _dt(x), hip.stream()), "st5_layernorm_gelu_fwd")
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.meta = (weight, bias, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        weight, bias, xshape = ctx.meta
+        rows, cols = x2.shape
+        g = dy.contiguous().view(rows, cols)
+        L = hip.lib()
+        dx = torch.empty_like(x2)
+        gw = grad_buffer(weight) if weight.requires_grad else None
+        gb = grad_buffer(bias) if bias.requires_grad else None
+        ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows, cols), x2.device)
+        hip.check(L.st5_layernorm_gelu_bwd(g.data_ptr(), x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           dx.data_ptr(), hip.ptr(gw), hip.ptr(gb), ws.data_ptr(), rows, cols, _dt(x2), hip.stream()),
+                  "st5_layernorm_gelu_bwd")
+        if gw is not None:
+            _grad_done(weight)
+        if gb is not None:
+            _grad_done(bias)
+        return dx.view(xshape), None, None, None
+
+
+def layer_norm_gelu(x, weight, bias, eps=1e-5):
+    """GELU(LayerNorm(x)); one fused pass each way when the row width allows (<= 512, a multiple of 4), else the composition."""
+    if x.shape[-1] % 4 == 0 and x.shape[-1] <= 512 and os.environ.get("ST5_LN_GELU_FUSED", "1") != "0":
+        return LayerNormGeluFunction.apply(x.contiguous(), weight, bias, float(eps))
+    return activation(layer_norm(x, weight, bias, eps), ACT_GELU)
+
+
 def layer_norm(x, weight, bias, eps=1e-5, gate=None, q8=False):
     """q8: the output's consumer is a Linear that may run on the fp8 GEMM (a pre-LN layer's QKV projection / fc1): in fp8 compute mode
     the kernel then writes the output's MX-fp8 image beside it (st5_layernorm_fwd_q8) and that Linear launches no quantiser."""
@@ -2574,7 +2619,7 @@ def conv_feature_extractor_layer_norm(wav, layers, gscale, params):
             x = Conv0UnfoldFunction.apply(wav, w, b, k, s)
         else:
             x = Conv1dStridedFunction.apply(x, w, b, k, s)
-        x = activation(layer_norm(x, lw, lb), ACT_GELU)
+        x = layer_norm_gelu(x, lw, lb)
     if gscale != 1.0:
         x = GradScaleFunction.apply(x, float(gscale))
     return x

@@ -207,6 +207,38 @@ def test_gemm_dact_and_dropout(cuda, dtype):
     assert torch.equal((Y != 0), (C1 != 0)) or ((Y != 0) ^ (C1 != 0)).float().mean().item() < 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(3001, 512), (70, 256), (5, 64)])
+def test_layernorm_gelu_one_pass_against_torch(cuda, dtype, rows, cols):
+    """Round 6 (st5_layernorm_gelu_fwd / _bwd: the layer-norm convolution extractor of t5_transformer_large): GELU(LayerNorm(x)) and its
+    backward -- dx, dgamma, dbeta ACCUMULATED into non-zero buffers -- against torch fp64 autograd on the same (rounded) inputs."""
+    torch.manual_seed(rows + cols)
+    X = dev(torch.randn(rows, cols) * 1.7 + 0.3, dtype, cuda)
+    DY = dev(torch.randn(rows, cols), dtype, cuda)
+    G = (torch.randn(cols) * 0.4 + 1.0).to(cuda); Bt = (torch.randn(cols) * 0.3).to(cuda)
+    L = hip.lib()
+    Y = torch.empty_like(X); DX = torch.empty_like(X)
+    mean = torch.empty(rows, device=cuda); rstd = torch.empty(rows, device=cuda)
+    dG = torch.full((cols,), 0.5, device=cuda); dB = torch.full((cols,), -0.25, device=cuda)
+    ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows, cols), cuda)
+    hip.check(L.st5_layernorm_gelu_fwd(X.data_ptr(), G.data_ptr(), Bt.data_ptr(), Y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, cols,
+                                       1e-5, hip.dt(dtype), hip.stream()), "st5_layernorm_gelu_fwd")
+    hip.check(L.st5_layernorm_gelu_bwd(DY.data_ptr(), X.data_ptr(), G.data_ptr(), Bt.data_ptr(), mean.data_ptr(), rstd.data_ptr(), DX.data_ptr(),
+                                       dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), rows, cols, hip.dt(dtype), hip.stream()), "st5_layernorm_gelu_bwd")
+    torch.cuda.synchronize()
+    x = X.double().requires_grad_(True); g = G.double().requires_grad_(True); b = Bt.double().requires_grad_(True)
+    y = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x, (cols,), g, b, 1e-5))
+    y.backward(DY.double())
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    def close(a, r, what, t=tol):
+        err = float((a.double() - r).abs().max()) / max(float(r.abs().max()), 1e-6)
+        assert err <= t, (what, err)
+    close(Y, y.detach(), "y")
+    close(DX, x.grad, "dx")
+    close(dG - 0.5, g.grad, "dgamma", tol * 4)
+    close(dB + 0.25, b.grad, "dbeta", tol * 4)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("keep", [1.0, 0.0])
 def test_layernorm_gated_by_a_layerdrop_flag(cuda, dtype, keep):
