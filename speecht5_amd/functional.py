@@ -104,6 +104,40 @@ class HostStaging:
         self.mode = None          # None | "record" | "capture"
         self.entries = []         # [dev, pinned, producer]
         self.i = 0
+        self.block = None         # (device block, [pinned image 0, pinned image 1]) once pack() has run
+        self.packed = set()       # ids of the entries that live inside the block
+
+    def pack(self):
+        """ONE device block and one pinned image (per slot) for all staged inputs, the entries re-pointed at 256-byte-aligned views of
+        them -- before the step is captured, so that the captured kernels read the views' addresses.  upload() is then a single copy:
+        the benched update stages ~55 small tensors (span masks, LayerDrop flags, time-mix draws, temperatures ...), and 55 separate
+        4-us blit kernels in front of every replay were 0.3-0.4 ms of an otherwise idle GPU per update (round 6)."""
+        ents = [e for e in self.entries if e[0] is not None and id(e) not in self.packed]
+        if not ents or self.block is not None or os.environ.get("ST5_STAGING_PACK", "1") == "0":
+            return
+        dev = ents[0][0].device
+        offs, tot = [], 0
+        for e in ents:
+            offs.append(tot)
+            tot += (e[0].numel() * e[0].element_size() + 255) // 256 * 256
+        D = torch.zeros(max(tot, 256), dtype=torch.uint8, device=dev)
+        H = [torch.zeros(max(tot, 256), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        for e, off in zip(ents, offs):
+            nb, dt, shp = e[0].numel() * e[0].element_size(), e[0].dtype, e[0].shape
+            view = lambda buf: buf[off:off + nb].view(dt).view(shp)
+            h0, h1 = view(H[0]), view(H[1])
+            h0.copy_(e[1])
+            if len(e) == 4:
+                h1.copy_(e[3])
+            d = view(D)
+            d.copy_(e[0])
+            e[0], e[1] = d, h0
+            if len(e) == 3:
+                e.append(h1)
+            else:
+                e[3] = h1
+            self.packed.add(id(e))
+        self.block = (D, H)
 
     def begin_step(self, mode):
         if mode == "record" and self.entries and torch.cuda.is_available():
@@ -170,8 +204,10 @@ class HostStaging:
             (e[3] if slot else e[1]).copy_(h)
 
     def upload(self, slot):
+        if self.block is not None:
+            self.block[0].copy_(self.block[1][slot], non_blocking=True)
         for e in self.entries:
-            if e[0] is not None:
+            if e[0] is not None and id(e) not in self.packed:
                 e[0].copy_(e[3] if slot else e[1], non_blocking=True)
 
     def ensure_second_images(self):
@@ -2568,8 +2604,15 @@ class Conv1dStridedFunction(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         w, bias, k, s, B, Lin, Cin, Cout, Lo = ctx.meta
         dtype, dev = dy.dtype, dy.device
-        dpre = torch.zeros(B, Lo + 2, Cout, dtype=dtype, device=dev)   # one zero row each side (k = 3 even phase)
-        dpre[:, 1:-1] = dy
+        # one zero row each side (k = 3 even phase) in ONE pass (was a zero fill of the whole buffer + a strided torch copy)
+        dyc = dy.contiguous()
+        onepass = os.environ.get("ST5_LNX_ONEPASS", "1") != "0"      # (A/B)
+        if onepass:
+            dpre = torch.empty(B, Lo + 2, Cout, dtype=dtype, device=dev)
+            hip.check(hip.lib().st5_pad_time(dyc.data_ptr(), dpre.data_ptr(), B, Lo, Cout, 1, 1, _dt(dtype), hip.stream()), "st5_pad_time")
+        else:
+            dpre = torch.zeros(B, Lo + 2, Cout, dtype=dtype, device=dev)
+            dpre[:, 1:-1] = dy
         ioff = Cout
         want_db = bias is not None and bias.requires_grad
         if w.requires_grad:
@@ -2577,11 +2620,15 @@ class Conv1dStridedFunction(torch.autograd.Function):
                         hip.operand(x, s * Cin, rpb=Lo, bstride=Lin * Cin), Cout, k, Cin, B * Lo, _dt(dtype), (dpre, x))
             _grad_done(w)
         if want_db:
-            _colsum_into(dy.contiguous().view(B * Lo, Cout), Cout, Cout, grad_buffer(bias))
+            _colsum_into(dyc.view(B * Lo, Cout), Cout, Cout, grad_buffer(bias))
             _grad_done(bias)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.zeros(B, Lin, Cin, dtype=dtype, device=dev)
+            # the GEMMs below write rows 0 .. covered - 1 of every utterance; only the uncovered tail rows are zero-filled
+            dx = torch.empty(B, Lin, Cin, dtype=dtype, device=dev) if onepass else torch.zeros(B, Lin, Cin, dtype=dtype, device=dev)
+            covered = 2 * Lo if k == 2 else 2 * Lo + 1
+            if onepass and covered < Lin:
+                hip.check(hip.lib().st5_zero_time_edges(dx.data_ptr(), B, Lin, Cin, 0, covered, _dt(dtype), hip.stream()), "st5_zero_time_edges")
             # (round 6: the K-major cached weight forms of ConvFeatureExtractorFunction -- these data gradients, the layer-norm extractor's
             #  of t5_transformer_large, ran on the register-staged general kernel with a k-strided B operand: 16 launches of ~400 us per
             #  Large B = 32 update)

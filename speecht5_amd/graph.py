@@ -110,6 +110,7 @@ class StepGraph:
 
     def capture(self):
         torch.cuda.synchronize(self.device)
+        self.staging.pack()      # (all staged inputs in one block: one upload per replay instead of one per tensor)
         with torch.cuda.stream(self.stream):
             self._pre_replay()
         torch.cuda.synchronize(self.device)
