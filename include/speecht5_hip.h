@@ -186,6 +186,11 @@ int st5_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
  * a pre-LN layer in fp8 compute mode (transformer_layer.py:103-110,124-126 with `encoder_normalize_before`). */
 int st5_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, void* q, uint8_t* sc,
                          int64_t rows, int32_t cols, float eps, void* stream);
+/* st5_layernorm_bwd whose dx also receives `addend` (dx = LayerNorm backward + addend; same shape / dtype as dx, cols % 4 == 0, cols <= 2048):
+ * the gradient of a pre-LN block's residual connection (transformer_layer.py:90-111 with layer_norm_first: y = x + f(LN(x))) folded into
+ * the LayerNorm backward at the block's input instead of an autograd accumulation kernel. */
+int st5_layernorm_bwd_add(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                          float* dbeta, void* ws, int64_t rows, int32_t cols, const void* addend, int dtype, void* stream);
 /* y = GELU(LN(x) * gamma + beta) in ONE pass and its backward (dx, dgamma += , dbeta += from the gradient of the activated output; LN(x) is
  * recomputed, nothing but x, mean, rstd is kept): the LayerNorm + GELU behind every convolution of the layer-norm feature extractor
  * (t5_transformer_large: speech_encoder_prenet.py:318-331 with extractor_mode=layer_norm).  cols % 4 == 0, cols <= 512; bf16 uses the GELU

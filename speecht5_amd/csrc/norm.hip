@@ -254,7 +254,10 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
                                                          const float* __restrict__ rstd, T* __restrict__ dx,
                                                          float* __restrict__ part, long long rows, int cols,
                                                          T* __restrict__ dxd, float drop_p, unsigned long long seed,
-                                                         const float* __restrict__ keep, const float* __restrict__ beta = nullptr) {
+                                                         const float* __restrict__ keep, const float* __restrict__ beta = nullptr,
+                                                         const T* __restrict__ addend = nullptr) {
+  // addend (st5_layernorm_bwd_add, round 6): dx = LayerNorm backward + addend -- the gradient of a pre-LN block's residual connection
+  // (y = x + f(LN(x))), handed over by the Linear that added the residual, so that autograd does not sum the two with a kernel of its own
   // keep (LayerDrop gate, st5_layernorm_gated_bwd): *keep == 0 -> the incoming gradient counts as zero (dx = 0, no dgamma / dbeta)
   const bool dropped = keep != nullptr && *keep == 0.f;
   const unsigned int thresh = dxd ? dropout_thresh(drop_p) : 0u;
@@ -340,6 +343,12 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ d
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = S.rs[r] * (gg_[i][e] - s1 - xh_[i][e] * s2);
+            if (addend) {
+              float a4[4];
+              load4f<T>(addend + ro + c, a4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] += a4[e];
+            }
             store4f<T>(dx + ro + c, o);
             if (dxd) {
               float dsc[4];
@@ -679,7 +688,9 @@ extern "C" int64_t st5_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols) {
 
 static int layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                          const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t rows,
-                         int32_t cols, void* dx_dropped, float drop_p, uint64_t drop_seed, int dtype, void* stream, const float* keep) {
+                         int32_t cols, void* dx_dropped, float drop_p, uint64_t drop_seed, int dtype, void* stream, const float* keep,
+                         const void* addend = nullptr) {
+  if (addend && (!dx || cols % 4 || cols > 2048)) return ST5_ERR_ARG;
   if (keep && (!dx || cols % 4 || cols > 2048)) return ST5_ERR_ARG;
   if (dx_dropped && (!dx || cols % 4 || cols > 2048 || drop_p <= 0.f || drop_p >= 1.f)) return ST5_ERR_ARG;
   if (!dy || !x || !gamma || !mean || !rstd || rows < 0 || cols <= 0 || cols > MAXCH * 512) return ST5_ERR_ARG;
@@ -723,10 +734,10 @@ static int layernorm_bwd(const void* dy, const void* x, const float* gamma, cons
   do {                                                                                                                  \
     if (pg) hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, true>), dim3(nb), dim3(256), shm, s, (const TT*)dy, (const TT*)x, gamma, \
                                mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols, (TT*)dx_dropped, drop_p,          \
-                               (unsigned long long)drop_seed, keep);                                                    \
+                               (unsigned long long)drop_seed, keep, (const float*)nullptr, (const TT*)addend);          \
     else hipLaunchKernelGGL((ln_bwd_vec_kernel<TT, NV_, false>), dim3(nb), dim3(256), 0, s, (const TT*)dy, (const TT*)x, gamma, \
                             mean, rstd, (TT*)dx, (float*)ws, (long long)rows, cols, (TT*)dx_dropped, drop_p,            \
-                            (unsigned long long)drop_seed, keep);                                                       \
+                            (unsigned long long)drop_seed, keep, (const float*)nullptr, (const TT*)addend);             \
   } while (0)
 #define LBV_T(TT)                                                                                                     \
   do {                                                                                                                \
@@ -771,6 +782,13 @@ extern "C" int st5_layernorm_bwd(const void* dy, const void* x, const float* gam
                                  const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t rows,
                                  int32_t cols, void* dx_dropped, float drop_p, uint64_t drop_seed, int dtype, void* stream) {
   return layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, dx_dropped, drop_p, drop_seed, dtype, stream, nullptr);
+}
+/* st5_layernorm_bwd with dx = (LayerNorm backward) + addend (same shape and dtype as dx; cols % 4 == 0, cols <= 2048): the residual gradient of a
+ * pre-LN block folded into the LayerNorm backward at the block's input. */
+extern "C" int st5_layernorm_bwd_add(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                                     float* dgamma, float* dbeta, void* ws, int64_t rows, int32_t cols, const void* addend, int dtype, void* stream) {
+  if (!addend) return ST5_ERR_ARG;
+  return layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, nullptr, 0.f, 0, dtype, stream, nullptr, addend);
 }
 extern "C" int st5_layernorm_gated_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                        const float* rstd, void* dx, float* dgamma, float* dbeta, void* ws, int64_t rows,

@@ -1205,7 +1205,7 @@ class _RelayedResidual:
 # -------------------------------------------------------------------------------------------------
 class FFNFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, w1, b1, w2, b2, act, p_act, p_out):
+    def forward(ctx, x, residual, w1, b1, w2, b2, act, p_act, p_out, relay_out=None):
         dtype = x.dtype
         x2 = _rows(x)
         M, d = x2.shape
@@ -1228,6 +1228,7 @@ class FFNFunction(torch.autograd.Function):
             _tag_dropout_output(y, p_out, s2, M, w2.shape[0])
         ctx.save_for_backward(x2, h, hpre, W1, W2)
         ctx.meta = (w1, b1, w2, b2, act, p_act, p_out, s1, s2, x.shape, residual is not None and not res_is_x, res_is_x)
+        ctx.relay_out = relay_out if (residual is not None and not res_is_x) else None
         return y.view(x.shape[:-1] + (w2.shape[0],))
 
     @staticmethod
@@ -1240,6 +1241,9 @@ class FFNFunction(torch.autograd.Function):
         g = dy.contiguous().view(M, dout)
         g_in = g
         d_res = dy if has_res else None
+        if ctx.relay_out is not None:      # (pre-LN block: the residual's gradient goes to the LayerNorm that opened the block)
+            ctx.relay_out.grad = g
+            d_res = None
         if p_out > 0:
             g = _dropped_grad(g, p_out, s2)
         # dHpre = (G . W2) * act'(Hpre) [* activation-dropout mask]   (fused epilogue)
@@ -1270,13 +1274,17 @@ class FFNFunction(torch.autograd.Function):
             _colsum_into(dh, Fd, Fd, grad_buffer(b1))
         if b1.requires_grad:
             _grad_done(b1)
-        return dx, d_res, None, None, None, None, None, None, None
+        return dx, d_res, None, None, None, None, None, None, None, None
 
 
-def ffn(x, residual, fc1, fc2, act=ACT_GELU, p_act=0.0, p_out=0.0):
+def ffn(x, residual, fc1, fc2, act=ACT_GELU, p_act=0.0, p_out=0.0, relay_out=None):
+    """relay_out (GradRelay): hand the residual's gradient to the relay (the LayerNorm that opened this pre-LN block adds it to its dX)
+    instead of returning it to autograd."""
     xc = x.contiguous()
     if residual is x and fc2.weight.shape[0] == x.shape[-1]:
         residual = "x"
+    if relay_out is not None and isinstance(residual, torch.Tensor):
+        return FFNFunction.apply(xc, residual.detach(), fc1.weight, fc1.bias, fc2.weight, fc2.bias, act, float(p_act), float(p_out), relay_out)
     return FFNFunction.apply(xc, residual, fc1.weight, fc1.bias, fc2.weight, fc2.bias, act, float(p_act), float(p_out))
 
 
@@ -1456,7 +1464,7 @@ def guided_attention_loss(att, ilens, olens, sigma, alpha):
 # -------------------------------------------------------------------------------------------------
 class LayerNormFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, gate=None, q8=False):
+    def forward(ctx, x, weight, bias, eps, gate=None, q8=False, relay=None):
         x2 = _rows(x)
         rows, cols = x2.shape
         y = torch.empty_like(x2)
@@ -1485,6 +1493,7 @@ class LayerNormFunction(torch.autograd.Function):
         ctx.save_for_backward(x2, mean, rstd)
         ctx.meta = (weight, bias, x.shape, tag)
         ctx.gate = gate
+        ctx.relay = relay
         return y.view(x.shape)
 
     @staticmethod
@@ -1505,7 +1514,17 @@ class LayerNormFunction(torch.autograd.Function):
         gb = grad_buffer(bias) if bias.requires_grad else None
         ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows, cols), x2.device)
         gate = ctx.gate
-        if gate is None:
+        relay, addend = ctx.relay, None
+        if relay is not None and relay.grad is not None:
+            # a pre-LN block's residual gradient (handed over by the Linear / FFN that added the residual, earlier in this backward pass)
+            addend, relay.grad = relay.grad, None
+        if addend is not None and gate is None and dx is not None and dxd is None:
+            assert addend.shape == (rows, cols) and addend.dtype == x2.dtype and addend.is_contiguous()
+            hip.check(L.st5_layernorm_bwd_add(g.data_ptr(), x2.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                              hip.ptr(gw), hip.ptr(gb), ws.data_ptr(), rows, cols, addend.data_ptr(), _dt(x2), hip.stream()),
+                      "st5_layernorm_bwd_add")
+            addend = None
+        elif gate is None:
             hip.check(L.st5_layernorm_bwd(g.data_ptr(), x2.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                           hip.ptr(dx), hip.ptr(gw), hip.ptr(gb), ws.data_ptr(), rows, cols, hip.ptr(dxd),
                                           tag[0] if dxd is not None else 0.0, tag[1] if dxd is not None else 0, _dt(x2),
@@ -1521,7 +1540,10 @@ class LayerNormFunction(torch.autograd.Function):
             _grad_done(weight)
         if gb is not None:
             _grad_done(bias)
-        return (dx.view(xshape) if dx is not None else None), None, None, None, None, None
+        if addend is not None:      # (a form the fused kernel does not cover: add it here, as autograd would have)
+            assert dx is not None, "a relayed residual gradient reached a LayerNorm whose input needs no gradient"
+            dx = dx + addend
+        return (dx.view(xshape) if dx is not None else None), None, None, None, None, None, None
 
 
 class LayerNormGeluFunction(torch.autograd.Function):
@@ -1569,14 +1591,16 @@ def layer_norm_gelu(x, weight, bias, eps=1e-5):
     return activation(layer_norm(x, weight, bias, eps), ACT_GELU)
 
 
-def layer_norm(x, weight, bias, eps=1e-5, gate=None, q8=False):
+def layer_norm(x, weight, bias, eps=1e-5, gate=None, q8=False, relay=None):
     """q8: the output's consumer is a Linear that may run on the fp8 GEMM (a pre-LN layer's QKV projection / fc1): in fp8 compute mode
-    the kernel then writes the output's MX-fp8 image beside it (st5_layernorm_fwd_q8) and that Linear launches no quantiser."""
+    the kernel then writes the output's MX-fp8 image beside it (st5_layernorm_fwd_q8) and that Linear launches no quantiser.
+    relay (GradRelay): this LayerNorm opens a pre-LN block y = x + f(LN(x)); the Linear / FFN that adds the residual hands dY to the relay
+    and this function's backward adds it to dX inside its kernel (st5_layernorm_bwd_add) -- no autograd accumulation kernel."""
     if gate is not None:
         gate.used = True
         return LayerNormFunction.apply(x.contiguous(), weight, bias, float(eps), gate)
-    if q8 and _FP8.enabled:
-        return LayerNormFunction.apply(x.contiguous(), weight, bias, float(eps), None, True)
+    if relay is not None or (q8 and _FP8.enabled):
+        return LayerNormFunction.apply(x.contiguous(), weight, bias, float(eps), None, bool(q8 and _FP8.enabled), relay)
     return LayerNormFunction.apply(x.contiguous(), weight, bias, float(eps))
 
 

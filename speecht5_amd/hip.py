@@ -90,6 +90,8 @@ _SIGS = {
     "st5_quant_mxfp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     "st5_multi_quant_mxfp8": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "st5_gemm_mxfp8_q": (c_int, [POINTER(GemmParams), c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "st5_layernorm_bwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                      c_void_p, c_int, c_void_p]),
     "st5_layernorm_gelu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_int, c_void_p]),
     "st5_layernorm_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int64, c_int32, c_int, c_void_p]),

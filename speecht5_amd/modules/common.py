@@ -17,8 +17,8 @@ class LayerNorm(nn.Module):
         self.eps = eps
         self.normalized_shape = (dim,)
 
-    def forward(self, x, gate=None, q8=False):
-        return Fn.layer_norm(x, self.weight, self.bias, self.eps, gate=gate, q8=q8)
+    def forward(self, x, gate=None, q8=False, relay=None):
+        return Fn.layer_norm(x, self.weight, self.bias, self.eps, gate=gate, q8=q8, relay=relay)
 
 
 def tbc_to_rows(x):

@@ -75,7 +75,7 @@ class MultiheadAttention(nn.Module, IncrementalState):
 
     # ---- batch-major row interface used by the layer mirrors (no layout copies) ----
     def forward_rows(self, x, B, T, *, kv=None, S=None, key_padding_mask=None, causal=False, position_bias=None,
-                     residual=None, out_dropout=0.0, need_weights=False, kv_all=None):
+                     residual=None, out_dropout=0.0, need_weights=False, kv_all=None, res_relay=None):
         """x [B*T, C] rows (query source); kv [B*S, C] rows (cross-attention source) or None for self-attention.
         Returns (out rows [B*T, C] = dropout(out_proj(attn)) + residual, probs [B,H,T,S] fp32 or None)."""
         H, hd = self.num_heads, self.head_dim
@@ -104,7 +104,7 @@ class MultiheadAttention(nn.Module, IncrementalState):
                 kvp = Fn.linear(kv, [self.k_proj.weight, self.v_proj.weight], [self.k_proj.bias, self.v_proj.bias])
                 ctx, probs = Fn.CrossAttentionFunction.apply(q, kvp, kpm, (B, H, T, S, hd, p, need_weights))
         out = Fn.linear(ctx, self.out_proj.weight, self.out_proj.bias, residual=residual,
-                        dropout_p=out_dropout if self.training else 0.0, relay_out=relay)
+                        dropout_p=out_dropout if self.training else 0.0, relay_out=relay if relay is not None else res_relay)
         return out, probs
 
     # ---- incremental decoding (multihead_attention.py:269-307 of the reference: saved_state prev_key / prev_value) ----

@@ -208,6 +208,35 @@ def test_gemm_dact_and_dropout(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(2100, 1024), (333, 768), (9, 64)])
+def test_layernorm_backward_with_residual_addend(cuda, dtype, rows, cols):
+    """Round 6 (st5_layernorm_bwd_add: the residual gradient of a pre-LN block folded into the LayerNorm backward): dx == the plain
+    backward's dx + addend up to ONE rounding of the sum (the fused form adds in fp32 before it rounds), dgamma / dbeta bit-identical."""
+    torch.manual_seed(rows)
+    X, DY, AD = dev(torch.randn(rows, cols) * 2 + 0.5, dtype, cuda), dev(torch.randn(rows, cols), dtype, cuda), dev(torch.randn(rows, cols), dtype, cuda)
+    G = torch.randn(cols).to(cuda)
+    L = hip.lib()
+    mean = X.float().mean(1).contiguous(); rstd = (X.float().var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    outs = []
+    for fused in (False, True):
+        DX = torch.empty_like(X)
+        dG = torch.ones(cols, device=cuda); dB = torch.ones(cols, device=cuda)
+        ws = hip.workspace(L.st5_layernorm_bwd_ws_bytes(rows, cols), cuda)
+        if fused:
+            hip.check(L.st5_layernorm_bwd_add(DY.data_ptr(), X.data_ptr(), G.data_ptr(), mean.data_ptr(), rstd.data_ptr(), DX.data_ptr(), dG.data_ptr(),
+                                              dB.data_ptr(), ws.data_ptr(), rows, cols, AD.data_ptr(), hip.dt(dtype), hip.stream()), "bwd add")
+        else:
+            hip.check(L.st5_layernorm_bwd(DY.data_ptr(), X.data_ptr(), G.data_ptr(), mean.data_ptr(), rstd.data_ptr(), DX.data_ptr(), dG.data_ptr(),
+                                          dB.data_ptr(), ws.data_ptr(), rows, cols, None, 0.0, 0, hip.dt(dtype), hip.stream()), "bwd")
+        torch.cuda.synchronize()
+        outs.append((DX, dG, dB))
+    want = outs[0][0].float() + AD.float()
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert float((outs[1][0].float() - want).abs().max()) <= tol * float(want.abs().max())
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,cols", [(3001, 512), (70, 256), (5, 64)])
 def test_layernorm_gelu_one_pass_against_torch(cuda, dtype, rows, cols):
     """Round 6 (st5_layernorm_gelu_fwd / _bwd: the layer-norm convolution extractor of t5_transformer_large): GELU(LayerNorm(x)) and its
