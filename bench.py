@@ -355,6 +355,8 @@ def main():
         hip.lib().st5_gemm_set_nt_tile(int(os.environ["ST5_NT_TILE"]))
     if os.environ.get("ST5_DEEP_RING"):   # A/B: "max_blocks,nbuf" of the 128x128 NT kernel's deep operand ring (nbuf 2 = off)
         hip.lib().st5_gemm_set_deep_ring(*[int(v) for v in os.environ["ST5_DEEP_RING"].split(",")])
+    if os.environ.get("ST5_NT_LONGK"):       # A/B: "tiles,nk" -- long-reduction NT problems of >= tiles 256x256 tiles on the phased kernel
+        hip.lib().st5_gemm_set_nt_longk(*[int(v) for v in os.environ["ST5_NT_LONGK"].split(",")])
     if os.environ.get("ST5_MX8_HEAVY_NK"):   # A/B (fp8 mode): k-tiles an epilogue-heavy fp8 GEMM needs before it takes the phased 256x256 kernel
         hip.lib().st5_gemm_set_mx8_heavy_nk(int(os.environ["ST5_MX8_HEAVY_NK"]))
     if os.environ.get("ST5_MX8_TILE"):       # A/B (fp8 mode): 1 = 128x128 always, 2 = phased 256x256 always

@@ -106,6 +106,9 @@ int st5_gemm_set_nt_tile(int mode);
  * (round 6: the transformer's Linear GEMMs at 8 utterances per GPU -- modules/transformer_layer.py:127-131, multihead_attention.py:213-231 --
  * are 0.25-3 rounds of 128x128 tiles); 0 = never.  Results are bit-identical for every choice. */
 int st5_gemm_set_m64_max_tiles(int tiles);
+/* (A/B) bf16 NT GEMMs of at least `tiles` tiles of 256x256 with at least `nk` k-tiles of 64 also run on the phased 256x256 kernel (the
+ * N = 768 long-reduction shapes: one block on 96 CUs instead of 384 tiles of 128x128 on all of them); tiles = 0: off (default). */
+int st5_gemm_set_nt_longk(int tiles, int nk);
 /* Block count the split-K choice of the fp32-output (weight-gradient) GEMMs aims for; default 384 (1.5 per CU). */
 int st5_gemm_set_splitk_target(int blocks);
 /* Weight-gradient (TN form, no row split / segments) GEMMs: 0 (default) = always the 128x128 LDS-DMA kernel; 1 = phased 256x256 kernel with

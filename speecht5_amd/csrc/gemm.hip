@@ -2272,9 +2272,14 @@ bool tn_glds_ok(const st5_gemm_params& p, int dtype) {
 // problems (8192^3: 1.20 against 0.89) -- or when ONE round of 256^2 tiles nearly fills the chip with a short reduction (3992 x 3072 x
 // 768: 192 tiles, 27.8 against 30.6 us).  Everything else of the transformer (96-384 tiles in 1.1-2 rounds, or long K on few tiles)
 // stays on 128^2, two blocks per CU.
+// (A/B knob, round 6, st5_gemm_set_nt_longk: problems of at least `g_nt_longk_tiles` tiles of 256^2 with a reduction of at least
+//  `g_nt_longk_nk` k-tiles also take the phased kernel -- the N = 768, K = 2304 / 3072 shapes at 8192 rows are 96 tiles: one block on 96
+//  CUs for 36-48 k-tiles instead of 384 tiles of 128^2 on every CU.  0 = off, the default.)
+int g_nt_longk_tiles = 0, g_nt_longk_nk = 36;
 bool nt256_pays(int M, int N, int nk64, int batch) {
   const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
   if (t256 >= 448) return true;
+  if (g_nt_longk_tiles > 0 && t256 >= g_nt_longk_tiles && nk64 >= g_nt_longk_nk) return true;
   return t256 >= 176 && t256 <= 256 && nk64 <= 16;
 }
 
@@ -3074,4 +3079,5 @@ extern "C" int st5_gemm_set_nt_tile(int mode) { if (mode < 0 || mode > 5) return
 extern "C" int st5_gemm_set_mx8_tile(int mode) { if (mode < 0 || mode > 2) return ST5_ERR_ARG; g_mx8_tile = mode; return ST5_OK; }
 /* (A/B) k-tiles of 128 an epilogue-heavy fp8 GEMM needs before the per-problem choice takes the phased 256x256 kernel; default 16, 0 = always. */
 extern "C" int st5_gemm_set_mx8_heavy_nk(int nk) { if (nk < 0) return ST5_ERR_ARG; g_mx8_heavy_nk = nk; return ST5_OK; }
+extern "C" int st5_gemm_set_nt_longk(int tiles, int nk) { if (tiles < 0 || nk < 1) return ST5_ERR_ARG; g_nt_longk_tiles = tiles; g_nt_longk_nk = nk; return ST5_OK; }
 extern "C" int st5_gemm_set_m64_max_tiles(int tiles) { if (tiles < 0) return ST5_ERR_ARG; g_m64_max_tiles = tiles; return ST5_OK; }

@@ -45,6 +45,7 @@ _SIGS = {
     "st5_stream_fork": (c_int, [c_void_p, c_void_p]),
     "st5_gemm_set_nt_tile": (c_int, [c_int]),
     "st5_gemm_set_m64_max_tiles": (c_int, [c_int]),
+    "st5_gemm_set_nt_longk": (c_int, [c_int, c_int]),
     "st5_gemm_set_mx8_tile": (c_int, [c_int]),
     "st5_gemm_set_mx8_heavy_nk": (c_int, [c_int]),
     "st5_gemm_set_tn_group_tile": (c_int, [c_int]),
