@@ -13,6 +13,7 @@ import math
 from types import SimpleNamespace
 
 import os
+import threading
 
 import torch
 
@@ -603,16 +604,19 @@ fp8_mirror = _Fp8Mirror()
 # cannot be handed to another tensor while the entry exists, and is dropped when its consumer takes it (or by the small FIFO bound).
 _q8_tags = {}      # y.data_ptr() -> (y, q, scales, rows, cols)
 _Q8_MAX = 8
+_q8_lock = threading.Lock()      # (producers and consumers run on the main thread AND on autograd's backward threads)
 
 
 def _q8_tag(y, q, sc, rows, cols):
-    while len(_q8_tags) >= _Q8_MAX:
-        _q8_tags.pop(next(iter(_q8_tags)), None)
-    _q8_tags[y.data_ptr()] = (y, q, sc, rows, cols)
+    with _q8_lock:
+        while len(_q8_tags) >= _Q8_MAX:
+            _q8_tags.pop(next(iter(_q8_tags)), None)
+        _q8_tags[y.data_ptr()] = (y, q, sc, rows, cols)
 
 
 def _q8_take(a2, rows, cols):
-    hit = _q8_tags.pop(a2.data_ptr(), None)
+    with _q8_lock:
+        hit = _q8_tags.pop(a2.data_ptr(), None)
     if hit is not None and hit[3:] == (rows, cols) and a2.is_contiguous():
         return hit[1], hit[2]
     return None
