@@ -293,6 +293,10 @@ int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const float* gamma, 
 /* A/B switch of the bf16 forward apply pass: 1 (default) = convolution on the matrix cores with split-bf16 operands (x = xh + xl,
  * w = wh + wl; wh.xh + wh.xl + wl.xh in two v_mfma_f32_32x32x16_bf16 per 32 channels x 32 steps), 0 = the VALU form. */
 int st5_conv0_set_mfma(int on);
+/* A/B switch of the matrix-core forward: 1 (default) = the clip's GroupNorm statistics and the weight fragments come from one launch
+ * (moments, statistics + fragments, apply: three launches), 0 = separate statistics and fragment launches (four).  `stats` holds the
+ * same bits either way. */
+int st5_conv0_set_fold(int on);
 int64_t st5_conv0_ws_bytes(int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride);
 
 /* ---- element-wise / reductions (glue ops fused where the reference has separate torch calls) */

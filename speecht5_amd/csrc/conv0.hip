@@ -153,44 +153,85 @@ __global__ __launch_bounds__(256) void conv0_moments2_kernel(const float* __rest
   for (int i = threadIdx.x; i < nm; i += 256)
     part[((long long)b * nchm + ch) * nm + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
-__global__ __launch_bounds__(256) void conv0_stats2_kernel(const float* __restrict__ part, double* __restrict__ mom, const float* __restrict__ w,
-                                                           float* __restrict__ stats, int C, int k, int L, int nchm, float eps) {
-  __shared__ double ms[MAXMOM];
-  __shared__ double ps[4][MAXMOM];
-  const int b = blockIdx.y, nm = nmom(k);
-  {   // chunk partials -> fp64 sums: four wave-sized groups take every fourth chunk (fixed order), folded in a fixed order
-    const int grp = threadIdx.x >> 6, ml = threadIdx.x & 63;
-    for (int base = 0; base < nm; base += 64) {
-      const int m = base + ml;
-      double sacc = 0.0;
-      if (m < nm)
-        for (int ch = grp; ch < nchm; ch += 4) sacc += (double)part[((long long)b * nchm + ch) * nm + m];
-      if (m < nm) ps[grp][m] = sacc;
-    }
-    __syncthreads();
-    for (int m = threadIdx.x; m < nm; m += 256) {
-      const double sacc = (ps[0][m] + ps[1][m]) + (ps[2][m] + ps[3][m]);
-      ms[m] = sacc;
-      if (blockIdx.x == 0) mom[(long long)b * nm + m] = sacc;
-    }
+// the two halves of conv0_stats2_kernel as device functions (conv0_stats_wfrag_kernel below runs them too)
+// chunk partials -> fp64 sums: two 128-lane groups take every second chunk, sixteen chunks per round (sixteen loads in flight per thread:
+// with one -- a runtime-trip-count loop -- the fold was nchm / 4 dependent L2 round trips), folded in a fixed order.  The first round's
+// loads can be issued early (fold_prefetch) so that they fly together with whatever else the caller loads.
+struct FoldPre { float v[16]; };
+__device__ __forceinline__ void fold_prefetch(const float* __restrict__ part, int b, int nm, int nchm, FoldPre& f) {
+  const int grp = threadIdx.x >> 7, m = threadIdx.x & 127;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) f.v[u] = (m < nm && grp + 2 * u < nchm) ? part[((long long)b * nchm + grp + 2 * u) * nm + m] : 0.f;
+}
+__device__ __forceinline__ void fold_chunk_moments(const float* __restrict__ part, double* __restrict__ mom, double* ms, double (*ps)[MAXMOM],
+                                                   int b, int nm, int nchm, bool publish, const FoldPre* pre) {
+  const int grp = threadIdx.x >> 7, ml = threadIdx.x & 127;
+  for (int base = 0; base < nm; base += 128) {
+    const int m = base + ml;
+    double sacc = 0.0;
+    if (m < nm)
+      for (int ch0 = grp; ch0 < nchm; ch0 += 32) {
+        float v[16];
+        if (pre && base == 0 && ch0 == grp) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = pre->v[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = ch0 + 2 * u < nchm ? part[((long long)b * nchm + ch0 + 2 * u) * nm + m] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (ch0 + 2 * u < nchm) sacc += (double)v[u];
+      }
+    if (m < nm) ps[grp][m] = sacc;
   }
   __syncthreads();
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (!stats || threadIdx.x >= 64 || c >= C) return;
+  for (int m = threadIdx.x; m < nm; m += 256) {
+    const double sacc = ps[0][m] + ps[1][m];
+    ms[m] = sacc;
+    if (publish) mom[(long long)b * nm + m] = sacc;
+  }
+  __syncthreads();
+}
+// mean and 1 / sqrt(var + eps) of one channel's convolution output from the waveform moments M_j = sum_t x_{t+j}, M_jj' = sum_t x_{t+j}
+// x_{t+j'}: s1 = sum_j w_j M_j, s2 = sum_j w_j (M_jj w_j + 2 sum_{j' > j} M_jj' w_j'), in fp64 with EXPLICIT fused multiply-adds in a
+// fixed order -- the two callers (taps from memory / from registers) round alike, so the forward's saved statistics are the same bits
+// whichever launch form produced them.  tap(j): tap j as a float, j < k.
+template <int KW, typename Tap>
+__device__ __forceinline__ void channel_stats(Tap tap, const double* ms, int k, int L, float eps, float& mean, float& rstd) {
   double s1 = 0.0, s2 = 0.0;
-  for (int j = 0; j < k; ++j) {
-    const double wj = (double)w[c * k + j];
-    s1 += wj * ms[j];
-    for (int jp = j; jp < k; ++jp) {
-      const double t = wj * (double)w[c * k + jp] * ms[ridx(k, j, jp)];
-      s2 += (jp == j) ? t : 2.0 * t;
+#pragma unroll
+  for (int j = 0; j < KW; ++j) {
+    if (j < k) {
+      const double wj = (double)tap(j);
+      s1 = fma(wj, ms[j], s1);
+      double off = 0.0;
+#pragma unroll
+      for (int jp = j + 1; jp < KW; ++jp)
+        if (jp < k) off = fma(ms[ridx(k, j, jp)], (double)tap(jp), off);
+      s2 = fma(wj, fma(ms[ridx(k, j, j)], wj, 2.0 * off), s2);
     }
   }
   const double mu = s1 / L;
-  double var = s2 / L - mu * mu;
+  double var = fma(-mu, mu, s2 / L);
   if (var < 0.0) var = 0.0;
-  stats[((long long)b * C + c) * 2 + 0] = (float)mu;
-  stats[((long long)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  mean = (float)mu;
+  rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+__global__ __launch_bounds__(256) void conv0_stats2_kernel(const float* __restrict__ part, double* __restrict__ mom, const float* __restrict__ w,
+                                                           float* __restrict__ stats, int C, int k, int L, int nchm, float eps) {
+  __shared__ double ms[MAXMOM];
+  __shared__ double ps[2][MAXMOM];
+  const int b = blockIdx.y, nm = nmom(k);
+  fold_chunk_moments(part, mom, ms, ps, b, nm, nchm, blockIdx.x == 0, nullptr);
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (!stats || threadIdx.x >= 64 || c >= C) return;
+  float mu, rs;
+  const float* wc = w + c * k;
+  if (k <= 10) channel_stats<10>([&](int j) { return wc[j]; }, ms, k, L, eps, mu, rs);
+  else channel_stats<MAXK>([&](int j) { return wc[j]; }, ms, k, L, eps, mu, rs);
+  stats[((long long)b * C + c) * 2 + 0] = mu;
+  stats[((long long)b * C + c) * 2 + 1] = rs;
 }
 
 // ---- forward apply: conv -> normalise -> affine -> GELU -> channels-last store ----
@@ -246,26 +287,60 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
 // call (B x 32 KB for 512 channels); a block keeps its clip's 32 KB in LDS.
 __device__ __forceinline__ int c0_perm(int m) { return 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3); }
 
-__global__ __launch_bounds__(128) void conv0_wfrag_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ stats, bf16x8* __restrict__ afrag, int C, int k) {
-  // afrag[b][tile][2][64 lanes]: the GroupNorm affine is folded in -- rows hold sc w (sc = rstd gamma, split in bf16 high / low parts)
-  // and the two spare k slots (30, 31) hold the shift sh = beta - mean sc (high / low part) against ones on the x side: the MFMA pair
-  // returns z = sc (w . x) + sh, the GELU argument, directly
-  const int mt = blockIdx.x, b = blockIdx.y, q = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int c = 32 * mt + c0_perm(l & 31), hi = l >> 5;
-  const float mu = stats[((long long)b * C + c) * 2], rs = stats[((long long)b * C + c) * 2 + 1];
-  const float sc = rs * gamma[c], sh = beta[c] - mu * sc;
+// one 16-byte fragment entry: afrag[.][tile mt][q][lane l] -- rows hold sc w (sc = rstd gamma, split in bf16 high / low parts) and the
+// two spare k slots (30, 31) hold the shift sh = beta - mean sc (high / low part) against ones on the x side: the MFMA pair returns
+// z = sc (w . x) + sh, the GELU argument, directly
+template <typename W>
+__device__ __forceinline__ bf16x8 wfrag_entry(W wj, int k, float sc, float sh, int q, int hi) {   // wj(j): tap j of the entry's channel
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int kk = 16 * q + 8 * hi + e, sec = kk / 10, j = kk - 10 * sec;
-    float v = (kk < 30 && j < k) ? sc * w[c * k + j] : 0.f;
+    float v = (kk < 30 && j < k) ? sc * wj(j) : 0.f;
     if (kk >= 30) v = sh;
     const bf16_t vh = (bf16_t)v;
     const bool low = sec == 2 && kk < 30 || kk == 31;
     o[e] = low ? (bf16_t)(v - (float)vh) : vh;
   }
-  afrag[((long long)(b * gridDim.x + mt) * 2 + q) * 64 + l] = o;
+  return o;
+}
+__global__ __launch_bounds__(128) void conv0_wfrag_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ stats, bf16x8* __restrict__ afrag, int C, int k) {
+  // afrag[b][tile][2][64 lanes]: the GroupNorm affine is folded in
+  const int mt = blockIdx.x, b = blockIdx.y, q = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int c = 32 * mt + c0_perm(l & 31), hi = l >> 5;
+  const float mu = stats[((long long)b * C + c) * 2], rs = stats[((long long)b * C + c) * 2 + 1];
+  const float sc = rs * gamma[c], sh = beta[c] - mu * sc;
+  afrag[((long long)(b * gridDim.x + mt) * 2 + q) * 64 + l] = wfrag_entry([&](int j) { return w[c * k + j]; }, k, sc, sh, q, hi);
+}
+
+// The forward's statistics and fragments in ONE launch (conv0_stats2_kernel + conv0_wfrag_kernel were ~9 + ~5 us of launch and load
+// latency for 65 x nchm floats per clip): a block of (32-channel tile, clip) folds the clip's moment partials, every thread derives the
+// statistics of the channel its fragment entry belongs to (four threads per channel, same arithmetic -- no exchange), one of them
+// publishes `stats`.  Same device functions as the two-launch form: same bits.  (Deriving them in the apply kernel's prologue instead
+// was measured: 1000 blocks x 512 channels of fp64 pushed that kernel from 56 to 212 registers or, capped at 128, into spills --
+// 94 us for the call against 87.)
+__global__ __launch_bounds__(256) void conv0_stats_wfrag_kernel(const float* __restrict__ part, const float* __restrict__ w,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ stats, bf16x8* __restrict__ afrag, int C, int k, int L,
+                                                                int nchm, float eps) {
+  __shared__ double ms[MAXMOM];
+  __shared__ double ps[2][MAXMOM];
+  const int mt = blockIdx.x, b = blockIdx.y, q = (threadIdx.x >> 6) & 1, l = threadIdx.x & 63;
+  const int c = 32 * mt + c0_perm(l & 31), hi = l >> 5;
+  float wr[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) wr[j] = j < k ? w[c * k + j] : 0.f;
+  const float ga = gamma[c], be = beta[c];
+  FoldPre pre;
+  fold_prefetch(part, b, nmom(k), nchm, pre);
+  fold_chunk_moments(part, nullptr, ms, ps, b, nmom(k), nchm, false, &pre);
+  if (threadIdx.x >= 128) return;
+  float mu, rs;
+  channel_stats<10>([&](int j) { return wr[j]; }, ms, k, L, eps, mu, rs);
+  if (q == 0 && hi == 0) { stats[((long long)b * C + c) * 2] = mu; stats[((long long)b * C + c) * 2 + 1] = rs; }
+  const float sc = rs * ga, sh = be - mu * sc;
+  afrag[((long long)(b * gridDim.x + mt) * 2 + q) * 64 + l] = wfrag_entry([&](int j) { return wr[j]; }, k, sc, sh, q, hi);
 }
 
 __global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __restrict__ wav, const bf16x8* __restrict__ afrag_g,
@@ -666,18 +741,21 @@ __host__ inline Ws carve(void* ws, int B, int nch, int C, int k) {
 
 // waveform moments (+ statistics when `stats` is given): two launches
 void launch_moments_stats(const float* wav, const float* w, float* stats, const Ws& W, int B, int S, int L, int C, int k, int stride, float eps,
-                          hipStream_t s) {
+                          hipStream_t s, bool with_stats = true) {
   const int nchm = (L + TCM - 1) / TCM;
   const size_t shm2 = (size_t)(((TCM - 1) * stride + k + 8 + 3) & ~3) * sizeof(float);
   if (shm2 > 60 * 1024) return;      // (strides far beyond the recipe's 5: the caller rejects them, see st5_conv0_gn_gelu_fwd)
   if (k <= 10) hipLaunchKernelGGL((conv0_moments2_kernel<10>), dim3(nchm, B), dim3(256), shm2, s, wav, W.part, S, L, k, stride, nchm);
   else hipLaunchKernelGGL((conv0_moments2_kernel<MAXK>), dim3(nchm, B), dim3(256), shm2, s, wav, W.part, S, L, k, stride, nchm);
-  hipLaunchKernelGGL(conv0_stats2_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, W.part, W.mom, w, stats, C, k, L, nchm, eps);
+  if (with_stats) hipLaunchKernelGGL(conv0_stats2_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, W.part, W.mom, w, stats, C, k, L, nchm, eps);
 }
 
 }  // namespace
 
-namespace { int g_conv0_mfma = 1; }
+namespace { int g_conv0_mfma = 1, g_conv0_fold = 1; }
+/* 1 (default): the matrix-core forward derives statistics and weight fragments in one launch (three in all); 0: conv0_stats2_kernel +
+   conv0_wfrag_kernel (four launches; A/B). */
+extern "C" int st5_conv0_set_fold(int on) { g_conv0_fold = on ? 1 : 0; return ST5_OK; }
 /* 1 (default): the bf16 forward apply pass on the matrix cores (split-bf16 operands); 0: the VALU form (A/B, and what fp32 always runs). */
 extern "C" int st5_conv0_set_mfma(int on) { g_conv0_mfma = on ? 1 : 0; return ST5_OK; }
 
@@ -701,18 +779,22 @@ extern "C" int st5_conv0_gn_gelu_fwd(const float* wav, const float* w, const flo
   const int nch = (L + TCH - 1) / TCH;
   const size_t shm = (size_t)(TCH * stride + k + MAXK) * sizeof(float);
   const Ws W = carve(ws, B, nch, C, k);
-  launch_moments_stats(wav, w, stats, W, B, S, L, C, k, stride, eps, s);
+  const bool mfma = dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 32 == 0 && C <= 1024;
+  const bool fold = mfma && g_conv0_fold;
+  launch_moments_stats(wav, w, stats, W, B, S, L, C, k, stride, eps, s, !fold);
 #define APPLY(TT, KW)                                                                                           \
   hipLaunchKernelGGL((conv0_apply_kernel<TT, KW>), dim3(nch, B), dim3(256), shm, s, wav, w, gamma, beta, stats, \
                      (TT*)out, S, L, C, k, stride)
-  if (dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 32 == 0 && C <= 1024) {
-    hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32, B), dim3(128), 0, s, w, gamma, beta, stats, W.afrag, C, k);
+  if (mfma) {
     const size_t shm_m = (size_t)(C / 32) * 2048 + shm;
     static bool attr = false;
     if (!attr) {
       if (hipFuncSetAttribute((const void*)conv0_apply_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
       attr = true;
     }
+    if (fold) hipLaunchKernelGGL(conv0_stats_wfrag_kernel, dim3(C / 32, B), dim3(256), 0, s, (const float*)W.part, w, gamma, beta, stats, W.afrag, C, k, L,
+                                 (L + TCM - 1) / TCM, eps);
+    else hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32, B), dim3(128), 0, s, w, gamma, beta, stats, W.afrag, C, k);
     hipLaunchKernelGGL(conv0_apply_mfma_kernel, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, (bf16_t*)out, S, L, C, k, stride);
   } else if (dtype == ST5_BF16) { if (k <= 10) APPLY(bf16_t, 10); else APPLY(bf16_t, MAXK); }
   else { if (k <= 10) APPLY(float, 10); else APPLY(float, MAXK); }

@@ -505,6 +505,36 @@ def test_conv0_matrix_core_apply_equals_the_valu_apply(cuda, B, S, C):
     assert float((diff > 0).float().mean()) < 0.03, float((diff > 0).float().mean())
 
 
+@pytest.mark.parametrize("B,S,C,k", [(2, 3007, 64, 10), (8, 160000, 512, 10), (3, 5125, 256, 7), (1, 4000, 1024, 10), (2, 300, 512, 10)])
+def test_conv0_folded_statistics_equal_the_separate_launches_bit_for_bit(cuda, B, S, C, k):
+    """The matrix-core forward with the statistics and weight fragments from ONE launch (moments, statistics + fragments, apply) against
+    the four-launch form (moments, statistics, fragments, apply): the same device functions in the same order, so the output AND the
+    saved statistics are the same bits -- at the benched shape, ragged tiles, k < 10, one time chunk, C = 1024."""
+    torch.manual_seed(S + C)
+    stride = 5
+    Lo = (S - k) // stride + 1
+    wav = torch.randn(B, S, device=cuda) * 0.7 + 0.05
+    w = (torch.randn(C, k) * math.sqrt(2.0 / k)).to(cuda)
+    g, b = (torch.rand(C) + 0.5).to(cuda), (torch.randn(C) * 0.1).to(cuda)
+    Ld = hip.lib()
+    ws = hip.workspace(Ld.st5_conv0_ws_bytes(B, S, C, k, stride), cuda)
+    res = []
+    try:
+        for mode in (0, 1):
+            hip.check(Ld.st5_conv0_set_fold(mode), "set_fold")
+            out = torch.full((B, Lo, C), float("nan"), dtype=torch.bfloat16, device=cuda)
+            stats = torch.full((B, C, 2), float("nan"), device=cuda)
+            hip.check(Ld.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                                               ws.data_ptr(), B, S, C, k, stride, 1e-5, hip.BF16, hip.stream()), "conv0 fwd")
+            torch.cuda.synchronize()
+            res.append((out, stats))
+    finally:
+        hip.check(Ld.st5_conv0_set_fold(1), "set_fold")
+    assert torch.isfinite(res[1][0].float()).all() and torch.isfinite(res[1][1]).all()
+    assert torch.equal(res[0][1], res[1][1]), "statistics"
+    assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16)), "output"
+
+
 @pytest.mark.parametrize("B,S,C,k", [(2, 6407, 128, 10), (1, 16000, 512, 10), (2, 4000, 256, 7), (1, 4000, 1024, 10)])   # (C = 1024: beyond the
 # four channel tiles a wave of the matrix-core backward holds -- the dispatcher must take the VALU kernel there, ADVICE r5)
 def test_conv0_matrix_core_backward_equals_the_valu_backward(cuda, B, S, C, k):
