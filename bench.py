@@ -367,6 +367,8 @@ def main():
         hip.lib().st5_gemm_set_splitk_target(int(os.environ["ST5_SPLITK_TARGET"]))
     if os.environ.get("ST5_CONV0_MFMA"):  # A/B: 0 = VALU form of conv layer 0's forward apply pass (default 1: matrix cores)
         hip.lib().st5_conv0_set_mfma(int(os.environ["ST5_CONV0_MFMA"]))
+    if os.environ.get("ST5_CONV0_GELU_TABLE"):  # A/B: 0 = conv layer 0's forward GELU as the polynomial (default 1: chord table in LDS)
+        hip.lib().st5_conv0_set_gelu_table(int(os.environ["ST5_CONV0_GELU_TABLE"]))
     if os.environ.get("ST5_CONV0_FOLD"):  # A/B: 0 = conv layer 0's statistics and weight fragments in two launches (default 1: one)
         hip.lib().st5_conv0_set_fold(int(os.environ["ST5_CONV0_FOLD"]))
     if os.environ.get("ST5_TN_PHASED"):   # A/B: 1 / 2 = weight-gradient GEMMs on the phased 256x256 kernel (default 0 = the 128x128 kernel)

@@ -297,6 +297,10 @@ int st5_conv0_set_mfma(int on);
  * (moments, statistics + fragments, apply: three launches), 0 = separate statistics and fragment launches (four).  `stats` holds the
  * same bits either way. */
 int st5_conv0_set_fold(int on);
+/* A/B switch of the matrix-core forward's GELU: 1 (default) = a 256-entry chord table of the upper tail Q = 1 - Phi in LDS,
+ * gelu(z) = max(z, 0) - |z| Q(|z|) (|error| <= 8.4e-6 |z|, 8.5 VALU issue slots per element), 0 = the transcendental-free
+ * polynomial (1.5e-5 |z|, 14.5 slots). */
+int st5_conv0_set_gelu_table(int on);
 int64_t st5_conv0_ws_bytes(int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride);
 
 /* ---- element-wise / reductions (glue ops fused where the reference has separate torch calls) */

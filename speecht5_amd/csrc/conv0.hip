@@ -320,9 +320,12 @@ __global__ __launch_bounds__(128) void conv0_wfrag_kernel(const float* __restric
 // publishes `stats`.  Same device functions as the two-launch form: same bits.  (Deriving them in the apply kernel's prologue instead
 // was measured: 1000 blocks x 512 channels of fp64 pushed that kernel from 56 to 212 registers or, capped at 128, into spills --
 // 94 us for the call against 87.)
+// The backward calls it with the forward's statistics (stats_in): no statistics are derived, and only the block of tile 0 folds the
+// moments -- to publish `mom` for conv0_bwd_final_kernel (conv0_stats2_kernel did only that there: one launch less).
 __global__ __launch_bounds__(256) void conv0_stats_wfrag_kernel(const float* __restrict__ part, const float* __restrict__ w,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* __restrict__ stats, bf16x8* __restrict__ afrag, int C, int k, int L,
+                                                                const float* __restrict__ stats_in, float* __restrict__ stats,
+                                                                double* __restrict__ mom, bf16x8* __restrict__ afrag, int C, int k, int L,
                                                                 int nchm, float eps) {
   __shared__ double ms[MAXMOM];
   __shared__ double ps[2][MAXMOM];
@@ -332,23 +335,58 @@ __global__ __launch_bounds__(256) void conv0_stats_wfrag_kernel(const float* __r
 #pragma unroll
   for (int j = 0; j < 10; ++j) wr[j] = j < k ? w[c * k + j] : 0.f;
   const float ga = gamma[c], be = beta[c];
-  FoldPre pre;
-  fold_prefetch(part, b, nmom(k), nchm, pre);
-  fold_chunk_moments(part, nullptr, ms, ps, b, nmom(k), nchm, false, &pre);
+  float mu = 0.f, rs = 0.f;
+  if (stats_in) { mu = stats_in[((long long)b * C + c) * 2]; rs = stats_in[((long long)b * C + c) * 2 + 1]; }
+  if (!stats_in || (mom && mt == 0)) {      // (block-uniform)
+    FoldPre pre;
+    fold_prefetch(part, b, nmom(k), nchm, pre);
+    fold_chunk_moments(part, mom, ms, ps, b, nmom(k), nchm, mom && mt == 0, &pre);
+  }
   if (threadIdx.x >= 128) return;
-  float mu, rs;
-  channel_stats<10>([&](int j) { return wr[j]; }, ms, k, L, eps, mu, rs);
-  if (q == 0 && hi == 0) { stats[((long long)b * C + c) * 2] = mu; stats[((long long)b * C + c) * 2 + 1] = rs; }
+  if (!stats_in) {
+    channel_stats<10>([&](int j) { return wr[j]; }, ms, k, L, eps, mu, rs);
+    if (q == 0 && hi == 0) { stats[((long long)b * C + c) * 2] = mu; stats[((long long)b * C + c) * 2 + 1] = rs; }
+  }
   const float sc = rs * ga, sh = be - mu * sc;
   afrag[((long long)(b * gridDim.x + mt) * 2 + q) * 64 + l] = wfrag_entry([&](int j) { return wr[j]; }, k, sc, sh, q, hi);
 }
 
+// GELU through a 256-entry table in LDS (TAB): with the polynomial the kernel is VALU-issue-bound -- 14.5 slots per output element, 131 M
+// elements per 8-clip batch = 48 us of issue on 256 CUs against 33 us to write them.  gelu(z) = max(z, 0) - |z| Q(|z|), Q = 1 - Phi the
+// upper tail on [0, 4.25] as chords over 255 intervals, an entry (Q, rise) two floats read with one ds_read_b64; beyond 4.25 the last
+// value (1.1e-5).  Q is the SMALL quantity on both sides (z > 0: z - z Q; z < 0: -|z| Q): |gelu error| <= 8.4e-6 |z| (the chord error
+// h^2 / 8 max|Phi''|; the polynomial: 1.5e-5 |z|), tests/test_isa_audit.py::test_conv0_gelu_table_error_bound.  8.5 slots: scale,
+// clamp, truncate, fract, address, the chord, max, the product.  (Entries packed as two fp16 in one dword + v_fma_mix_f32 were
+// measured too: the same 60 us -- bank conflicts are not what bounds the kernel -- at 13x the error, so the fp32 pairs stay.)
+// The table costs 2 KB of LDS (four blocks per CU still fit) and 256 erfcf calls per block.
+constexpr float C0_GT_MAX = 4.25f, C0_GT_SCALE = 255.f / C0_GT_MAX;
+// What is left after the table (60 us): the write stream itself.  With the SAME bytes stored lane-consecutively (wrong placement, timing
+// experiment tools/r6b/call31.sh) the kernel takes 51.9 us = 5.0 TB/s of pure writes -- the chip's write ceiling as far as this kernel
+// can see it; the real pattern (a lane's 16-byte chunks lie 1 KB apart: 32 rows per store instruction) costs 7 us over that.
+// (Written per element; hipcc keeps ~4 table reads in flight.  Staging all sixteen reads of a tile first was measured slower -- 62.8 us
+//  against 59.0 -- on the same kind of A/B, profiles/r6b_conv0_fold_ab.txt.)
+__device__ __forceinline__ float gelu_tab(float z, const float2* gt) {
+  const float a = fminf(fabsf(z) * C0_GT_SCALE, 255.f);
+  const float2 e = gt[(int)a];
+  const float q = fmaf(__builtin_amdgcn_fractf(a), e.y, e.x);
+  float relu;
+  asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(z));      // (one slot; fmaxf adds a canonicalising v_max z, z in front)
+  return fmaf(-fabsf(z), q, relu);
+}
+template <bool TAB>
 __global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __restrict__ wav, const bf16x8* __restrict__ afrag_g,
-                                                               bf16_t* __restrict__ out, int S, int L, int C, int k, int stride) {
+                                                               bf16_t* __restrict__ out, int S, int L, int C, int k, int stride, int seg_bytes) {
   extern __shared__ __attribute__((aligned(16))) char sm0[];
   const int ntile = C / 32;
   bf16x8* afr = reinterpret_cast<bf16x8*>(sm0);                       // [ntile][2][64 lanes] x 16 B (this clip's)
   float* seg = reinterpret_cast<float*>(sm0 + (size_t)ntile * 2048);
+  const float2* gt = reinterpret_cast<const float2*>(sm0 + (size_t)ntile * 2048 + seg_bytes);   // [256] (TAB)
+  if constexpr (TAB) {
+    const float h = C0_GT_MAX / 255.f, x0 = threadIdx.x * h;
+    const float v0 = 0.5f * erfcf(x0 * 0.70710678118654752f);
+    const float v1 = threadIdx.x < 255 ? 0.5f * erfcf((x0 + h) * 0.70710678118654752f) : v0;
+    const_cast<float2*>(gt)[threadIdx.x] = make_float2(v0, v1 - v0);
+  }
   const int b = blockIdx.y, t0 = blockIdx.x * TCH;
   const int nt = min(TCH, L - t0);
   stage_wav(seg, wav, b, S, t0, nt, k, stride);
@@ -389,7 +427,10 @@ __global__ __launch_bounds__(256) void conv0_apply_mfma_kernel(const float* __re
       if (tv) {
         bf16x8 o0, o1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { o0[e] = (bf16_t)gelu_poly(acc[e]); o1[e] = (bf16_t)gelu_poly(acc[8 + e]); }
+        for (int e = 0; e < 8; ++e) {
+          o0[e] = (bf16_t)(TAB ? gelu_tab(acc[e], gt) : gelu_poly(acc[e]));
+          o1[e] = (bf16_t)(TAB ? gelu_tab(acc[8 + e], gt) : gelu_poly(acc[8 + e]));
+        }
         *reinterpret_cast<bf16x8*>(orow + mt * 32) = o0;
         *reinterpret_cast<bf16x8*>(orow + mt * 32 + 8) = o1;
       }
@@ -491,12 +532,27 @@ __device__ __forceinline__ bf16x8 c0_tr_frag(const char* tile, int off_lo, int o
   return u.v;
 }
 
+// gelu'(z) = Phi(z) + z phi(z) through a SIGNED 512-entry chord table in LDS (TAB; the forward's gelu_tab is its sibling): nodes
+// -R + i h, R = 4.35, h = 2 R / 511, an entry (value, rise) two floats; outside [-R, R] the end values (1.0001 / -1.3e-4).  Six issue
+// slots -- scale + offset, clamp (v_med3), truncate, fract, address, the chord -- against the polynomial's 13; |error| <= h^2 / 8 times
+// the largest third derivative of gelu (0.77) = 2.8e-5 (the polynomial: 1.2e-4), tests/test_isa_audit.py::
+// test_conv0_gelu_grad_table_error_bound.
+constexpr float C0_GG_R = 4.35f, C0_GG_SCALE = 511.f / (2.f * C0_GG_R), C0_GG_OFF = 255.5f;
+__device__ __forceinline__ float gelu_grad_tab(float z, const float2* gg) {
+  const float a = __builtin_amdgcn_fmed3f(fmaf(z, C0_GG_SCALE, C0_GG_OFF), 0.f, 511.f);
+  const float2 e = gg[(int)a];
+  return fmaf(__builtin_amdgcn_fractf(a), e.y, e.x);
+}
+__device__ __forceinline__ float c0_gelu_grad_exact(float x) {
+  return 0.5f * erfcf(-x * 0.70710678118654752f) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
 #ifndef C0_BWD_OCC
 #define C0_BWD_OCC 2      // waves per SIMD the backward kernel is compiled for (measured: 3 = 168 registers + 17-27 spilled dwords: 164-177 us against 120)
 #endif
 #ifndef C0_BWD_PREFETCH
 #define C0_BWD_PREFETCH 4 // channel tiles whose dY loads are issued ahead (4 = the whole time step's)
 #endif
+template <bool TAB>
 __global__ __launch_bounds__(256, C0_BWD_OCC) void conv0_bwd_mfma_kernel(const float* __restrict__ wav, const bf16x8* __restrict__ afrag_g,
                                                              const bf16_t* __restrict__ dY,
                                                              float* __restrict__ part, int S, int L, int C, int k, int stride, int nch) {
@@ -508,10 +564,19 @@ __global__ __launch_bounds__(256, C0_BWD_OCC) void conv0_bwd_mfma_kernel(const f
   const int nt = min(TCH, L - t0);
   const int nseg_pad = (TCH - 1) * stride + k + MAXK;
   char* trbase = reinterpret_cast<char*>(seg + ((nseg_pad + 3) & ~3));  // one [32 t][32 c] tile per wave
+  const float2* gg = reinterpret_cast<const float2*>(trbase + 4 * C0_TILE_B);   // [512] (TAB)
   stage_wav(seg, wav, b, S, t0, nt, k, stride);
   {
     const bf16x8* afb = afrag_g + (long long)b * ntile * 128;
     for (int i = threadIdx.x; i < ntile * 128; i += 256) afr[i] = afb[i];
+  }
+  if constexpr (TAB) {
+    const float h = 2.f * C0_GG_R / 511.f;
+    for (int i = threadIdx.x; i < 512; i += 256) {
+      const float v0 = c0_gelu_grad_exact(-C0_GG_R + i * h);
+      const float v1 = i < 511 ? c0_gelu_grad_exact(-C0_GG_R + (i + 1) * h) : v0;
+      const_cast<float2*>(gg)[i] = make_float2(v0, v1 - v0);
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -596,12 +661,16 @@ __global__ __launch_bounds__(256, C0_BWD_OCC) void conv0_bwd_mfma_kernel(const f
       y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, y, 0, 0, 0);
       const unsigned int dw_[8] = {dv0.x, dv0.y, dv0.z, dv0.w, dv1.x, dv1.y, dv1.z, dv1.w};
       bf16x8 dh0, dh1;
+      typedef float c0_f2 __attribute__((ext_vector_type(2)));
+      typedef bf16_t c0_b2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; r += 2) {      // (pairs: one v_cvt_pk_bf16_f32 per two elements)
         const unsigned int pk = dw_[r >> 1];
-        const float dyv = __uint_as_float((r & 1) ? (pk & 0xffff0000u) : (pk << 16));
-        const bf16_t h = (bf16_t)(dyv * gelu_grad_poly(y[r]));      // (y IS the GELU argument: the affine rides in the fragments)
-        if (r < 8) dh0[r] = h; else dh1[r - 8] = h;
+        c0_f2 dz;                              // (y IS the GELU argument: the affine rides in the fragments)
+        dz[0] = __uint_as_float(pk << 16) * (TAB ? gelu_grad_tab(y[r], gg) : gelu_grad_poly(y[r]));
+        dz[1] = __uint_as_float(pk & 0xffff0000u) * (TAB ? gelu_grad_tab(y[r + 1], gg) : gelu_grad_poly(y[r + 1]));
+        const c0_b2 hb = __builtin_convertvector(dz, c0_b2);
+        if (r < 8) { dh0[r] = hb[0]; dh0[r + 1] = hb[1]; } else { dh1[r - 8] = hb[0]; dh1[r - 7] = hb[1]; }
       }
       // wave-private transpose: rows = this lane's time step, 32 bytes of its 16 channels
       *reinterpret_cast<bf16x8*>(trh + n * C0_TP + 32 * hi) = dh0;
@@ -752,7 +821,10 @@ void launch_moments_stats(const float* wav, const float* w, float* stats, const 
 
 }  // namespace
 
-namespace { int g_conv0_mfma = 1, g_conv0_fold = 1; }
+namespace { int g_conv0_mfma = 1, g_conv0_fold = 1, g_conv0_gelu_tab = 1; }
+/* 1 (default): the matrix-core forward evaluates GELU through a 256-entry chord table of the normal upper tail in LDS (8.5 VALU slots
+   per element); 0: the degree-19 polynomial (14.5 slots; A/B). */
+extern "C" int st5_conv0_set_gelu_table(int on) { g_conv0_gelu_tab = on ? 1 : 0; return ST5_OK; }
 /* 1 (default): the matrix-core forward derives statistics and weight fragments in one launch (three in all); 0: conv0_stats2_kernel +
    conv0_wfrag_kernel (four launches; A/B). */
 extern "C" int st5_conv0_set_fold(int on) { g_conv0_fold = on ? 1 : 0; return ST5_OK; }
@@ -786,16 +858,22 @@ extern "C" int st5_conv0_gn_gelu_fwd(const float* wav, const float* w, const flo
   hipLaunchKernelGGL((conv0_apply_kernel<TT, KW>), dim3(nch, B), dim3(256), shm, s, wav, w, gamma, beta, stats, \
                      (TT*)out, S, L, C, k, stride)
   if (mfma) {
-    const size_t shm_m = (size_t)(C / 32) * 2048 + shm;
+    const int seg_bytes = (int)((shm + 7) & ~(size_t)7);
+    const size_t shm_m = (size_t)(C / 32) * 2048 + seg_bytes + (g_conv0_gelu_tab ? 256 * sizeof(float2) : 0);
     static bool attr = false;
     if (!attr) {
-      if (hipFuncSetAttribute((const void*)conv0_apply_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
+      if (hipFuncSetAttribute((const void*)conv0_apply_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+          hipFuncSetAttribute((const void*)conv0_apply_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+        return ST5_ERR_LAUNCH;
       attr = true;
     }
-    if (fold) hipLaunchKernelGGL(conv0_stats_wfrag_kernel, dim3(C / 32, B), dim3(256), 0, s, (const float*)W.part, w, gamma, beta, stats, W.afrag, C, k, L,
-                                 (L + TCM - 1) / TCM, eps);
+    if (fold) hipLaunchKernelGGL(conv0_stats_wfrag_kernel, dim3(C / 32, B), dim3(256), 0, s, (const float*)W.part, w, gamma, beta, (const float*)nullptr,
+                                 stats, (double*)nullptr, W.afrag, C, k, L, (L + TCM - 1) / TCM, eps);
     else hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32, B), dim3(128), 0, s, w, gamma, beta, stats, W.afrag, C, k);
-    hipLaunchKernelGGL(conv0_apply_mfma_kernel, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, (bf16_t*)out, S, L, C, k, stride);
+    if (g_conv0_gelu_tab)
+      hipLaunchKernelGGL(conv0_apply_mfma_kernel<true>, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, (bf16_t*)out, S, L, C, k, stride, seg_bytes);
+    else
+      hipLaunchKernelGGL(conv0_apply_mfma_kernel<false>, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, (bf16_t*)out, S, L, C, k, stride, seg_bytes);
   } else if (dtype == ST5_BF16) { if (k <= 10) APPLY(bf16_t, 10); else APPLY(bf16_t, MAXK); }
   else { if (k <= 10) APPLY(float, 10); else APPLY(float, MAXK); }
 #undef APPLY
@@ -817,7 +895,9 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
   const size_t shm = (size_t)(TCH * stride + k + MAXK) * sizeof(float);
   const Ws W = carve(ws, B, nch, C, k);
   // waveform moments again (0.64 MB/clip; cheaper than keeping them alive between forward and backward)
-  launch_moments_stats(wav, w, nullptr, W, B, S, L, C, k, stride, 0.f, s);
+  const bool mfma = dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 128 == 0 && C <= 512 && TCH % 32 == 0;
+  const bool fold = mfma && g_conv0_fold;      // (the fragment launch folds and publishes the moments itself)
+  launch_moments_stats(wav, w, nullptr, W, B, S, L, C, k, stride, 0.f, s, !fold);
   const int KWv = k <= 10 ? 10 : MAXK, nv = KWv + 2;
   {   // ST5_POISON=1 (debug): the partials region is NaN before the backward kernel fills it -- a reduce that ran ahead of a
       // block of conv0_bwd_kernel, or a block that never stored, then shows as NaN instead of as last step's value
@@ -829,18 +909,23 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
                      (const TT*)dY, W.part, S, L, C, k, stride, nch)
   // (C <= 512: conv0_bwd_mfma_kernel holds at most four 128-channel tiles per wave -- G[4], dvq[4]; wider layers take the VALU kernel,
   //  whose channel loop has no such bound.  ADVICE r5: the guard said 1024 and tiles 4.. were silently never computed.)
-  const bool mfma = dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 128 == 0 && C <= 512 && TCH % 32 == 0;
   if (mfma) {
-    hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32, B), dim3(128), 0, s, w, gamma, beta, stats, W.afrag, C, k);
+    if (fold) hipLaunchKernelGGL(conv0_stats_wfrag_kernel, dim3(C / 32, B), dim3(256), 0, s, (const float*)W.part, w, gamma, beta, stats, (float*)nullptr,
+                                 W.mom, W.afrag, C, k, L, (L + TCM - 1) / TCM, 0.f);
+    else hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32, B), dim3(128), 0, s, w, gamma, beta, stats, W.afrag, C, k);
     const size_t seg_f = (size_t)(((TCH - 1) * stride + k + MAXK + 3) & ~3);
-    const size_t shm_m = (size_t)(C / 32) * 2048 + seg_f * sizeof(float) + (size_t)4 * C0_TILE_B;
+    const size_t shm_m = (size_t)(C / 32) * 2048 + seg_f * sizeof(float) + (size_t)4 * C0_TILE_B + (g_conv0_gelu_tab ? 512 * sizeof(float2) : 0);
     static bool attr = false;
     if (!attr) {
-      if (hipFuncSetAttribute((const void*)conv0_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return ST5_ERR_LAUNCH;
+      if (hipFuncSetAttribute((const void*)conv0_bwd_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+          hipFuncSetAttribute((const void*)conv0_bwd_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+        return ST5_ERR_LAUNCH;
       attr = true;
     }
-    hipLaunchKernelGGL(conv0_bwd_mfma_kernel, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, (const bf16_t*)dY, W.part, S, L,
-                       C, k, stride, nch);
+    if (g_conv0_gelu_tab)
+      hipLaunchKernelGGL(conv0_bwd_mfma_kernel<true>, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, (const bf16_t*)dY, W.part, S, L, C, k, stride, nch);
+    else
+      hipLaunchKernelGGL(conv0_bwd_mfma_kernel<false>, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, (const bf16_t*)dY, W.part, S, L, C, k, stride, nch);
   } else if (dtype == ST5_BF16) { if (k <= 10) BWD(bf16_t, 10); else BWD(bf16_t, MAXK); }
   else { if (k <= 10) BWD(float, 10); else BWD(float, MAXK); }
 #undef BWD

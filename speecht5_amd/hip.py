@@ -108,6 +108,7 @@ _SIGS = {
     "st5_conv0_ws_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "st5_conv0_set_mfma": (c_int, [c_int]),
     "st5_conv0_set_fold": (c_int, [c_int]),
+    "st5_conv0_set_gelu_table": (c_int, [c_int]),
     "st5_cast_from_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int, c_void_p]),
     "st5_cast_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "st5_colsum_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_float, c_int32, c_int,

@@ -70,6 +70,41 @@ def test_gelu_poly_error_bound():
     assert (err <= 2.5e-5 + 1.6e-5 * np.abs(xd)).all()
 
 
+def test_conv0_gelu_table_error_bound():
+    """conv0.hip gelu_tab (the matrix-core forward of conv layer 0): gelu(z) = max(z, 0) - |z| Q(|z|) with the upper tail Q = 1 - Phi
+    as 255 chords on [0, 4.25], an entry (Q, rise) two floats -- restated in numpy (fp32 table, the chord and the product each one fused
+    multiply-add) with the constants parsed from the source, against the exact erf-GELU: |Q error| <= 8.5e-6 inside the table,
+    |gelu error| <= 1.1e-5 |z| everywhere (beyond 4.25 the last node's 1.07e-5 stands in for a tail that has vanished), <= 2e-5 in
+    absolute terms for |z| <= 4 -- below the polynomial's 2.5e-5."""
+    import re
+    import numpy as np
+    from scipy.special import erfc
+    src = open(os.path.join(ROOT, "speecht5_amd", "csrc", "conv0.hip")).read()
+    gmax = float(re.search(r"C0_GT_MAX = (\d+\.\d+)f", src).group(1))
+    assert "C0_GT_SCALE = 255.f / C0_GT_MAX" in src and "fminf(fabsf(z) * C0_GT_SCALE, 255.f)" in src
+    assert "make_float2(v0, v1 - v0)" in src and "fmaf(__builtin_amdgcn_fractf(a), e.y, e.x)" in src
+    h = np.float32(gmax) / np.float32(255)
+    x0 = (np.arange(256, dtype=np.float32) * h).astype(np.float32)
+    v0 = (0.5 * erfc(x0.astype(np.float64) / np.sqrt(2))).astype(np.float32)
+    v1 = (0.5 * erfc((x0 + h).astype(np.float64) / np.sqrt(2))).astype(np.float32)
+    v1[255] = v0[255]
+    rise = (v1 - v0).astype(np.float32)
+    z = np.linspace(-8, 8, 1600001).astype(np.float32)
+    a = np.minimum(np.abs(z) * np.float32(255.0 / gmax), np.float32(255)).astype(np.float32)
+    i = a.astype(np.int32)
+    fr = (a - np.floor(a)).astype(np.float32)
+    q = (fr.astype(np.float64) * rise[i].astype(np.float64) + v0[i].astype(np.float64)).astype(np.float32)
+    got = (-np.abs(z).astype(np.float64) * q + np.maximum(z, 0)).astype(np.float32).astype(np.float64)
+    zd = z.astype(np.float64)
+    Q = 0.5 * erfc(np.abs(zd) / np.sqrt(2))
+    ref = np.maximum(zd, 0) - np.abs(zd) * Q            # == z Phi(z)
+    err = np.abs(got - ref)
+    inside = np.abs(zd) <= gmax
+    assert np.abs(q.astype(np.float64) - Q)[inside].max() <= 8.5e-6, np.abs(q.astype(np.float64) - Q)[inside].max()
+    assert (err <= 1.1e-5 * np.abs(zd) + 1e-7).all(), float((err - 1.1e-5 * np.abs(zd)).max())
+    assert err[np.abs(zd) <= 4].max() <= 2e-5, err[np.abs(zd) <= 4].max()
+
+
 def test_gelu_grad_poly_error_bound():
     """common.h gelu_grad_poly (derivative of GELU in the bf16 backward epilogues), restated in numpy from the parsed constants:
     |error| <= 1.3e-4 everywhere (the exact derivative lies in [-0.13, 1.13]; the factor multiplies bf16 operands)."""

@@ -516,6 +516,7 @@ def test_conv0_folded_statistics_equal_the_separate_launches_bit_for_bit(cuda, B
     wav = torch.randn(B, S, device=cuda) * 0.7 + 0.05
     w = (torch.randn(C, k) * math.sqrt(2.0 / k)).to(cuda)
     g, b = (torch.rand(C) + 0.5).to(cuda), (torch.randn(C) * 0.1).to(cuda)
+    dY = (torch.randn(B, Lo, C, device=cuda) * 0.3).to(torch.bfloat16)
     Ld = hip.lib()
     ws = hip.workspace(Ld.st5_conv0_ws_bytes(B, S, C, k, stride), cuda)
     res = []
@@ -526,13 +527,20 @@ def test_conv0_folded_statistics_equal_the_separate_launches_bit_for_bit(cuda, B
             stats = torch.full((B, C, 2), float("nan"), device=cuda)
             hip.check(Ld.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), stats.data_ptr(),
                                                ws.data_ptr(), B, S, C, k, stride, 1e-5, hip.BF16, hip.stream()), "conv0 fwd")
+            dW = torch.zeros(C, k, device=cuda); dG = torch.zeros(C, device=cuda); dB = torch.zeros(C, device=cuda)
+            hip.check(Ld.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), stats.data_ptr(), dY.data_ptr(),
+                                               dW.data_ptr(), dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), B, S, C, k, stride, 1.0, hip.BF16,
+                                               hip.stream()), "conv0 bwd")
             torch.cuda.synchronize()
-            res.append((out, stats))
+            res.append((out, stats, dW, dG, dB))
     finally:
         hip.check(Ld.st5_conv0_set_fold(1), "set_fold")
     assert torch.isfinite(res[1][0].float()).all() and torch.isfinite(res[1][1]).all()
     assert torch.equal(res[0][1], res[1][1]), "statistics"
     assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16)), "output"
+    # the backward: the fragment launch folds and publishes the waveform moments itself (no statistics launch) -- same bits
+    for i, nm in ((2, "dW"), (3, "dgamma"), (4, "dbeta")):
+        assert torch.isfinite(res[1][i]).all() and torch.equal(res[0][i], res[1][i]), nm
 
 
 @pytest.mark.parametrize("B,S,C,k", [(2, 6407, 128, 10), (1, 16000, 512, 10), (2, 4000, 256, 7), (1, 4000, 1024, 10)])   # (C = 1024: beyond the
