@@ -105,6 +105,38 @@ def test_conv0_gelu_table_error_bound():
     assert err[np.abs(zd) <= 4].max() <= 2e-5, err[np.abs(zd) <= 4].max()
 
 
+def test_conv0_gelu_grad_table_error_bound():
+    """conv0.hip gelu_grad_tab (the matrix-core backward of conv layer 0): gelu'(z) = Phi(z) + z phi(z) as 511 chords over [-4.35, 4.35],
+    an entry (value, rise) two floats, index = clamp(z scale + 255.5, 0, 511) -- restated in numpy with the constants parsed from the
+    source, against the exact derivative: |error| <= 3e-5 inside the table, <= 1.4e-4 beyond it (the end values stand in for 1 and 0) --
+    the polynomial it replaces: 1.2e-4 everywhere."""
+    import re
+    import numpy as np
+    from scipy.special import erfc
+    src = open(os.path.join(ROOT, "speecht5_amd", "csrc", "conv0.hip")).read()
+    R = float(re.search(r"C0_GG_R = (\d+\.\d+)f", src).group(1))
+    assert "C0_GG_SCALE = 511.f / (2.f * C0_GG_R), C0_GG_OFF = 255.5f" in src
+    assert "__builtin_amdgcn_fmed3f(fmaf(z, C0_GG_SCALE, C0_GG_OFF), 0.f, 511.f)" in src
+
+    def exact(x):
+        x = np.asarray(x, np.float64)
+        return 0.5 * erfc(-x / np.sqrt(2)) + x * np.exp(-0.5 * x * x) / np.sqrt(2 * np.pi)
+    h = np.float32(2 * R) / np.float32(511)
+    nodes = (np.float32(-R) + np.arange(513, dtype=np.float32) * h).astype(np.float32)
+    v = exact(nodes).astype(np.float32)
+    val, rise = v[:512].copy(), (v[1:513] - v[:512]).astype(np.float32)
+    rise[511] = 0
+    z = np.linspace(-8, 8, 1600001).astype(np.float32)
+    a = np.clip((z.astype(np.float64) * np.float32(511.0 / (2 * R)) + 255.5).astype(np.float32), 0, 511).astype(np.float32)
+    i = a.astype(np.int32)
+    fr = (a - np.floor(a)).astype(np.float32)
+    got = (fr.astype(np.float64) * rise[i] + val[i]).astype(np.float32).astype(np.float64)
+    err = np.abs(got - exact(z))
+    inside = np.abs(z) <= R
+    assert err[inside].max() <= 3e-5, err[inside].max()
+    assert err.max() <= 1.4e-4, err.max()
+
+
 def test_gelu_grad_poly_error_bound():
     """common.h gelu_grad_poly (derivative of GELU in the bf16 backward epilogues), restated in numpy from the parsed constants:
     |error| <= 1.3e-4 everywhere (the exact derivative lies in [-0.13, 1.13]; the factor multiplies bf16 operands)."""
