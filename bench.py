@@ -141,14 +141,16 @@ def conv0_device_time(device, B, reps=20):
     stats = torch.empty(B, C, 2, device=device)
     dw, dg, db = torch.zeros(C, k, device=device), torch.zeros(C, device=device), torch.zeros(C, device=device)
     ws = hip.workspace(L_.st5_conv0_ws_bytes(B, S, C, k, stride), device)
+    mom = torch.empty(B, L_.st5_conv0_mom_count(k), dtype=torch.float64, device=device)   # (as functional.ConvFeatureExtractorFunction calls them)
 
     def fwd():
-        hip.check(L_.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b_.data_ptr(), out.data_ptr(), stats.data_ptr(), ws.data_ptr(),
-                                            B, S, C, k, stride, 1e-5, hip.BF16, hip.stream()), "conv0 fwd")
+        hip.check(L_.st5_conv0_gn_gelu_fwd_m(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b_.data_ptr(), out.data_ptr(), stats.data_ptr(), mom.data_ptr(),
+                                              ws.data_ptr(), B, S, C, k, stride, 1e-5, hip.BF16, hip.stream()), "conv0 fwd")
 
     def bwd():
-        hip.check(L_.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b_.data_ptr(), stats.data_ptr(), dy.data_ptr(), dw.data_ptr(),
-                                            dg.data_ptr(), db.data_ptr(), ws.data_ptr(), B, S, C, k, stride, 1.0, hip.BF16, hip.stream()), "conv0 bwd")
+        hip.check(L_.st5_conv0_gn_gelu_bwd_m(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b_.data_ptr(), stats.data_ptr(), mom.data_ptr(), dy.data_ptr(),
+                                              dw.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), B, S, C, k, stride, 1.0, hip.BF16, hip.stream()),
+                  "conv0 bwd")
     res = {}
     for nm, fn in (("conv0_gn_gelu_fwd", fwd), ("conv0_gn_gelu_bwd", bwd)):
         for _ in range(3):

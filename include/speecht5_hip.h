@@ -290,6 +290,16 @@ int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const float* gamma, 
                           const float* stats, const void* dY, float* dw, float* dgamma, float* dbeta, void* ws,
                           int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride, float gscale, int dtype,
                           void* stream);
+/* The same pair with the waveform moments carried from the forward to the backward: `mom` = B x st5_conv0_mom_count(k) doubles (sum_t
+ * x[s t + j] and sum_t x[s t + j] x[s t + j'], j <= j' < k: what the GroupNorm backward needs of the waveform besides dY).  The forward
+ * publishes them (NULL: not), the backward given them skips its own pass over the waveform and the fold (two launches of ~17 us for 4 KB
+ * of results); NULL in the backward = st5_conv0_gn_gelu_bwd.  Same results bit for bit: the same kernels produce the same doubles. */
+int32_t st5_conv0_mom_count(int32_t k);
+int st5_conv0_gn_gelu_fwd_m(const float* wav, const float* w, const float* gamma, const float* beta, void* out, float* stats, double* mom,
+                            void* ws, int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride, float eps, int dtype, void* stream);
+int st5_conv0_gn_gelu_bwd_m(const float* wav, const float* w, const float* gamma, const float* beta, const float* stats, const double* mom,
+                            const void* dY, float* dw, float* dgamma, float* dbeta, void* ws, int32_t B, int32_t S, int32_t C, int32_t k,
+                            int32_t stride, float gscale, int dtype, void* stream);
 /* A/B switch of the bf16 forward apply pass: 1 (default) = convolution on the matrix cores with split-bf16 operands (x = xh + xl,
  * w = wh + wl; wh.xh + wh.xl + wl.xh in two v_mfma_f32_32x32x16_bf16 per 32 channels x 32 steps), 0 = the VALU form. */
 int st5_conv0_set_mfma(int on);

@@ -810,13 +810,13 @@ __host__ inline Ws carve(void* ws, int B, int nch, int C, int k) {
 
 // waveform moments (+ statistics when `stats` is given): two launches
 void launch_moments_stats(const float* wav, const float* w, float* stats, const Ws& W, int B, int S, int L, int C, int k, int stride, float eps,
-                          hipStream_t s, bool with_stats = true) {
+                          hipStream_t s, bool with_stats = true, double* mom = nullptr) {
   const int nchm = (L + TCM - 1) / TCM;
   const size_t shm2 = (size_t)(((TCM - 1) * stride + k + 8 + 3) & ~3) * sizeof(float);
   if (shm2 > 60 * 1024) return;      // (strides far beyond the recipe's 5: the caller rejects them, see st5_conv0_gn_gelu_fwd)
   if (k <= 10) hipLaunchKernelGGL((conv0_moments2_kernel<10>), dim3(nchm, B), dim3(256), shm2, s, wav, W.part, S, L, k, stride, nchm);
   else hipLaunchKernelGGL((conv0_moments2_kernel<MAXK>), dim3(nchm, B), dim3(256), shm2, s, wav, W.part, S, L, k, stride, nchm);
-  if (with_stats) hipLaunchKernelGGL(conv0_stats2_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, W.part, W.mom, w, stats, C, k, L, nchm, eps);
+  if (with_stats) hipLaunchKernelGGL(conv0_stats2_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, W.part, mom ? mom : W.mom, w, stats, C, k, L, nchm, eps);
 }
 
 }  // namespace
@@ -838,9 +838,16 @@ extern "C" int64_t st5_conv0_ws_bytes(int32_t B, int32_t S, int32_t C, int32_t k
          ((int64_t)B * nmom(k) + (int64_t)B * C * (MAXK + 2)) * (int64_t)sizeof(double) + 16 + (int64_t)B * C * 64;   // + MFMA weight fragments (per clip: the GroupNorm affine is folded in)
 }
 
+extern "C" int32_t st5_conv0_mom_count(int32_t k) { return k >= 1 && k <= MAXK ? nmom(k) : 0; }
+
 extern "C" int st5_conv0_gn_gelu_fwd(const float* wav, const float* w, const float* gamma, const float* beta,
                                      void* out, float* stats, void* ws, int32_t B, int32_t S, int32_t C, int32_t k,
                                      int32_t stride, float eps, int dtype, void* stream) {
+  return st5_conv0_gn_gelu_fwd_m(wav, w, gamma, beta, out, stats, nullptr, ws, B, S, C, k, stride, eps, dtype, stream);
+}
+extern "C" int st5_conv0_gn_gelu_fwd_m(const float* wav, const float* w, const float* gamma, const float* beta,
+                                       void* out, float* stats, double* mom, void* ws, int32_t B, int32_t S, int32_t C, int32_t k,
+                                       int32_t stride, float eps, int dtype, void* stream) {
   if (!wav || !w || !gamma || !beta || !out || !stats || !ws) return ST5_ERR_ARG;
   if (C % 8 || C > 2048 || 256 % (C / 8 > 256 ? 256 : C / 8) || k > MAXK || k < 1 || stride < 1 || stride > 7) return ST5_ERR_ARG;
   if (C / 8 > 256) return ST5_ERR_ARG;
@@ -853,7 +860,7 @@ extern "C" int st5_conv0_gn_gelu_fwd(const float* wav, const float* w, const flo
   const Ws W = carve(ws, B, nch, C, k);
   const bool mfma = dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 32 == 0 && C <= 1024;
   const bool fold = mfma && g_conv0_fold;
-  launch_moments_stats(wav, w, stats, W, B, S, L, C, k, stride, eps, s, !fold);
+  launch_moments_stats(wav, w, stats, W, B, S, L, C, k, stride, eps, s, !fold, mom);
 #define APPLY(TT, KW)                                                                                           \
   hipLaunchKernelGGL((conv0_apply_kernel<TT, KW>), dim3(nch, B), dim3(256), shm, s, wav, w, gamma, beta, stats, \
                      (TT*)out, S, L, C, k, stride)
@@ -868,7 +875,7 @@ extern "C" int st5_conv0_gn_gelu_fwd(const float* wav, const float* w, const flo
       attr = true;
     }
     if (fold) hipLaunchKernelGGL(conv0_stats_wfrag_kernel, dim3(C / 32, B), dim3(256), 0, s, (const float*)W.part, w, gamma, beta, (const float*)nullptr,
-                                 stats, (double*)nullptr, W.afrag, C, k, L, (L + TCM - 1) / TCM, eps);
+                                 stats, mom, W.afrag, C, k, L, (L + TCM - 1) / TCM, eps);
     else hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(C / 32, B), dim3(128), 0, s, w, gamma, beta, stats, W.afrag, C, k);
     if (g_conv0_gelu_tab)
       hipLaunchKernelGGL(conv0_apply_mfma_kernel<true>, dim3(nch, B), dim3(256), shm_m, s, wav, W.afrag, (bf16_t*)out, S, L, C, k, stride, seg_bytes);
@@ -885,6 +892,12 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
                                      const float* stats, const void* dY, float* dw, float* dgamma, float* dbeta,
                                      void* ws, int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride,
                                      float gscale, int dtype, void* stream) {
+  return st5_conv0_gn_gelu_bwd_m(wav, w, gamma, beta, stats, nullptr, dY, dw, dgamma, dbeta, ws, B, S, C, k, stride, gscale, dtype, stream);
+}
+extern "C" int st5_conv0_gn_gelu_bwd_m(const float* wav, const float* w, const float* gamma, const float* beta,
+                                       const float* stats, const double* mom, const void* dY, float* dw, float* dgamma, float* dbeta,
+                                       void* ws, int32_t B, int32_t S, int32_t C, int32_t k, int32_t stride,
+                                       float gscale, int dtype, void* stream) {
   if (!wav || !w || !gamma || !beta || !stats || !dY || !ws) return ST5_ERR_ARG;
   if (C % 8 || C / 8 > 256 || 256 % (C / 8) || k > MAXK || k < 1 || stride < 1 || stride > 7) return ST5_ERR_ARG;
   const int L = out_len(S, k, stride);
@@ -896,8 +909,9 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
   const Ws W = carve(ws, B, nch, C, k);
   // waveform moments again (0.64 MB/clip; cheaper than keeping them alive between forward and backward)
   const bool mfma = dtype == ST5_BF16 && g_conv0_mfma && k <= 10 && C % 128 == 0 && C <= 512 && TCH % 32 == 0;
-  const bool fold = mfma && g_conv0_fold;      // (the fragment launch folds and publishes the moments itself)
-  launch_moments_stats(wav, w, nullptr, W, B, S, L, C, k, stride, 0.f, s, !fold);
+  const bool fold = mfma && g_conv0_fold && !mom;      // (the fragment launch folds and publishes the moments itself)
+  // waveform moments: the forward's, when the caller kept them (B x nmom doubles); else once more from the waveform (0.64 MB / clip)
+  if (!mom) launch_moments_stats(wav, w, nullptr, W, B, S, L, C, k, stride, 0.f, s, !fold);
   const int KWv = k <= 10 ? 10 : MAXK, nv = KWv + 2;
   {   // ST5_POISON=1 (debug): the partials region is NaN before the backward kernel fills it -- a reduce that ran ahead of a
       // block of conv0_bwd_kernel, or a block that never stored, then shows as NaN instead of as last step's value
@@ -930,7 +944,7 @@ extern "C" int st5_conv0_gn_gelu_bwd(const float* wav, const float* w, const flo
   else { if (k <= 10) BWD(float, 10); else BWD(float, MAXK); }
 #undef BWD
   hipLaunchKernelGGL(conv0_bwd_reduce_kernel, dim3((C * nv + 31) / 32, B), dim3(256), 0, s, W.part, W.sums, C, nch, nv);
-  hipLaunchKernelGGL(conv0_bwd_final_kernel, dim3((C + 1) / 2), dim3(256), 0, s, W.sums, W.mom, w, gamma, stats, dw, dgamma,
+  hipLaunchKernelGGL(conv0_bwd_final_kernel, dim3((C + 1) / 2), dim3(256), 0, s, W.sums, mom ? mom : (const double*)W.mom, w, gamma, stats, dw, dgamma,
                      dbeta, B, C, k, L, nv, gscale, mfma ? 1 : 0);
   HIP_CHECK_LAUNCH();
   return ST5_OK;

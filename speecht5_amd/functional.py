@@ -2415,6 +2415,8 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
         L0 = (S - k0) // s0 + 1
         y = torch.empty(B, L0, C0, dtype=dtype, device=dev)
         stats = torch.empty(B, C0, 2, dtype=torch.float32, device=dev)
+        # the waveform moments travel to the backward with the statistics (B x 65 doubles): it then needs no pass over the waveform
+        mom = torch.empty(B, L.st5_conv0_mom_count(k0), dtype=torch.float64, device=dev)
         wsb = hip.workspace(L.st5_conv0_ws_bytes(B, S, C0, k0, s0), dev)
         w0f = w0.detach().reshape(C0, k0).contiguous()
         # the frontend AS A UNIT: algorithmic bytes = sum over layers of (input + output) once, GroupNorm / GELU
@@ -2432,9 +2434,9 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
         front_region.__enter__()
         # algorithmic HBM bytes: waveform in (fp32) + channels-last output once
         with hip.profiler.region("conv0_gn_gelu_fwd", B * S * 4 + B * L0 * C0 * y.element_size()):
-            hip.check(L.st5_conv0_gn_gelu_fwd(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), y.data_ptr(),
-                                              stats.data_ptr(), wsb.data_ptr(), B, S, C0, k0, s0, 1e-5, _dt(dtype), hip.stream()),
-                      "st5_conv0_gn_gelu_fwd")
+            hip.check(L.st5_conv0_gn_gelu_fwd_m(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), y.data_ptr(),
+                                                stats.data_ptr(), mom.data_ptr(), wsb.data_ptr(), B, S, C0, k0, s0, 1e-5, _dt(dtype),
+                                                hip.stream()), "st5_conv0_gn_gelu_fwd_m")
         acts, pres, lens = [y], [None], [L0]
         x, Lin, Cin = y, L0, C0
         for i, (C, k, s) in enumerate(layers[1:]):
@@ -2447,7 +2449,7 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
             acts.append(out); pres.append(pre); lens.append(Lo)
             x, Lin, Cin = out, Lo, C
         front_region.__exit__(None, None, None)
-        ctx.save_for_backward(wav, stats, *acts[:-1], *pres[1:])
+        ctx.save_for_backward(wav, stats, mom, *acts[:-1], *pres[1:])
         ctx.meta = (layers, gscale, w0, gn_w, gn_b, ws, lens, B, S)
         return x
 
@@ -2455,10 +2457,10 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
     def backward(ctx, dy):
         layers, gscale, w0, gn_w, gn_b, ws, lens, B, S = ctx.meta
         saved = ctx.saved_tensors
-        wav, stats = saved[0], saved[1]
+        wav, stats, mom = saved[0], saved[1], saved[2]
         n = len(layers)
-        acts = saved[2:2 + n - 1]          # outputs of layers 0..n-2 (inputs of layers 1..n-1)
-        pres = (None,) + tuple(saved[2 + n - 1:])  # pre-activations of layers 1..n-1
+        acts = saved[3:3 + n - 1]          # outputs of layers 0..n-2 (inputs of layers 1..n-1)
+        pres = (None,) + tuple(saved[3 + n - 1:])  # pre-activations of layers 1..n-1
         dtype = dy.dtype
         dev = dy.device
         L = hip.lib()
@@ -2544,10 +2546,11 @@ class ConvFeatureExtractorFunction(torch.autograd.Function):
             gw0 = grad_buffer(w0) if w0.requires_grad else None
             # algorithmic HBM bytes: waveform + ONE read of dY (the kernels read dY twice: GroupNorm sums, then dW)
             with hip.profiler.region("conv0_gn_gelu_bwd", B * S * 4 + dpre.numel() * dpre.element_size()):
-                hip.check(L.st5_conv0_gn_gelu_bwd(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), stats.data_ptr(),
-                                                  dpre.data_ptr(), hip.ptr(gw0), hip.ptr(grad_buffer(gn_w)) if gn_w.requires_grad else 0,
-                                                  hip.ptr(grad_buffer(gn_b)) if gn_b.requires_grad else 0, wsb.data_ptr(), B, S, C0, k0, s0,
-                                                  1.0, _dt(dtype), hip.stream()), "st5_conv0_gn_gelu_bwd")
+                hip.check(L.st5_conv0_gn_gelu_bwd_m(wav.data_ptr(), w0f.data_ptr(), gn_w.data_ptr(), gn_b.data_ptr(), stats.data_ptr(),
+                                                    mom.data_ptr(), dpre.data_ptr(), hip.ptr(gw0),
+                                                    hip.ptr(grad_buffer(gn_w)) if gn_w.requires_grad else 0,
+                                                    hip.ptr(grad_buffer(gn_b)) if gn_b.requires_grad else 0, wsb.data_ptr(), B, S, C0, k0, s0,
+                                                    1.0, _dt(dtype), hip.stream()), "st5_conv0_gn_gelu_bwd_m")
             for p in (w0, gn_w, gn_b):
                 if p.requires_grad:
                     _grad_done(p)

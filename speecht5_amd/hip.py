@@ -105,6 +105,12 @@ _SIGS = {
     "st5_conv0_gn_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int,
                                       c_void_p]),
+    "st5_conv0_gn_gelu_fwd_m": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                        c_int32, c_int32, c_int32, c_int32, c_float, c_int, c_void_p]),
+    "st5_conv0_gn_gelu_bwd_m": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int,
+                                        c_void_p]),
+    "st5_conv0_mom_count": (c_int32, [c_int32]),
     "st5_conv0_ws_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "st5_conv0_set_mfma": (c_int, [c_int]),
     "st5_conv0_set_fold": (c_int, [c_int]),

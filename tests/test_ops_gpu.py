@@ -541,6 +541,23 @@ def test_conv0_folded_statistics_equal_the_separate_launches_bit_for_bit(cuda, B
     # the backward: the fragment launch folds and publishes the waveform moments itself (no statistics launch) -- same bits
     for i, nm in ((2, "dW"), (3, "dgamma"), (4, "dbeta")):
         assert torch.isfinite(res[1][i]).all() and torch.equal(res[0][i], res[1][i]), nm
+    # ... and with the moments carried over from the forward (st5_conv0_gn_gelu_fwd_m / _bwd_m: no pass over the waveform at all)
+    out = torch.full((B, Lo, C), float("nan"), dtype=torch.bfloat16, device=cuda)
+    stats = torch.full((B, C, 2), float("nan"), device=cuda)
+    mom = torch.full((B, Ld.st5_conv0_mom_count(k)), float("nan"), dtype=torch.float64, device=cuda)
+    assert mom.shape[1] == k + k * (k + 1) // 2
+    hip.check(Ld.st5_conv0_gn_gelu_fwd_m(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                                         mom.data_ptr(), ws.data_ptr(), B, S, C, k, stride, 1e-5, hip.BF16, hip.stream()), "conv0 fwd_m")
+    ws.view(torch.uint8).fill_(0xFF)        # (nothing of the forward's workspace may be needed)
+    dW = torch.zeros(C, k, device=cuda); dG = torch.zeros(C, device=cuda); dB = torch.zeros(C, device=cuda)
+    hip.check(Ld.st5_conv0_gn_gelu_bwd_m(wav.data_ptr(), w.data_ptr(), g.data_ptr(), b.data_ptr(), stats.data_ptr(), mom.data_ptr(),
+                                         dY.data_ptr(), dW.data_ptr(), dG.data_ptr(), dB.data_ptr(), ws.data_ptr(), B, S, C, k, stride, 1.0,
+                                         hip.BF16, hip.stream()), "conv0 bwd_m")
+    torch.cuda.synchronize()
+    assert torch.isfinite(mom).all()
+    assert torch.equal(out.view(torch.int16), res[1][0].view(torch.int16)) and torch.equal(stats, res[1][1])
+    for t, i, nm in ((dW, 2, "dW"), (dG, 3, "dgamma"), (dB, 4, "dbeta")):
+        assert torch.equal(t, res[1][i]), nm
 
 
 @pytest.mark.parametrize("B,S,C,k", [(2, 6407, 128, 10), (1, 16000, 512, 10), (2, 4000, 256, 7), (1, 4000, 1024, 10)])   # (C = 1024: beyond the
