@@ -1,5 +1,6 @@
 // Element-wise, gather/scatter and small reduction kernels of the SpeechT5 hot path (HBM-bound;
 // 16-byte vector IO, grid-stride).  Each replaces a torch call site cited in include/speecht5_hip.h.
+#include <mutex>
 #include "common.h"
 #include "../../include/speecht5_hip.h"
 
@@ -786,17 +787,31 @@ extern "C" int st5_masked_fill_rows_bwd(void* dx, const uint8_t* mask, float* dv
   const unsigned ny = (unsigned)(rows < 256 ? rows : 256);
   dim3 grid((unsigned)((cols + 255) / 256), ny);
   float* part = nullptr;
-  if (dv) {   // grow-only partial buffer [256][cols] (first use / growth happens outside stream capture)
-    static float* g_part = nullptr;
-    static size_t g_part_n = 0;
-    const size_t want = (size_t)256 * cols;
-    if (want > g_part_n) {
-      if (g_part) (void)hipFree(g_part);
-      g_part = nullptr; g_part_n = 0;
-      if (st5_dev_malloc(&g_part, want * sizeof(float)) != hipSuccess) return ST5_ERR_LAUNCH;
-      g_part_n = want;
+  if (dv) {   // grow-only partial buffer [256][cols] PER STREAM (first use / growth happens outside stream capture): one buffer for the
+    // whole process would be shared by two micro-batches whose backward passes run side by side on two streams
+    struct Part { hipStream_t s; float* p; size_t n; };
+    static Part g_parts[16] = {};
+    static int g_nparts = 0;
+    static std::mutex g_mu;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Part* e = nullptr;
+    for (int i = 0; i < g_nparts; ++i)
+      if (g_parts[i].s == s) e = &g_parts[i];
+    if (!e) {
+      if (g_nparts == 16) {      // (more streams than slots: recycle the first slot; hipFree waits for the device)
+        if (g_parts[0].p) (void)hipFree(g_parts[0].p);
+        e = &g_parts[0];
+      } else e = &g_parts[g_nparts++];
+      e->s = s; e->p = nullptr; e->n = 0;
     }
-    part = g_part;
+    const size_t want = (size_t)256 * cols;
+    if (want > e->n) {
+      if (e->p) (void)hipFree(e->p);
+      e->p = nullptr; e->n = 0;
+      if (st5_dev_malloc(&e->p, want * sizeof(float)) != hipSuccess) return ST5_ERR_LAUNCH;
+      e->n = want;
+    }
+    part = e->p;
   }
   DISPATCH(dtype, hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)dx, mask, part, (long long)rows, cols),
            hipLaunchKernelGGL(masked_fill_rows_bwd_kernel<float>, grid, dim3(256), 0, s, (float*)dx, mask, part, (long long)rows, cols));
