@@ -25,6 +25,9 @@ import torch.distributed as dist
 from . import functional as Fn
 
 
+
+_SBS_STREAM_POOL = {}   # (device index, priority, position) -> the second micro-batch's stream, shared by every wrapper of the process
+
 class _Trigger(torch.autograd.Function):
     """Identity whose backward tells the owner that every gradient produced by the graph BEHIND this point (the layers
     that run after it in the forward) is complete for this backward pass."""
@@ -348,8 +351,20 @@ class FlatGradDataParallel:
             # ST5_SBS_PRIORITY (A/B): HIP priority of the second micro-batch's stream (-1 = high).  The text micro-batch is the longer
             # chain (8.1 against 4.75 TFLOP): whatever it gains while both are resident comes off the update's critical path.
             prio = int(os.environ.get("ST5_SBS_PRIORITY", "0"))
-            self._fwd_streams.append(cur if os.environ.get("ST5_SERIAL_MICRO") == "1"
-                                     else torch.cuda.Stream(device=self.flat.device, priority=prio))
+            # The stream comes from a process-wide pool (one per device, priority and position), not from a fresh torch.cuda.Stream()
+            # per wrapper: the library keeps per-stream state in small tables keyed by the stream handle (8 split-K slab workspaces,
+            # 32 deferred-reduction and LayerNorm states, csrc/gemm.hip / norm.hip) whose recycling paths are for streams that come and
+            # go -- a process that builds many wrappers (a test session) walked torch's pool of 32 streams through them
+            # (profiles/r6b_side_by_side_flake.txt).  ST5_SBS_STREAM_POOL=0 restores a stream per wrapper (A/B).
+            if os.environ.get("ST5_SERIAL_MICRO") == "1":
+                self._fwd_streams.append(cur)
+            elif os.environ.get("ST5_SBS_STREAM_POOL", "1") == "0":
+                self._fwd_streams.append(torch.cuda.Stream(device=self.flat.device, priority=prio))
+            else:
+                key = (self.flat.device.index, prio, len(self._fwd_streams))
+                if key not in _SBS_STREAM_POOL:
+                    _SBS_STREAM_POOL[key] = torch.cuda.Stream(device=self.flat.device, priority=prio)
+                self._fwd_streams.append(_SBS_STREAM_POOL[key])
         if n > 1 and self.flat2 is None:
             # the second gradient buffer is created (and zero-filled) HERE, on the current stream, before the streams fork: created
             # lazily inside the second backward it was zero-filled on this stream while the other stream already accumulated into it
